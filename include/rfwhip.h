@@ -1,0 +1,149 @@
+/*
+ * rfwhip.h — C ABI of the MI355X-native (gfx950, HIP) wavefront rendercore for MeirBon/rendering-fw.
+ *
+ * This is the drop-in boundary: a `rfw::RenderContext` plugin (RFW/system/context/rfw/context/context.h:74-111)
+ * forwards each virtual call to the entry point listed beside it below; `rendering-fw_amd/csrc/plugin/HipRT.cpp`
+ * is that plugin, and INTEGRATION.md shows the binding.  Only PODs from rfwhip_abi.h, plain pointers and sizes
+ * cross this boundary; errors are int codes + rfwhip_last_error() (the reference throws std::runtime_error across
+ * the .so boundary, context.h:84-91 — the plugin shim re-throws).  Every pointer argument is borrowed for the call
+ * only: the core uploads into HBM inside the call and never dereferences host memory later (contrast
+ * EmbreeRT/src/Mesh.cpp:29,46 which keeps shared buffers).
+ *
+ * All calls for one context must come from one thread at a time (RFW/system/src/rfw/app.cpp:15-16).
+ */
+#ifndef RFWHIP_H
+#define RFWHIP_H
+
+#include "rfwhip_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFWHIP_API __attribute__((visibility("default")))
+
+typedef struct rfwhip_context rfwhip_context;
+
+enum rfwhip_status
+{
+	RFWHIP_OK = 0,
+	RFWHIP_ERR_INVALID_ARGUMENT = 1,
+	RFWHIP_ERR_NO_DEVICE = 2, /* no HIP device / kernel image not loadable: the core never falls back to a CPU path */
+	RFWHIP_ERR_HIP = 3,
+	RFWHIP_ERR_STATE = 4,
+	RFWHIP_ERR_UNSUPPORTED = 5
+};
+
+/* Thread-local description of the last failure of any rfwhip_* call on this thread. */
+RFWHIP_API const char *rfwhip_last_error(void);
+RFWHIP_API const char *rfwhip_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------
+ * createRenderContext / destroyRenderContext   (RFW/system/context/rfw/context/export.h:8-15)
+ * rank/world: this process renders the image rows whose 8-row strip index s satisfies s % world == rank
+ * (SURVEY §8e); world = 1 renders everything. */
+RFWHIP_API int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_context **out);
+/* RenderContext::cleanup() (context.h:93).  Idempotent: the reference calls it twice on unload
+ * (system.cpp:160-178 + EmbreeRT/src/Context.cpp:30). */
+RFWHIP_API int rfwhip_cleanup(rfwhip_context *ctx);
+RFWHIP_API void rfwhip_destroy(rfwhip_context *ctx);
+
+/* RenderContext::init(GLuint*, uint width, uint height) (context.h:88) with the headless BUFFER target
+ * (RenderTarget::BUFFER, context.h:27-34); may be called again on resize (app.cpp:44-59). */
+RFWHIP_API int rfwhip_init(rfwhip_context *ctx, uint32_t width, uint32_t height);
+
+/* ---- scene synchronisation, in the order rfw::system::synchronize issues them (system.cpp:247-433) ----------- */
+/* set_sky(const std::vector<glm::vec3>&, size_t w, size_t h)                               context.h:100 */
+RFWHIP_API int rfwhip_set_sky(rfwhip_context *ctx, const float *rgb, size_t width, size_t height);
+/* set_textures(const std::vector<TextureData>&)                                            context.h:97 */
+RFWHIP_API int rfwhip_set_textures(rfwhip_context *ctx, const rfwhip_texture *textures, size_t count);
+/* set_materials(const std::vector<DeviceMaterial>&, const std::vector<MaterialTexIds>&)    context.h:95-96 */
+RFWHIP_API int rfwhip_set_materials(rfwhip_context *ctx, const rfwhip_material *materials,
+									const rfwhip_material_tex_ids *tex_ids, size_t count);
+/* set_mesh(size_t index, const Mesh&): same vertexCount as before => refit, else rebuild    context.h:98,
+ * EmbreeRT/src/Mesh.cpp:33-35, bvh/src/top_level_bvh.cpp:26 */
+RFWHIP_API int rfwhip_set_mesh(rfwhip_context *ctx, size_t index, const rfwhip_mesh *mesh);
+/* set_instance(size_t i, size_t meshIdx, const mat4& transform, const mat3& inverse_transform)
+ * transform: column-major 4x4 object->world; normal_matrix: column-major 3x3 inverse-transpose
+ * (system.cpp:347).                                                                          context.h:99 */
+RFWHIP_API int rfwhip_set_instance(rfwhip_context *ctx, size_t index, size_t mesh_index, const float *transform16,
+								   const float *normal_matrix9);
+/* set_lights(LightCount, area*, point*, spot*, directional*)                                context.h:101-103 */
+RFWHIP_API int rfwhip_set_lights(rfwhip_context *ctx, rfwhip_light_count count, const rfwhip_area_light *area,
+								 const rfwhip_point_light *point, const rfwhip_spot_light *spot,
+								 const rfwhip_directional_light *directional);
+/* update(): once after a batch of set_* — builds the TLAS, uploads descriptors              context.h:108 */
+RFWHIP_API int rfwhip_update(rfwhip_context *ctx);
+
+/* ---- per-frame ---------------------------------------------------------------------------------------------- */
+/* Camera::get_view() (Camera.cpp:74-88) as a free function; pure host arithmetic. */
+RFWHIP_API void rfwhip_camera_get_view(const rfwhip_camera *camera, rfwhip_camera_view *view);
+/* render_frame(const Camera&, RenderStatus) (context.h:94).  Enqueues `spp` samples per pixel on the context's
+ * HIP stream and returns without a host sync; RESET clears the accumulator and the sample index, CONVERGE
+ * accumulates (context.h:19-23, CUDART/src/Context.cpp:75-80). */
+RFWHIP_API int rfwhip_render(rfwhip_context *ctx, const rfwhip_camera *camera, int status);
+/* Block until every enqueued render has finished (the reference's render_frame ends with glFinish /
+ * cudaDeviceSynchronize: the plugin shim calls rfwhip_render + rfwhip_wait). Resolves stage timings. */
+RFWHIP_API int rfwhip_wait(rfwhip_context *ctx);
+
+/* Present: accumulator / samples -> float4 RGBA rows, row 0 = top image row.
+ * Full image on this rank (world == 1), host or device destination of width*height*4 floats. */
+RFWHIP_API int rfwhip_read_framebuffer(rfwhip_context *ctx, float *rgba_host);
+RFWHIP_API int rfwhip_read_framebuffer_device(rfwhip_context *ctx, void *rgba_device);
+/* Multi-GPU: this rank's strips, compacted, padded to rfwhip_local_rows() rows (same on every rank). */
+RFWHIP_API uint32_t rfwhip_local_rows(const rfwhip_context *ctx);
+RFWHIP_API int rfwhip_read_local_framebuffer_device(rfwhip_context *ctx, void *rgba_device);
+/* Root-side inverse of the strip interleave: gathered = [world][local_rows][width] float4 -> [height][width]. */
+RFWHIP_API int rfwhip_deinterleave_device(rfwhip_context *ctx, const void *gathered_device, void *rgba_device);
+
+/* get_probe_results / set_probe_index                                                       context.h:104,109 */
+RFWHIP_API int rfwhip_set_probe_index(rfwhip_context *ctx, uint32_t x, uint32_t y);
+RFWHIP_API int rfwhip_get_probe_results(rfwhip_context *ctx, uint32_t *instance_index, uint32_t *primitive_index,
+										float *distance);
+/* get_stats()                                                                               context.h:110 */
+RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats);
+
+/* get_settings / set_setting (context.h:106-107). Keys:
+ *   integrator   = "parity" (restates EmbreeRT/src/Context.cpp:104-300) | "pt" (CUDART/src/Kernels.cu:571-794)
+ *   spp          = samples per pixel enqueued by one rfwhip_render call (default 1)
+ *   max_depth    = MAX_PATH_LENGTH of the pt integrator (settings.h:5, default 2)
+ *   jitter       = "xor128" (EmbreeRT: rfw::utils::xor128 stream) | "center" (r0=r1=0.5) — parity integrator only
+ *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)
+ *   count_traversal = "0"|"1": instrumented traversal (popped inner nodes / triangle tests), for the roofline
+ *   lds_nodes    = number of top-of-tree BVH node pairs staged in LDS per workgroup (0 disables)
+ * Returns the number of keys; fills up to cap pointers with static strings. */
+RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
+RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);
+RFWHIP_API int rfwhip_get_settings(rfwhip_context *ctx, const char **keys, size_t cap);
+
+/* ---- measurement hooks (bench / tests; not part of the reference interface) ---------------------------------- */
+typedef struct rfwhip_counters
+{
+	uint64_t rays_extend;	 /* closest-hit rays traced since the last reset (primary + extension) */
+	uint64_t rays_shadow;	 /* any-hit rays traced */
+	uint64_t inner_extend;	 /* popped inner nodes (each loads both 32 B children), closest-hit rays */
+	uint64_t tris_extend;	 /* triangle tests, closest-hit rays */
+	uint64_t inner_shadow;
+	uint64_t tris_shadow;
+	uint64_t shaded;		 /* shade-kernel invocations with a hit */
+	uint64_t samples;		 /* pixel samples started */
+} rfwhip_counters;
+RFWHIP_API int rfwhip_get_counters(rfwhip_context *ctx, rfwhip_counters *out, int reset);
+
+/* Accumulated hipEvent time (ms) and launch count per kernel family since the last reset; requires
+ * stage_timing=1.  which: 0 generate, 1 extend, 2 shade, 3 connect, 4 finalize, 5 refit. */
+RFWHIP_API int rfwhip_get_kernel_time(rfwhip_context *ctx, int which, float *ms, uint32_t *launches, int reset);
+
+/* Raw closest-hit records of the most recent primary wave (parity tests): per pixel of this rank's local image
+ * t (1e34 = miss), primID, instID, u, v. Any pointer may be NULL. */
+RFWHIP_API int rfwhip_read_primary_hits(rfwhip_context *ctx, float *t, int32_t *prim, int32_t *inst, float *u,
+										float *v);
+
+/* BVH of mesh `index` as built on the device side (bvh_node.h layout) + its primitive order. */
+RFWHIP_API int rfwhip_get_bvh(rfwhip_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,
+							  uint32_t *prim_indices, size_t prim_cap, size_t *node_count, size_t *prim_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFWHIP_H */

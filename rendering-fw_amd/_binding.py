@@ -1,0 +1,209 @@
+"""Host-side mirror of rfw::RenderContext (RFW/system/context/rfw/context/context.h:74-111) over a C ABI.
+
+`CoreBinding` speaks to any shared library that exports the entry points of include/rfwhip.h under a given prefix.
+The product instantiates it with librfwhip.so / "rfwhip_" (context.py); the test oracle re-uses it with its own
+library and prefix.  Method names, argument meaning and error behaviour follow the reference interface: failures
+raise RuntimeError (the reference throws std::runtime_error across the plugin boundary, context.h:84-91).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class CoreBinding:
+    def __init__(self, lib, prefix, device=0, rank=0, world=1):
+        self._lib = lib
+        self._p = prefix
+        self._ctx = C.c_void_p()
+        self._declare()
+        self._check(self._fn("create")(int(device), int(rank), int(world), C.byref(self._ctx)))
+        self.rank, self.world = rank, world
+        self.width = self.height = 0
+
+    # ---- plumbing -------------------------------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _has(self, name):
+        return hasattr(self._lib, self._p + name)
+
+    def _declare(self):
+        vp, sz, u32, i32, fp = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_float
+        sig = {
+            "last_error": (C.c_char_p, []),
+            "create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+            "cleanup": (i32, [vp]),
+            "destroy": (None, [vp]),
+            "init": (i32, [vp, u32, u32]),
+            "set_sky": (i32, [vp, vp, sz, sz]),
+            "set_textures": (i32, [vp, vp, sz]),
+            "set_materials": (i32, [vp, vp, vp, sz]),
+            "set_mesh": (i32, [vp, sz, C.POINTER(abi.Mesh)]),
+            "set_instance": (i32, [vp, sz, sz, vp, vp]),
+            "set_lights": (i32, [vp, abi.LightCount, vp, vp, vp, vp]),
+            "update": (i32, [vp]),
+            "camera_get_view": (None, [C.POINTER(abi.CameraPOD), C.POINTER(abi.CameraView)]),
+            "render": (i32, [vp, C.POINTER(abi.CameraPOD), i32]),
+            "wait": (i32, [vp]),
+            "read_framebuffer": (i32, [vp, vp]),
+            "local_rows": (u32, [vp]),
+            "set_probe_index": (i32, [vp, u32, u32]),
+            "get_probe_results": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(fp)]),
+            "get_stats": (i32, [vp, C.POINTER(abi.RenderStats)]),
+            "set_setting": (i32, [vp, C.c_char_p, C.c_char_p]),
+            "read_primary_hits": (i32, [vp, vp, vp, vp, vp, vp]),
+            "get_bvh": (i32, [vp, sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        }
+        for name, (res, args) in sig.items():
+            f = self._fn(name)
+            f.restype, f.argtypes = res, args
+
+    def _check(self, code):
+        if code != 0:
+            msg = self._fn("last_error")()
+            raise RuntimeError((msg or b"unknown error").decode(errors="replace"))
+
+    # ---- rfw::RenderContext ------------------------------------------------------------------------------------------
+    def get_supported_targets(self):
+        return ["BUFFER"]  # RenderTarget::BUFFER, context.h:27-34
+
+    def init(self, width, height):
+        self._check(self._fn("init")(self._ctx, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def cleanup(self):
+        if self._ctx:
+            self._check(self._fn("cleanup")(self._ctx))
+
+    def destroy(self):
+        if self._ctx:
+            self._fn("destroy")(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def render_frame(self, camera, status=abi.RESET):
+        """render_frame(const Camera&, RenderStatus): synchronous like the reference (glFinish at the end)."""
+        self.render_async(camera, status)
+        self.wait()
+
+    def render_async(self, camera, status=abi.RESET):
+        pod = camera.pod() if hasattr(camera, "pod") else camera
+        self._check(self._fn("render")(self._ctx, C.byref(pod), int(status)))
+
+    def wait(self):
+        self._check(self._fn("wait")(self._ctx))
+
+    def set_materials(self, materials, tex_ids=None):
+        m = np.ascontiguousarray(materials, dtype=abi.MATERIAL_DTYPE)
+        if tex_ids is None:
+            tex_ids = np.full(len(m), -1, dtype=np.int32).repeat(11).reshape(len(m), 11).view(abi.MATERIAL_TEX_IDS_DTYPE)
+        t = np.ascontiguousarray(tex_ids)
+        self._check(self._fn("set_materials")(self._ctx, m.ctypes.data, t.ctypes.data, len(m)))
+
+    def set_textures(self, textures):
+        """textures: list of dicts {type, width, height, data(np.ndarray)}; data may include appended mip levels."""
+        arr = (abi.Texture * max(1, len(textures)))()
+        keep = []
+        for i, t in enumerate(textures):
+            data = np.ascontiguousarray(t["data"])
+            keep.append(data)
+            per = 4 if t["type"] == abi.TEX_FLOAT4 else 1
+            arr[i] = abi.Texture(t["type"], t["width"], t["height"], data.size // per, 0, 0, data.ctypes.data)
+        self._check(self._fn("set_textures")(self._ctx, C.cast(arr, C.c_void_p), len(textures)))
+
+    def set_mesh(self, index, vertices, triangles, indices=None):
+        v = _f32(vertices).reshape(-1, 4)
+        tr = np.ascontiguousarray(triangles, dtype=abi.TRIANGLE_DTYPE)
+        idx = None if indices is None else np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        m = abi.Mesh(v.ctypes.data, None, None, tr.ctypes.data, None if idx is None else idx.ctypes.data, len(v), len(tr))
+        self._check(self._fn("set_mesh")(self._ctx, int(index), C.byref(m)))
+
+    def set_instance(self, i, mesh_idx, transform, normal_matrix=None):
+        """transform: 4x4 in maths (row, col) convention; sent column-major like glm::mat4.  normal_matrix defaults to
+        the inverse-transpose of the upper 3x3 (system.cpp:347)."""
+        t = np.asarray(transform, dtype=np.float64).reshape(4, 4)
+        if normal_matrix is None:
+            normal_matrix = np.linalg.inv(t[:3, :3]).T
+        n = np.asarray(normal_matrix, dtype=np.float64).reshape(3, 3)
+        tc, nc = _f32(t.T).ravel(), _f32(n.T).ravel()
+        self._check(self._fn("set_instance")(self._ctx, int(i), int(mesh_idx), tc.ctypes.data, nc.ctypes.data))
+
+    def set_sky(self, pixels, width, height):
+        p = _f32(pixels).reshape(-1, 3)
+        assert len(p) == width * height
+        self._check(self._fn("set_sky")(self._ctx, p.ctypes.data, int(width), int(height)))
+
+    def set_lights(self, area=None, point=None, spot=None, directional=None):
+        def prep(a, dt):
+            a = np.zeros(0, dtype=dt) if a is None else np.ascontiguousarray(a, dtype=dt)
+            return a, (a.ctypes.data if len(a) else None)
+
+        a, pa = prep(area, abi.AREA_LIGHT_DTYPE)
+        p, pp = prep(point, abi.POINT_LIGHT_DTYPE)
+        s, ps = prep(spot, abi.SPOT_LIGHT_DTYPE)
+        d, pd = prep(directional, abi.DIRECTIONAL_LIGHT_DTYPE)
+        self._check(self._fn("set_lights")(self._ctx, abi.LightCount(len(a), len(p), len(s), len(d)), pa, pp, ps, pd))
+
+    def get_probe_results(self):
+        inst, prim, dist = C.c_uint32(), C.c_uint32(), C.c_float()
+        self._check(self._fn("get_probe_results")(self._ctx, C.byref(inst), C.byref(prim), C.byref(dist)))
+        return inst.value, prim.value, dist.value
+
+    def set_probe_index(self, x, y):
+        self._check(self._fn("set_probe_index")(self._ctx, int(x), int(y)))
+
+    def set_setting(self, key, value):
+        self._check(self._fn("set_setting")(self._ctx, str(key).encode(), str(value).encode()))
+
+    def update(self):
+        self._check(self._fn("update")(self._ctx))
+
+    def get_stats(self):
+        s = abi.RenderStats()
+        self._check(self._fn("get_stats")(self._ctx, C.byref(s)))
+        return s
+
+    # ---- headless BUFFER target + test hooks ----------------------------------------------------------------------
+    def camera_view(self, camera):
+        v = abi.CameraView()
+        pod = camera.pod() if hasattr(camera, "pod") else camera
+        self._fn("camera_get_view")(C.byref(pod), C.byref(v))
+        return v
+
+    def framebuffer(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._fn("read_framebuffer")(self._ctx, out.ctypes.data))
+        return out
+
+    def local_rows(self):
+        return int(self._fn("local_rows")(self._ctx))
+
+    def primary_hits(self):
+        n = self.width * self.height
+        t, u, v = (np.empty(n, np.float32) for _ in range(3))
+        prim, inst = np.empty(n, np.int32), np.empty(n, np.int32)
+        self._check(self._fn("read_primary_hits")(self._ctx, t.ctypes.data, prim.ctypes.data, inst.ctypes.data,
+                                                   u.ctypes.data, v.ctypes.data))
+        shp = (self.height, self.width)
+        return {"t": t.reshape(shp), "prim": prim.reshape(shp), "inst": inst.reshape(shp), "u": u.reshape(shp),
+                "v": v.reshape(shp)}
+
+    def get_bvh(self, mesh_index):
+        nn, np_ = C.c_size_t(), C.c_size_t()
+        self._check(self._fn("get_bvh")(self._ctx, int(mesh_index), None, 0, None, 0, C.byref(nn), C.byref(np_)))
+        nodes = np.zeros(nn.value, dtype=abi.BVH_NODE_DTYPE)
+        prims = np.zeros(np_.value, dtype=np.uint32)
+        self._check(self._fn("get_bvh")(self._ctx, int(mesh_index), nodes.ctypes.data, len(nodes), prims.ctypes.data,
+                                        len(prims), C.byref(nn), C.byref(np_)))
+        return nodes, prims

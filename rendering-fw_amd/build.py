@@ -1,0 +1,72 @@
+"""In-tree build of the native pieces with hipcc for gfx950 (no CMake, no JIT cache: the .so files must travel to the
+GPU box with the repository snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+CORE_SOURCES = ["rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + INCLUDE, "-I" + CSRC,
+          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".hpp"))]
+    d += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    pdir = os.path.join(CSRC, "plugin")
+    if os.path.isdir(pdir):
+        for root, _, files in os.walk(pdir):
+            d += [os.path.join(root, f) for f in files]
+    return d
+
+
+def build(force=False, verbose=False):
+    """Compile librfwhip.so (core + C ABI) and HipRT.so (the rfw::RenderContext plugin). Returns the paths."""
+    deps = _deps()
+    outs = []
+    core = os.path.join(HERE, "librfwhip.so")
+    if force or _stale(core, deps):
+        objs = []
+        for src in CORE_SOURCES:
+            obj = os.path.join(CSRC, src + ".o")
+            cmd = [HIPCC] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if src.endswith(".hip"):
+                cmd += ["-x", "hip"] if False else []
+            _run(cmd, verbose)
+            objs.append(obj)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", core, "-lpthread"], verbose)
+    outs.append(core)
+    plugin_src = os.path.join(CSRC, "plugin", "HipRT.cpp")
+    if os.path.exists(plugin_src):
+        plugin = os.path.join(HERE, "HipRT.so")  # no "lib" prefix: system.cpp:119-121 dlopens "<Name>.so"
+        if force or _stale(plugin, deps + [core]):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + INCLUDE,
+                  "-I" + os.path.join(CSRC, "plugin"), plugin_src, "-o", plugin, "-L" + HERE, "-lrfwhip",
+                  "-Wl,-rpath,$ORIGIN"], verbose)
+        outs.append(plugin)
+    return outs
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("native build failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+    if verbose and r.stdout.strip():
+        print(r.stdout, file=sys.stderr)
+
+
+if __name__ == "__main__":
+    print("\n".join(build(force="--force" in sys.argv, verbose=True)))

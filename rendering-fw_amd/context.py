@@ -1,0 +1,80 @@
+"""RenderContext over librfwhip.so — the HIP rendercore behind the reference's plugin interface
+(RFW/system/context/rfw/context/context.h:74-111).  There is no CPU path: if the library or a HIP device is missing
+the constructor raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from ._binding import CoreBinding
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librfwhip.so")
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree librfwhip.so (RTLD_GLOBAL is not needed; HIP is linked in)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librfwhip.so is missing (%s): build it with __graft_entry__.build(); "
+                "the rendercore has no fallback path" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+class RenderContext(CoreBinding):
+    def __init__(self, device=0, rank=0, world=1):
+        super().__init__(load_library(), "rfwhip_", device, rank, world)
+        vp, u32, i32, fp = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+        for name, res, args in [
+            ("read_framebuffer_device", i32, [vp, vp]),
+            ("read_local_framebuffer_device", i32, [vp, vp]),
+            ("deinterleave_device", i32, [vp, vp, vp]),
+            ("get_counters", i32, [vp, C.POINTER(abi.Counters), i32]),
+            ("get_kernel_time", i32, [vp, i32, C.POINTER(fp), C.POINTER(u32), i32]),
+            ("get_setting", i32, [vp, C.c_char_p, C.c_char_p, C.c_size_t]),
+            ("get_settings", i32, [vp, C.POINTER(C.c_char_p), C.c_size_t]),
+            ("version", C.c_char_p, []),
+        ]:
+            f = self._fn(name)
+            f.restype, f.argtypes = res, args
+
+    # ---- device-side presents (torch tensors hand over data_ptr()) ---------------------------------------------------
+    def read_framebuffer_device(self, device_ptr):
+        self._check(self._fn("read_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
+
+    def read_local_framebuffer_device(self, device_ptr):
+        self._check(self._fn("read_local_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
+
+    def deinterleave_device(self, gathered_ptr, out_ptr):
+        self._check(self._fn("deinterleave_device")(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr)))
+
+    # ---- measurement hooks -------------------------------------------------------------------------------------------
+    def get_counters(self, reset=False):
+        c = abi.Counters()
+        self._check(self._fn("get_counters")(self._ctx, C.byref(c), int(reset)))
+        return c.as_dict()
+
+    KERNELS = ("generate", "extend", "shade", "connect", "finalize", "refit")
+
+    def get_kernel_time(self, which, reset=False):
+        ms, n = C.c_float(), C.c_uint32()
+        idx = self.KERNELS.index(which) if isinstance(which, str) else int(which)
+        self._check(self._fn("get_kernel_time")(self._ctx, idx, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def get_setting(self, key):
+        buf = C.create_string_buffer(128)
+        self._check(self._fn("get_setting")(self._ctx, str(key).encode(), buf, 128))
+        return buf.value.decode()
+
+    def get_settings(self):
+        keys = (C.c_char_p * 32)()
+        n = self._fn("get_settings")(self._ctx, keys, 32)
+        return {keys[i].decode(): self.get_setting(keys[i].decode()) for i in range(n)}
+
+    def version(self):
+        return self._fn("version")().decode()
