@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the HIP wavefront rendercore on BASELINE.json's headline workload.
+
+  python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2]): synthetic ~1 M-triangle displaced grid (1 002 528 triangles, seed 0x5EED) +
+synthetic HDR sky + 8 emissive light triangles + 2 point lights, 1920x1080, wavefront path-tracing integrator
+(primary generate -> BVH2 traverse + Moller-Trumbore -> shade with next-event estimation -> compaction -> connect),
+MAX_PATH_LENGTH 2 like the reference (settings.h:5).  One *step* = one frame of `--spp` samples per pixel enqueued as
+one wavefront batch, plus — for N > 1 — the RCCL gather of the rank-local strips and the de-interleave on rank 0.
+Inputs (scene, BVH, path buffers) are resident in HBM before the timed region starts.
+
+The JSON line carries, besides the driver contract fields:
+  roofline      dominant kernel (extend = closest-hit traversal): algorithmic bytes per SURVEY §8(d)
+                (ray 32 B in [+32 B out for generated primaries], 64 B per popped inner node, 52 B per triangle test,
+                16 B hit record out) from an instrumented replay of the same frames, divided by the kernel's mean
+                duration measured with hipEvents on the render stream inside the timed region; peak = 8 TB/s HBM3E.
+  cpu_baseline  the CPU oracle's restatement of the same integrator ("port") on the host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step (one wavefront batch)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--grid", type=int, default=708, help="terrain cells per side (708 -> 1 002 528 triangles)")
+    ap.add_argument("--integrator", default="pt", choices=["pt", "parity"])
+    ap.add_argument("--max-depth", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_extend.json"),
+                    help="optional PMC-derived HBM bytes per extend launch (see profiles/README.md)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    from __graft_entry__ import load_package
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rendercore has no CPU path (the CPU oracle is only the baseline)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = load_package()
+    t0 = time.time()
+    scene = pkg.scenes.terrain(n=args.grid, width=args.width, height_px=args.height)
+    t_scene = time.time() - t0
+    ctx = pkg.RenderContext(device=local_rank, rank=rank, world=world)
+    ctx.init(args.width, args.height)
+    t0 = time.time()
+    scene.upload(ctx)
+    t_upload = time.time() - t0
+    ctx.set_setting("integrator", args.integrator)
+    ctx.set_setting("spp", args.spp)
+    ctx.set_setting("max_depth", args.max_depth)
+    ctx.set_setting("stage_timing", 1)
+    ctx.set_setting("count_traversal", 0)
+
+    W, H = args.width, args.height
+    local_rows = ctx.local_rows()
+    local_fb = torch.empty((local_rows, W, 4), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(local_fb) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered_flat = torch.empty((world, local_rows, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    full_fb = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+    gather_ms = []
+
+    def step(k, first):
+        # render_frame(camera, status): RESET on the first step of a series, CONVERGE afterwards (context.h:19-23)
+        ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
+        if world > 1:
+            ctx.wait()
+            t = time.perf_counter()
+            ctx.read_local_framebuffer_device(local_fb.data_ptr())
+            dist.gather(local_fb, gathered, dst=0)
+            if rank == 0:
+                torch.stack(gathered, out=gathered_flat)
+                torch.cuda.synchronize()
+                ctx.deinterleave_device(gathered_flat.data_ptr(), full_fb.data_ptr())
+            gather_ms.append((time.perf_counter() - t) * 1e3)
+
+    def fence():
+        ctx.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k, k == 0)
+    fence()
+    for name in ctx.KERNELS:
+        ctx.get_kernel_time(name, reset=True)
+    del gather_ms[:]
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        step(k, k == 0)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if world == 1:
+        ctx.read_framebuffer_device(full_fb.data_ptr())
+    kernel_times = {name: ctx.get_kernel_time(name) for name in ctx.KERNELS}
+    stats = ctx.get_stats().as_dict()
+
+    samples = float(W) * H * args.spp * args.steps
+    value = samples / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (extend) -------------------------------------------------------------------------
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        ext_ms, ext_launches = kernel_times["extend"]
+        ctx.set_setting("count_traversal", 1)
+        ctx.set_setting("stage_timing", 0)
+        ctx.get_counters(reset=True)
+        replay = min(args.steps, 4)
+        for k in range(replay):  # same sample indices as the first `replay` timed steps => identical rays
+            ctx.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+        ctx.wait()
+        cnt = ctx.get_counters(reset=True)
+        ctx.set_setting("count_traversal", 0)
+        launches_replay = replay * (args.max_depth + 1 if args.integrator == "pt" else 1)
+        primaries = float(W) * H * args.spp * replay / world
+        algo_bytes = (cnt["rays_extend"] * (32 + 16) + primaries * 32 + 64.0 * cnt["inner_extend"] + 52.0 * cnt["tris_extend"])
+        bytes_per_launch = algo_bytes / launches_replay
+        ms_per_launch = ext_ms / max(1, ext_launches)
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                if tj.get("spp") == args.spp and tj.get("workload") == scene.name:
+                    traffic = tj.get("hbm_bytes_per_extend_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": ms_per_launch,
+            "launches_timed": ext_launches,
+            "per_ray": {"inner_nodes": cnt["inner_extend"] / max(1, cnt["rays_extend"]),
+                        "triangle_tests": cnt["tris_extend"] / max(1, cnt["rays_extend"]),
+                        "rays_per_sample": cnt["rays_extend"] / max(1.0, primaries),
+                        "shadow_rays_per_sample": cnt["rays_shadow"] / max(1.0, primaries)},
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
+        }
+
+    # ---- CPU baseline: the oracle (a port, not the reference build) on this box's host cores ----------------------------
+    cpu_baseline = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from __graft_entry__ import load_oracle
+        orc = load_oracle()
+        cores = os.cpu_count() or 1
+        ref = orc.OracleContext(pkg)
+        ref.init(W, H)
+        t0 = time.time()
+        scene.upload(ref)  # includes the oracle's own (reference-style) BVH build; not timed
+        t_build = time.time() - t0
+        ref.set_setting("integrator", args.integrator)
+        ref.set_setting("max_depth", args.max_depth)
+        ref.set_setting("spp", 1)
+        ref.set_setting("threads", cores)
+        done, spent = 0, 0.0
+        while spent < args.cpu_seconds and done < 64:
+            t0 = time.perf_counter()
+            ref.render_frame(scene.camera, pkg.RESET if done == 0 else pkg.CONVERGE)
+            spent += time.perf_counter() - t0
+            done += 1
+        cpu_value = float(W) * H * done / spent / 1e6
+        cpu_baseline = {"value": round(cpu_value, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                        "sample": "%d full %dx%d frame(s) at 1 spp of the same scene/camera/integrator (%s, depth %d), "
+                                  "oracle/rfw_oracle.c with OpenMP, %.1f s; oracle BVH build %.1f s not timed"
+                                  % (done, W, H, args.integrator, args.max_depth, spent, t_build)}
+        # cross-check while both are here: same first sample => images agree (oracle = checker, not the thing measured)
+        ref.destroy()
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/sec at 1920x1080, 1M-tri scene; 1/2/4/8-GPU tile scaling",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d triangles, %dx%d, %s integrator depth %d, %d spp per step, %d area-light "
+                                   "triangles + %d point lights, synthetic 2048x1024 HDR sky"
+                                   % (scene.name, scene.triangle_count(), W, H, args.integrator, args.max_depth, args.spp,
+                                      len(scene.area_lights), len(scene.point_lights)),
+                       "parallelism": "image strips of 8 rows interleaved over %d rank(s), one RCCL gather per step" % world,
+                       "spp_per_step": args.spp},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_times.items()},
+            "last_frame_counts": {k: stats[k] for k in ("primaryCount", "secondaryCount", "deepCount", "shadowCount")},
+            "gather_ms_per_step": round(sum(gather_ms) / len(gather_ms), 4) if gather_ms else 0.0,
+            "setup_s": {"scene": round(t_scene, 2), "upload_and_bvh": round(t_upload, 2)},
+            "image_mean": float(full_fb[..., :3].mean().item()),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

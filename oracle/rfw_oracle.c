@@ -1597,7 +1597,10 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 		const v3 wo = vscale(D, -1.0f);
 		bsdf_sample(&sd, Tg, Bt, iN, wo, &R, &newPdf, q3, q4);
 		const v3 bs = bsdf_eval(&sd, iN, wo, R, t, flip < 0);
-		T = vscale(vmul(vscale(vscale(T, 1.0f), 1.0f / survival_probability(T)), bs), fabsf(vdot(iN, R)));
+		{
+			const float surv = survival_probability(T);
+			T = vscale(vmul(V3(T.x / surv, T.y / surv, T.z / surv), bs), fabsf(vdot(iN, R)));
+		}
 		if (newPdf < 1e-6f || isnan(newPdf) || T.x < 0.0f || T.y < 0.0f || T.z < 0.0f)
 			return;
 		O = vadd(I, vscale(N, 1e-5f));

@@ -1,0 +1,270 @@
+// bvh_build.cpp — binned-SAH BVH2 builder (host, C++17).  See bvh_build.h.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <numeric>
+#include <thread>
+
+namespace bvh
+{
+namespace
+{
+
+struct Box
+{
+	float mn[3], mx[3];
+	void reset()
+	{
+		for (int a = 0; a < 3; a++)
+			mn[a] = 1e34f, mx[a] = -1e34f;
+	}
+	void grow(const float *lo, const float *hi)
+	{
+		for (int a = 0; a < 3; a++)
+			mn[a] = std::min(mn[a], lo[a]), mx[a] = std::max(mx[a], hi[a]);
+	}
+	void grow(const Box &b) { grow(b.mn, b.mx); }
+	float half_area() const
+	{
+		const float e0 = mx[0] - mn[0], e1 = mx[1] - mn[1], e2 = mx[2] - mn[2];
+		return std::max(0.0f, e0 * e1 + e0 * e2 + e1 * e2);
+	}
+};
+
+constexpr int BINS = 16;
+constexpr float TRAVERSAL_COST = 1.0f; // relative to one triangle test
+constexpr size_t PARALLEL_MIN = 1u << 15;
+
+struct Builder
+{
+	const float *bmin, *bmax;
+	std::vector<float> cen; // n x 3
+	int max_leaf, depth_limit;
+	rt::Node *nodes;
+	int *parents;
+	uint32_t *order;
+	std::atomic<int> max_depth{0};
+	std::atomic<int> tasks{0};
+	int max_tasks = 1;
+
+	void set_node(int idx, const Box &b, float pad, int left_first, int count)
+	{
+		for (int a = 0; a < 3; a++)
+			nodes[idx].bmin[a] = b.mn[a] - pad, nodes[idx].bmax[a] = b.mx[a] + pad;
+		nodes[idx].left_first = left_first;
+		nodes[idx].count = count;
+	}
+
+	// Builds the subtree of node `idx` over order[first, first+count) using node slots [pool, pool + 2*count - 2).
+	// Every subtree owns a private slot range, so parallel subtrees never contend and the layout is deterministic.
+	void subdivide(int idx, uint32_t first, uint32_t count, int depth, int pool)
+	{
+		int d = max_depth.load();
+		while (depth > d && !max_depth.compare_exchange_weak(d, depth))
+		{
+		}
+		if ((int)count <= 1)
+			return;
+		// bounds of centroids
+		float cmn[3] = {1e34f, 1e34f, 1e34f}, cmx[3] = {-1e34f, -1e34f, -1e34f};
+		for (uint32_t i = 0; i < count; i++)
+		{
+			const float *c = &cen[3ull * order[first + i]];
+			for (int a = 0; a < 3; a++)
+				cmn[a] = std::min(cmn[a], c[a]), cmx[a] = std::max(cmx[a], c[a]);
+		}
+		Box nb;
+		for (int a = 0; a < 3; a++)
+			nb.mn[a] = nodes[idx].bmin[a], nb.mx[a] = nodes[idx].bmax[a];
+		const float parent_area = std::max(nb.half_area(), 1e-30f);
+
+		int levels_needed = 0;
+		for (uint32_t c = count; c > (uint32_t)max_leaf; c = (c + 1) / 2)
+			levels_needed++;
+		const bool budget_short = depth + levels_needed + 1 >= depth_limit;
+
+		int best_axis = -1, best_bin = -1;
+		float best_cost = 1e34f;
+		if (!budget_short)
+		{
+			for (int axis = 0; axis < 3; axis++)
+			{
+				const float ext = cmx[axis] - cmn[axis];
+				if (!(ext > 0.0f))
+					continue;
+				Box bb[BINS];
+				uint32_t bc[BINS];
+				for (int b = 0; b < BINS; b++)
+					bb[b].reset(), bc[b] = 0;
+				const float scale = (float)BINS / ext;
+				for (uint32_t i = 0; i < count; i++)
+				{
+					const uint32_t p = order[first + i];
+					int b = (int)((cen[3ull * p + axis] - cmn[axis]) * scale);
+					b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+					bb[b].grow(&bmin[3ull * p], &bmax[3ull * p]);
+					bc[b]++;
+				}
+				float right_area[BINS];
+				uint32_t right_cnt[BINS];
+				Box acc;
+				acc.reset();
+				uint32_t n = 0;
+				for (int b = BINS - 1; b > 0; b--)
+				{
+					acc.grow(bb[b]);
+					n += bc[b];
+					right_area[b] = acc.half_area();
+					right_cnt[b] = n;
+				}
+				acc.reset();
+				n = 0;
+				for (int b = 0; b < BINS - 1; b++)
+				{
+					acc.grow(bb[b]);
+					n += bc[b];
+					if (n == 0 || right_cnt[b + 1] == 0)
+						continue;
+					const float cost = acc.half_area() * (float)n + right_area[b + 1] * (float)right_cnt[b + 1];
+					if (cost < best_cost)
+						best_cost = cost, best_axis = axis, best_bin = b;
+				}
+			}
+		}
+		const float split_cost = TRAVERSAL_COST + best_cost / parent_area;
+		if ((int)count <= max_leaf && (best_axis < 0 || (float)count <= split_cost))
+			return; // leaf
+
+		uint32_t mid;
+		if (best_axis >= 0)
+		{
+			const float ext = cmx[best_axis] - cmn[best_axis];
+			const float scale = (float)BINS / ext;
+			const float lo = cmn[best_axis];
+			const int bbin = best_bin, ax = best_axis;
+			uint32_t *it = std::partition(order + first, order + first + count, [&](uint32_t p) {
+				int b = (int)((cen[3ull * p + ax] - lo) * scale);
+				b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+				return b <= bbin;
+			});
+			mid = (uint32_t)(it - (order + first));
+		}
+		else
+		{
+			// no usable SAH plane (identical centroids) or depth budget short: median split on the widest axis
+			int ax = 0;
+			for (int a = 1; a < 3; a++)
+				if (cmx[a] - cmn[a] > cmx[ax] - cmn[ax])
+					ax = a;
+			mid = count / 2;
+			std::nth_element(order + first, order + first + mid, order + first + count, [&](uint32_t a, uint32_t b) {
+				const float ca = cen[3ull * a + ax], cb = cen[3ull * b + ax];
+				return ca < cb || (ca == cb && a < b);
+			});
+		}
+		if (mid == 0 || mid == count)
+			mid = count / 2;
+
+		Box lb, rb;
+		lb.reset(), rb.reset();
+		for (uint32_t i = 0; i < mid; i++)
+			lb.grow(&bmin[3ull * order[first + i]], &bmax[3ull * order[first + i]]);
+		for (uint32_t i = mid; i < count; i++)
+			rb.grow(&bmin[3ull * order[first + i]], &bmax[3ull * order[first + i]]);
+		const int left = pool;
+		set_node(left, lb, 1e-5f, (int)first, (int)mid);
+		set_node(left + 1, rb, 1e-5f, (int)(first + mid), (int)(count - mid));
+		parents[left] = idx, parents[left + 1] = idx;
+		nodes[idx].left_first = left;
+		nodes[idx].count = -1;
+		// a subtree over k primitives has at most 2k - 2 descendant nodes: [pool, pool+2) is the child pair, the left
+		// subtree's descendants take [pool+2, pool+2*mid), the right one's start at pool + 2*mid
+		const int lpool = pool + 2, rpool = pool + 2 * (int)mid;
+		if (count >= PARALLEL_MIN && tasks.load() < max_tasks)
+		{
+			tasks.fetch_add(1);
+			auto fut = std::async(std::launch::async, [&]() { subdivide(left, first, mid, depth + 1, lpool); });
+			subdivide(left + 1, first + mid, count - mid, depth + 1, rpool);
+			fut.get();
+			tasks.fetch_sub(1);
+		}
+		else
+		{
+			subdivide(left, first, mid, depth + 1, lpool);
+			subdivide(left + 1, first + mid, count - mid, depth + 1, rpool);
+		}
+	}
+};
+
+} // namespace
+
+void build(const float *bmin, const float *bmax, size_t n, int max_leaf, int depth_limit, Result &out)
+{
+	out.nodes.clear(), out.order.clear(), out.parents.clear();
+	out.max_depth = 0;
+	if (max_leaf < 1)
+		max_leaf = 1;
+	if (max_leaf > rt::MAX_LEAF_PRIMS)
+		max_leaf = rt::MAX_LEAF_PRIMS;
+	if (n == 0)
+		return;
+	// sparse build: subtree over k primitives owns 2k node slots; compacted afterwards
+	std::vector<rt::Node> sparse(2 * n + 2);
+	std::vector<int> sparents(2 * n + 2, -1);
+	std::memset(sparse.data(), 0, sparse.size() * sizeof(rt::Node));
+	out.order.resize(n);
+	std::iota(out.order.begin(), out.order.end(), 0u);
+	Builder b;
+	b.bmin = bmin, b.bmax = bmax;
+	b.cen.resize(3 * n);
+	Box root;
+	root.reset();
+	for (size_t i = 0; i < n; i++)
+	{
+		for (int a = 0; a < 3; a++)
+			b.cen[3 * i + a] = 0.5f * (bmin[3 * i + a] + bmax[3 * i + a]);
+		root.grow(&bmin[3 * i], &bmax[3 * i]);
+	}
+	b.max_leaf = max_leaf, b.depth_limit = depth_limit;
+	b.nodes = sparse.data(), b.parents = sparents.data(), b.order = out.order.data();
+	b.max_tasks = (int)std::max(1u, std::thread::hardware_concurrency());
+	b.set_node(0, root, 0.0f, 0, (int)n);
+	b.subdivide(0, 0, (uint32_t)n, 0, 2);
+	out.max_depth = b.max_depth.load();
+
+	// compaction in depth-first preorder (children pairs stay adjacent and 64-byte aligned: pairs start at even
+	// indices because the root pair (0,1) does)
+	out.nodes.reserve(2 * n + 4);
+	out.parents.reserve(2 * n + 4);
+	out.nodes.push_back(sparse[0]);
+	out.parents.push_back(-1);
+	rt::Node unused;
+	std::memset(&unused, 0, sizeof(unused));
+	unused.count = 0;
+	out.nodes.push_back(unused);
+	out.parents.push_back(-1);
+	std::vector<int> stack;
+	stack.push_back(0);
+	while (!stack.empty())
+	{
+		const int dst = stack.back();
+		stack.pop_back();
+		if (out.nodes[dst].count >= 0)
+			continue;
+		const int src_left = out.nodes[dst].left_first;
+		const int new_left = (int)out.nodes.size();
+		out.nodes.push_back(sparse[src_left]);
+		out.nodes.push_back(sparse[src_left + 1]);
+		out.parents.push_back(dst);
+		out.parents.push_back(dst);
+		out.nodes[dst].left_first = new_left;
+		stack.push_back(new_left + 1);
+		stack.push_back(new_left);
+	}
+}
+
+} // namespace bvh

@@ -1,0 +1,49 @@
+// kernels.h — host-callable launchers of the wavefront stages (implemented in kernels.hip).
+#pragma once
+#include "rt_types.h"
+
+namespace rtk
+{
+
+struct Params
+{
+	rt::SceneView sc;
+	rt::WaveView wv;
+	rt::CamView cam;
+	rt::FrameView fr;
+	uint32_t depth;		// pathLength of this wave
+	uint32_t max_depth; // MAX_PATH_LENGTH
+	uint32_t parity_no_jitter;
+	uint32_t lds_pairs; // number of top-of-tree node pairs staged in LDS (0 = off)
+};
+
+enum GenMode
+{
+	GEN_BUFFER = 0, // rays come from the wave buffers (depth >= 1)
+	GEN_PT = 1,		// generate pt primary rays   (CUDART generatePrimaryRay)
+	GEN_PARITY = 2	// generate parity primary rays (EmbreeRT GenerateRay8 draw order)
+};
+
+typedef void *stream_t; // hipStream_t
+
+// device properties used for grid sizing
+void set_device_cus(int cus);
+
+// zero the per-render wave counters (ext/shadow/probe) and set ext[0] = primary_count
+void launch_init_counters(rt::WaveCounters *c, uint32_t primary_count, stream_t s);
+void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
+					   uint32_t packets_per_sample, uint32_t spp, stream_t s);
+void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t s);
+void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t s);
+void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s);
+void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s);
+void launch_resolve(const Params &p, stream_t s);
+// out: local layout (local_rows x W) when full == 0, else full image (H x W; world must be 1)
+void launch_present(const Params &p, rt::f4 *out, float scale, int full, stream_t s);
+void launch_deinterleave(const rt::f4 *gathered, rt::f4 *out, uint32_t W, uint32_t H, uint32_t local_rows,
+						 uint32_t world, stream_t s);
+// bottom-up refit of one BLAS after its vertices changed: leaf_order[i] = original primitive of leaf slot i
+void launch_refit(rt::Node *nodes, const int *parents, uint32_t node_count, rt::f4 *tri_verts, const rt::f4 *verts,
+				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s);
+
+} // namespace rtk

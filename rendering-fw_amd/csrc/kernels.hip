@@ -1,0 +1,804 @@
+// kernels.hip — the wavefront stages of the HIP rendercore for gfx950 (MI355X, CDNA4).
+//
+//   extend        closest-hit traversal of one wave of rays (primary rays are generated in the same kernel)
+//   shade_parity  EmbreeRT-equivalent direct-lighting integrator (shadow rays traced inline, fixed light order)
+//   shade_pt      path-tracing shade: emits a compacted shadow-ray wave and a compacted extension-ray wave
+//   connect       any-hit traversal of the shadow wave, adds unoccluded contributions
+//   resolve/present/deinterleave   accumulate the batch, scale by 1/samples, undo the multi-GPU strip interleave
+//   rng_states    xor128 jump-ahead: per-packet generator states for the parity integrator's jitter stream
+//   refit         bottom-up BVH refit after a same-topology set_mesh
+//
+// CDNA4 specifics:
+//   * one wave64 = one 8x8 pixel tile of the primary wave; a 256-thread workgroup = 4 tiles;
+//   * the traversal stack lives in LDS as stack[entry][thread] (bank = thread % 32: conflict-free), 24 entries per
+//     lane, with a private-memory spill that ordinary rays never reach;
+//   * stream compaction uses one __ballot + mbcnt prefix and ONE atomicAdd per wave (the reference issues one
+//     atomicAdd per surviving thread, CUDART/src/Kernels.cu:640,747,788);
+//   * persistent grids: blocks = CUs x 8 grid-stride over 256-ray chunks, and the chunk order is XCD-aware — block b
+//     runs on XCD b % 8, so XCD x walks the contiguous chunk range [x*n/8, (x+1)*n/8): neighbouring tiles (which
+//     share BVH nodes and triangles) meet in the same 4 MiB L2;
+//   * wave counts come from device-side counters; the host never reads a counter between bounces
+//     (contrast CUDART/src/Context.cpp:98,145).
+// No MFMA: the path is divergent pointer chasing, bounded by memory latency/bandwidth.
+#include "kernels.h"
+#include "rt_core.h"
+
+#include <string.h>
+
+using namespace rt;
+
+namespace rtk
+{
+
+constexpr int BLOCK = 256;
+
+// ================================================================================================================
+// per-thread context: traversal stack + compaction + statistics.  Device and host-emulation flavours.
+// ================================================================================================================
+#if defined(RT_DEVICE_BUILD)
+
+struct Ctx
+{
+	TravStack stk;
+
+	// wave-aggregated slot allocation: returns the compacted index for lanes with flag set
+	__device__ __forceinline__ uint32_t compact(bool flag, uint32_t *counter)
+	{
+		const unsigned long long mask = __ballot(flag);
+		if (mask == 0ull)
+			return 0u;
+		const uint32_t lane = __lane_id();
+		const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+		uint32_t base = 0;
+		if (lane == leader)
+			base = atomicAdd(counter, (uint32_t)__popcll(mask));
+		base = __shfl(base, (int)leader);
+		const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+		return base + prefix;
+	}
+	__device__ __forceinline__ void add64(unsigned long long *dst, uint32_t v)
+	{
+		// wave reduction, then one atomic per wave
+		for (int o = 32; o > 0; o >>= 1)
+			v += __shfl_down(v, o);
+		if (__lane_id() == 0 && v)
+			atomicAdd(dst, (unsigned long long)v);
+	}
+};
+
+#else
+
+struct Ctx
+{
+	TravStack stk;
+	uint32_t lds[LDS_STACK];
+	Ctx()
+	{
+		stk.lds = lds;
+		stk.stride = 1;
+	}
+	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
+	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
+};
+
+#endif
+
+// ================================================================================================================
+// work items (one ray / path / pixel each) — shared by the device kernels and the host emulation
+// ================================================================================================================
+template <int GEN, bool COUNT>
+RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+{
+	f3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
+	const uint32_t b = p.depth & 1u;
+	if (GEN == GEN_BUFFER)
+	{
+		if (active)
+		{
+			const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
+			O = xyz(o4), D = xyz(d4);
+		}
+	}
+	else
+	{
+		const PixelRef pr = slot_to_pixel(p.fr, i);
+		active = active && pr.valid;
+		if (GEN == GEN_PT)
+		{
+			if (active)
+				pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
+		}
+		else
+		{
+			// EmbreeRT renders whole 4x2 packets only (Context.cpp:137-139): remainder columns/rows are never written
+			const uint32_t npx = p.fr.W / 4u, npy = p.fr.H / 2u;
+			active = active && pr.x < npx * 4u && pr.y < npy * 2u;
+			if (active)
+			{
+				float r0 = 0.5f, r1 = 0.5f, r2 = 0.5f, r3 = 0.5f;
+				if (!p.parity_no_jitter)
+				{
+					// Ray.cpp:213-216 — 8 x r0, 8 x r1, 8 x r2, 8 x r3 per packet; lane j of the packet takes draw j
+					const uint32_t packet = (pr.y / 2u) * npx + pr.x / 4u;
+					const uint32_t lane = (pr.y & 1u) * 4u + (pr.x & 3u);
+					const uint32_t *sp = p.wv.packet_rng + 4ull * ((unsigned long long)pr.sample * npx * npy + packet);
+					uint32_t s[4] = {sp[0], sp[1], sp[2], sp[3]};
+					const bool lens = p.cam.aperture != 0.0f;
+					const uint32_t draws = lens ? 32u : 16u;
+					for (uint32_t k = 0; k < draws; k++)
+					{
+						const float r = u32_to_unit(xor128_next(s));
+						if (k == lane)
+							r0 = r;
+						else if (k == 8u + lane)
+							r1 = r;
+						else if (k == 16u + lane)
+							r2 = r;
+						else if (k == 24u + lane)
+							r3 = r;
+					}
+				}
+				parity_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, r0, r1, r2, r3, O, D);
+			}
+		}
+		if (active)
+		{
+			p.wv.org[0][i] = mk4(O.x, O.y, O.z, ubits((i << 1) | 1u));
+			p.wv.dir[0][i] = mk4(D.x, D.y, D.z, 0.0f);
+		}
+	}
+	Hit h;
+	h.t = 1e34f, h.u = 0, h.v = 0, h.prim = -1, h.inst = -1;
+	TStat st;
+	st.inner = 0, st.tris = 0;
+	if (active)
+	{
+		trace<false, COUNT>(p.sc, O, D, 1e-5f, 1e34f, h, ctx.stk, st);
+		f4 *hb = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
+		int *ib = p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
+		hb[i] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
+		ib[i] = h.inst;
+	}
+	if (COUNT)
+	{
+		ctx.add64(&p.wv.counters->inner_extend, st.inner);
+		ctx.add64(&p.wv.counters->tris_extend, st.tris);
+		ctx.add64(&p.wv.counters->rays_extend, active ? 1u : 0u);
+	}
+}
+
+template <bool COUNT>
+RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+{
+	const PixelRef pr = slot_to_pixel(p.fr, i);
+	active = active && pr.valid && pr.x < (p.fr.W / 4u) * 4u && pr.y < (p.fr.H / 2u) * 2u;
+	TStat st;
+	st.inner = 0, st.tris = 0;
+	uint32_t nshadow = 0;
+	f4 out = mk4(0, 0, 0, 0);
+	if (active)
+	{
+		const f4 o4 = p.wv.org[0][i], d4 = p.wv.dir[0][i], h4 = p.wv.hit0[i];
+		Hit h;
+		h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = p.wv.hit0_inst[i];
+		if (h.prim < 0)
+		{
+			const f3 s = parity_sky(p.sc, xyz(d4));
+			out = mk4(s.x, s.y, s.z, 0.0f);
+		}
+		else
+		{
+			if (pr.sample == 0 && pr.y * p.fr.W + pr.x == p.fr.probe_pixel)
+			{
+				WaveCounters *c = p.wv.counters;
+				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
+			}
+			out = parity_shade<COUNT>(p.sc, xyz(o4), xyz(d4), h, ctx.stk, st, nshadow);
+		}
+	}
+	if (pr.valid)
+		p.wv.rad[i] = out;
+	if (COUNT)
+	{
+		ctx.add64(&p.wv.counters->inner_shadow, st.inner);
+		ctx.add64(&p.wv.counters->tris_shadow, st.tris);
+		ctx.add64(&p.wv.counters->rays_shadow, nshadow);
+		ctx.add64(&p.wv.counters->shaded, (active && out.w > 0.0f) ? 1u : 0u);
+	}
+}
+
+RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+{
+	const uint32_t b = p.depth & 1u, nb = b ^ 1u;
+	ShadeOut out;
+	out.radiance = mk3(0, 0, 0);
+	out.emit_shadow = false, out.emit_ext = false;
+	uint32_t slot = 0;
+	bool write_rad = false;
+	if (active)
+	{
+		const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
+		const f4 h4 = (p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i];
+		const int hi = (p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst)[i];
+		PathIn in;
+		in.O = xyz(o4), in.D = xyz(d4);
+		const uint32_t ow = fbits(o4.w);
+		in.slot = ow >> 1, in.flags = ow & 1u, in.packedN = fbits(d4.w);
+		slot = in.slot;
+		if (p.depth == 0)
+			in.T = mk3(1, 1, 1), in.bsdfPdf = 1.0f;
+		else
+		{
+			const f4 t4 = p.wv.thr[b][i];
+			in.T = xyz(t4), in.bsdfPdf = t4.w;
+		}
+		const PixelRef pr = slot_to_pixel(p.fr, in.slot);
+		if (p.depth == 0 && !pr.valid)
+			active = false;
+		else
+		{
+			in.pixel = pr.y * p.fr.W + pr.x;
+			in.sampleIdx = p.fr.sample_base + pr.sample;
+			in.depth = p.depth;
+			Hit h;
+			h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = hi;
+			if (p.depth == 0 && h.prim >= 0 && pr.sample == 0 && in.pixel == p.fr.probe_pixel)
+			{
+				WaveCounters *c = p.wv.counters;
+				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
+			}
+			pt_shade(p.sc, p.cam, p.max_depth, in, h, out);
+			write_rad = true;
+		}
+	}
+	if (write_rad)
+	{
+		// depth 0 initialises the slot (no clear pass); later depths accumulate.  One path per slot => no race.
+		if (p.depth == 0)
+			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, 1.0f);
+		else if (out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
+		{
+			f4 r = p.wv.rad[slot];
+			r.x += out.radiance.x, r.y += out.radiance.y, r.z += out.radiance.z;
+			p.wv.rad[slot] = r;
+		}
+	}
+	WaveCounters *c = p.wv.counters;
+	const uint32_t si = ctx.compact(out.emit_shadow, &c->shadow[p.depth]);
+	if (out.emit_shadow)
+	{
+		p.wv.sh_org[si] = out.so;
+		p.wv.sh_dir[si] = out.sd;
+		p.wv.sh_rad[si] = out.se;
+	}
+	const uint32_t ei = ctx.compact(out.emit_ext, &c->ext[p.depth + 1]);
+	if (out.emit_ext)
+	{
+		p.wv.org[nb][ei] = out.eo;
+		p.wv.dir[nb][ei] = out.ed;
+		p.wv.thr[nb][ei] = out.et;
+	}
+}
+
+template <bool COUNT>
+RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+{
+	TStat st;
+	st.inner = 0, st.tris = 0;
+	if (active)
+	{
+		const f4 o4 = p.wv.sh_org[i], d4 = p.wv.sh_dir[i];
+		Hit h;
+		if (!trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st))
+		{
+			const f4 e4 = p.wv.sh_rad[i];
+			const uint32_t slot = fbits(o4.w);
+			f4 r = p.wv.rad[slot];
+			r.x += e4.x, r.y += e4.y, r.z += e4.z;
+			p.wv.rad[slot] = r;
+		}
+	}
+	if (COUNT)
+	{
+		ctx.add64(&p.wv.counters->inner_shadow, st.inner);
+		ctx.add64(&p.wv.counters->tris_shadow, st.tris);
+		ctx.add64(&p.wv.counters->rays_shadow, active ? 1u : 0u);
+	}
+}
+
+// local pixel (yl, x) -> tiled slot offset within one sample
+RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
+{
+	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
+		c->ext[d] = 0u, c->shadow[d] = 0u;
+	c->ext[0] = primary_count;
+	c->probe_valid = 0u;
+}
+
+RT_FN uint32_t local_pixel_to_slot(const FrameView &fr, uint32_t x, uint32_t yl)
+{
+	const uint32_t tile = (yl / TILE) * fr.tiles_x + x / TILE;
+	return tile * 64u + (yl % TILE) * TILE + (x % TILE);
+}
+
+RT_FN void resolve_item(const Params &p, uint32_t li)
+{
+	const uint32_t x = li % p.fr.W, yl = li / p.fr.W;
+	if (local_to_global_row(p.fr, yl) >= p.fr.H)
+		return;
+	const uint32_t lp = local_pixel_to_slot(p.fr, x, yl);
+	f4 a = p.wv.acc[li];
+	for (uint32_t s = 0; s < p.fr.spp; s++)
+	{
+		const f4 r = p.wv.rad[(unsigned long long)s * p.fr.slots + lp];
+		a.x += r.x, a.y += r.y, a.z += r.z, a.w += r.w;
+	}
+	p.wv.acc[li] = a;
+}
+
+RT_FN void present_item(const Params &p, f4 *out, float scale, int full, uint32_t li)
+{
+	const uint32_t x = li % p.fr.W, yl = li / p.fr.W;
+	const uint32_t y = local_to_global_row(p.fr, yl);
+	const f4 a = p.wv.acc[li];
+	const f4 v = mk4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+	if (full)
+	{
+		if (y < p.fr.H)
+			out[y * p.fr.W + x] = v;
+	}
+	else
+		out[li] = y < p.fr.H ? v : mk4(0, 0, 0, 0);
+}
+
+RT_FN void deinterleave_item(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, uint32_t local_rows, uint32_t world,
+							 uint32_t gi)
+{
+	const uint32_t x = gi % W, y = gi / W;
+	if (y >= H)
+		return;
+	const uint32_t strip = y / STRIP_ROWS, rank = strip % world;
+	const uint32_t yl = (strip / world) * STRIP_ROWS + y % STRIP_ROWS;
+	out[gi] = gathered[((unsigned long long)rank * local_rows + yl) * W + x];
+}
+
+// xor128 jump-ahead: jump_table[k] = M^(2^k) as 128 columns x 4 words
+RT_FN void gf2_apply(const uint32_t *m, uint32_t s[4])
+{
+	uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+	for (int w = 0; w < 4; w++)
+		for (int bit = 0; bit < 32; bit++)
+			if ((s[w] >> bit) & 1u)
+			{
+				const uint32_t *c = m + 4 * (w * 32 + bit);
+				r0 ^= c[0], r1 ^= c[1], r2 ^= c[2], r3 ^= c[3];
+			}
+	s[0] = r0, s[1] = r1, s[2] = r2, s[3] = r3;
+}
+constexpr uint32_t RNG_RUN = 32; // packets per rng_states thread
+RT_FN void rng_states_item(uint32_t *states, const uint32_t base[4], const uint32_t *table, uint32_t total, uint32_t r)
+{
+	const unsigned long long start = (unsigned long long)r * RNG_RUN;
+	if (start >= total)
+		return;
+	uint32_t s[4] = {base[0], base[1], base[2], base[3]};
+	const unsigned long long draws = start * 32ull;
+	for (int k = 0; k < 64; k++)
+		if ((draws >> k) & 1ull)
+			gf2_apply(table + 512ull * k, s);
+	for (uint32_t j = 0; j < RNG_RUN && start + j < total; j++)
+	{
+		uint32_t *o = states + 4ull * (start + j);
+		o[0] = s[0], o[1] = s[1], o[2] = s[2], o[3] = s[3];
+		for (int d = 0; d < 32; d++)
+			xor128_next(s);
+	}
+}
+
+// refit, pass 1: rewrite the leaf-ordered triangle vertices from the new mesh vertices
+RT_FN void refit_tris_item(f4 *tri_verts, const f4 *verts, const uint32_t *indices, uint32_t slot)
+{
+	const uint32_t prim = fbits(tri_verts[3ull * slot].w);
+	uint32_t i0 = 3u * prim, i1 = i0 + 1u, i2 = i0 + 2u;
+	if (indices)
+		i0 = indices[3ull * prim], i1 = indices[3ull * prim + 1], i2 = indices[3ull * prim + 2];
+	const f4 a = verts[i0], b = verts[i1], c = verts[i2];
+	tri_verts[3ull * slot] = mk4(a.x, a.y, a.z, ubits(prim));
+	tri_verts[3ull * slot + 1] = mk4(b.x, b.y, b.z, 1.0f);
+	tri_verts[3ull * slot + 2] = mk4(c.x, c.y, c.z, 1.0f);
+}
+RT_FN void leaf_bounds(const Node &n, const f4 *tri_verts, float mn[3], float mx[3])
+{
+	mn[0] = mn[1] = mn[2] = 1e34f, mx[0] = mx[1] = mx[2] = -1e34f;
+	for (int k = 0; k < n.count; k++)
+		for (int v = 0; v < 3; v++)
+		{
+			const f4 q = tri_verts[3ull * (uint32_t)(n.left_first + k) + v];
+			mn[0] = fminf(mn[0], q.x), mn[1] = fminf(mn[1], q.y), mn[2] = fminf(mn[2], q.z);
+			mx[0] = fmaxf(mx[0], q.x), mx[1] = fmaxf(mx[1], q.y), mx[2] = fmaxf(mx[2], q.z);
+		}
+	// per-triangle boxes are grown by 1e-5 (bvh_tree.cpp:412), node boxes once more (bvh_node.h:218-219)
+	for (int a = 0; a < 3; a++)
+		mn[a] -= 2e-5f, mx[a] += 2e-5f;
+}
+
+// ================================================================================================================
+#if defined(RT_DEVICE_BUILD)
+// ================================================================================================================
+
+static int g_cus = 256;
+void set_device_cus(int cus) { g_cus = cus > 0 ? cus : 256; }
+
+// XCD-aware chunk walk of a persistent grid: iteration k of block b handles chunk  xcd*cpx + k*bpx + j,
+// with xcd = b % 8, j = b / 8, bpx = gridDim/8 blocks per XCD, cpx = ceil(nchunks/8) chunks per XCD.
+struct ChunkWalk
+{
+	uint32_t xcd, j, bpx, cpx, nchunks;
+	__device__ __forceinline__ ChunkWalk(uint32_t count)
+	{
+		nchunks = (count + BLOCK - 1) / BLOCK;
+		xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+		cpx = (nchunks + 7u) >> 3;
+	}
+	__device__ __forceinline__ bool chunk(uint32_t k, uint32_t &c) const
+	{
+		const uint32_t q = k * bpx + j;
+		if (q >= cpx)
+			return false;
+		c = xcd * cpx + q;
+		return true;
+	}
+};
+
+#define RT_STACK_DECL                                        \
+	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];          \
+	Ctx ctx;                                                 \
+	ctx.stk.lds = s_stack + threadIdx.x;                     \
+	ctx.stk.stride = BLOCK;
+
+template <int GEN, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_extend(const Params p, const uint32_t fixed_count)
+{
+	RT_STACK_DECL
+	const uint32_t count = GEN == GEN_BUFFER ? p.wv.counters->ext[p.depth] : fixed_count;
+	const ChunkWalk w(count);
+	uint32_t c;
+	for (uint32_t k = 0; w.chunk(k, c); k++)
+	{
+		const uint32_t i = c * BLOCK + threadIdx.x;
+		if (c < w.nchunks)
+			extend_item<GEN, COUNT>(p, i, i < count, ctx);
+	}
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_shade_parity(const Params p, const uint32_t count)
+{
+	RT_STACK_DECL
+	const ChunkWalk w(count);
+	uint32_t c;
+	for (uint32_t k = 0; w.chunk(k, c); k++)
+	{
+		const uint32_t i = c * BLOCK + threadIdx.x;
+		if (c < w.nchunks)
+			shade_parity_item<COUNT>(p, i, i < count, ctx);
+	}
+}
+
+__global__ void __launch_bounds__(BLOCK) k_shade_pt(const Params p)
+{
+	Ctx ctx;
+	ctx.stk.lds = nullptr, ctx.stk.stride = 0;
+	const uint32_t count = p.wv.counters->ext[p.depth];
+	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
+	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+	{
+		const uint32_t i = c * BLOCK + threadIdx.x;
+		shade_pt_item(p, i, i < count, ctx);
+	}
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_connect(const Params p)
+{
+	RT_STACK_DECL
+	const uint32_t count = p.wv.counters->shadow[p.depth];
+	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
+	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+	{
+		const uint32_t i = c * BLOCK + threadIdx.x;
+		connect_item<COUNT>(p, i, i < count, ctx);
+	}
+}
+
+__global__ void __launch_bounds__(BLOCK) k_resolve(const Params p)
+{
+	const uint32_t n = p.fr.W * p.fr.local_rows;
+	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+		resolve_item(p, i);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_present(const Params p, f4 *out, float scale, int full)
+{
+	const uint32_t n = p.fr.W * p.fr.local_rows;
+	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+		present_item(p, out, scale, full, i);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H,
+														uint32_t local_rows, uint32_t world)
+{
+	const uint32_t n = W * H;
+	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+
+__global__ void k_init_counters(WaveCounters *c, uint32_t primary_count)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+		init_counters_item(c, primary_count);
+}
+
+struct RngBase
+{
+	uint32_t s[4];
+};
+__global__ void __launch_bounds__(BLOCK) k_rng_states(uint32_t *states, RngBase base, const uint32_t *table, uint32_t total)
+{
+	const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+	rng_states_item(states, base.s, table, total, r);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_refit_tris(f4 *tri_verts, const f4 *verts, const uint32_t *indices, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n)
+		refit_tris_item(tri_verts, verts, indices, i);
+}
+
+// pass 2: one thread per node; leaves recompute their box and walk up; the second thread to arrive at a parent
+// (agent-scope counter + fences: the sibling's box was written by another CU) merges the two children.
+__global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *nodes, const int *parents, uint32_t node_count,
+													   const f4 *tri_verts, uint32_t *flags)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= node_count)
+		return;
+	const Node n = nodes[i];
+	if (n.count < 0 || (i == 1u)) // inner node, or the unused slot next to the root
+		return;
+	float mn[3], mx[3];
+	leaf_bounds(n, tri_verts, mn, mx);
+	for (int a = 0; a < 3; a++)
+		nodes[i].bmin[a] = mn[a], nodes[i].bmax[a] = mx[a];
+	int cur = (int)i;
+	for (;;)
+	{
+		const int parent = parents[cur];
+		if (parent < 0)
+			break;
+		__threadfence(); // release our box
+		if (atomicAdd(&flags[parent], 1u) == 0u)
+			break;		 // first arrival: the sibling will continue
+		__threadfence(); // acquire the sibling's box
+		const int l = nodes[parent].left_first;
+		for (int a = 0; a < 3; a++)
+		{
+			const float lo0 = __hip_atomic_load(&nodes[l].bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const float lo1 = __hip_atomic_load(&nodes[l + 1].bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const float hi0 = __hip_atomic_load(&nodes[l].bmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const float hi1 = __hip_atomic_load(&nodes[l + 1].bmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			nodes[parent].bmin[a] = fminf(lo0, lo1);
+			nodes[parent].bmax[a] = fmaxf(hi0, hi1);
+		}
+		cur = parent;
+	}
+}
+
+static inline uint32_t persistent_grid(uint32_t items)
+{
+	uint32_t blocks = (items + BLOCK - 1) / BLOCK;
+	uint32_t cap = (uint32_t)g_cus * 8u;
+	if (blocks > cap)
+		blocks = cap;
+	blocks = (blocks + 7u) & ~7u; // multiple of 8 so every XCD gets the same number of blocks
+	return blocks ? blocks : 8u;
+}
+
+void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t s)
+{
+	hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, (hipStream_t)s, c, primary_count);
+}
+
+void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
+					   uint32_t packets_per_sample, uint32_t spp, stream_t s)
+{
+	const uint32_t total = packets_per_sample * spp;
+	const uint32_t threads = (total + RNG_RUN - 1) / RNG_RUN;
+	RngBase b;
+	memcpy(b.s, base_state, 16);
+	hipLaunchKernelGGL(k_rng_states, dim3((threads + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, states, b,
+					   jump_table, total);
+}
+
+void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t s)
+{
+	const dim3 g(persistent_grid(max_items)), b(BLOCK);
+	hipStream_t st = (hipStream_t)s;
+#define RT_EXT(G, C) hipLaunchKernelGGL((k_extend<G, C>), g, b, 0, st, p, max_items)
+	if (gen == GEN_BUFFER)
+	{
+		if (count)
+			RT_EXT(GEN_BUFFER, true);
+		else
+			RT_EXT(GEN_BUFFER, false);
+	}
+	else if (gen == GEN_PT)
+	{
+		if (count)
+			RT_EXT(GEN_PT, true);
+		else
+			RT_EXT(GEN_PT, false);
+	}
+	else
+	{
+		if (count)
+			RT_EXT(GEN_PARITY, true);
+		else
+			RT_EXT(GEN_PARITY, false);
+	}
+#undef RT_EXT
+}
+
+void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t s)
+{
+	const dim3 g(persistent_grid(max_items)), b(BLOCK);
+	if (count)
+		hipLaunchKernelGGL((k_shade_parity<true>), g, b, 0, (hipStream_t)s, p, max_items);
+	else
+		hipLaunchKernelGGL((k_shade_parity<false>), g, b, 0, (hipStream_t)s, p, max_items);
+}
+
+void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
+{
+	hipLaunchKernelGGL(k_shade_pt, dim3(persistent_grid(max_items)), dim3(BLOCK), 0, (hipStream_t)s, p);
+}
+
+void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
+{
+	const dim3 g(persistent_grid(max_items)), b(BLOCK);
+	if (count)
+		hipLaunchKernelGGL((k_connect<true>), g, b, 0, (hipStream_t)s, p);
+	else
+		hipLaunchKernelGGL((k_connect<false>), g, b, 0, (hipStream_t)s, p);
+}
+
+void launch_resolve(const Params &p, stream_t s)
+{
+	hipLaunchKernelGGL(k_resolve, dim3(persistent_grid(p.fr.W * p.fr.local_rows)), dim3(BLOCK), 0, (hipStream_t)s, p);
+}
+
+void launch_present(const Params &p, f4 *out, float scale, int full, stream_t s)
+{
+	hipLaunchKernelGGL(k_present, dim3(persistent_grid(p.fr.W * p.fr.local_rows)), dim3(BLOCK), 0, (hipStream_t)s, p,
+					   out, scale, full);
+}
+
+void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, uint32_t local_rows, uint32_t world,
+						 stream_t s)
+{
+	hipLaunchKernelGGL(k_deinterleave, dim3(persistent_grid(W * H)), dim3(BLOCK), 0, (hipStream_t)s, gathered, out, W, H,
+					   local_rows, world);
+}
+
+void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_verts, const f4 *verts,
+				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s)
+{
+	hipStream_t st = (hipStream_t)s;
+	hipMemsetAsync(flags, 0, sizeof(uint32_t) * node_count, st);
+	hipLaunchKernelGGL(k_refit_tris, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tri_verts, verts, indices,
+					   tri_count);
+	hipLaunchKernelGGL(k_refit_nodes, dim3((node_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, parents,
+					   node_count, tri_verts, flags);
+}
+
+// ================================================================================================================
+#else // RFWHIP_HOST_EMULATION: the same work items driven by plain loops (tests/emu only — never shipped)
+// ================================================================================================================
+
+void set_device_cus(int) {}
+void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count); }
+
+void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
+					   uint32_t packets_per_sample, uint32_t spp, stream_t)
+{
+	const uint32_t total = packets_per_sample * spp;
+	for (uint32_t r = 0; r < (total + RNG_RUN - 1) / RNG_RUN; r++)
+		rng_states_item(states, base_state, jump_table, total, r);
+}
+void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
+{
+	Ctx ctx;
+	const uint32_t n = gen == GEN_BUFFER ? p.wv.counters->ext[p.depth] : max_items;
+	for (uint32_t i = 0; i < n; i++)
+	{
+		if (gen == GEN_BUFFER)
+			count ? extend_item<GEN_BUFFER, true>(p, i, true, ctx) : extend_item<GEN_BUFFER, false>(p, i, true, ctx);
+		else if (gen == GEN_PT)
+			count ? extend_item<GEN_PT, true>(p, i, true, ctx) : extend_item<GEN_PT, false>(p, i, true, ctx);
+		else
+			count ? extend_item<GEN_PARITY, true>(p, i, true, ctx) : extend_item<GEN_PARITY, false>(p, i, true, ctx);
+	}
+}
+void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t)
+{
+	Ctx ctx;
+	for (uint32_t i = 0; i < max_items; i++)
+		count ? shade_parity_item<true>(p, i, true, ctx) : shade_parity_item<false>(p, i, true, ctx);
+}
+void launch_shade_pt(const Params &p, uint32_t, stream_t)
+{
+	Ctx ctx;
+	const uint32_t n = p.wv.counters->ext[p.depth];
+	for (uint32_t i = 0; i < n; i++)
+		shade_pt_item(p, i, true, ctx);
+}
+void launch_connect(const Params &p, bool count, uint32_t, stream_t)
+{
+	Ctx ctx;
+	const uint32_t n = p.wv.counters->shadow[p.depth];
+	for (uint32_t i = 0; i < n; i++)
+		count ? connect_item<true>(p, i, true, ctx) : connect_item<false>(p, i, true, ctx);
+}
+void launch_resolve(const Params &p, stream_t)
+{
+	for (uint32_t i = 0; i < p.fr.W * p.fr.local_rows; i++)
+		resolve_item(p, i);
+}
+void launch_present(const Params &p, f4 *out, float scale, int full, stream_t)
+{
+	for (uint32_t i = 0; i < p.fr.W * p.fr.local_rows; i++)
+		present_item(p, out, scale, full, i);
+}
+void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, uint32_t local_rows, uint32_t world, stream_t)
+{
+	for (uint32_t i = 0; i < W * H; i++)
+		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_verts, const f4 *verts,
+				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)
+{
+	for (uint32_t i = 0; i < tri_count; i++)
+		refit_tris_item(tri_verts, verts, indices, i);
+	memset(flags, 0, sizeof(uint32_t) * node_count);
+	for (uint32_t i = 0; i < node_count; i++)
+	{
+		const Node n = nodes[i];
+		if (n.count < 0 || i == 1u)
+			continue;
+		float mn[3], mx[3];
+		leaf_bounds(n, tri_verts, mn, mx);
+		for (int a = 0; a < 3; a++)
+			nodes[i].bmin[a] = mn[a], nodes[i].bmax[a] = mx[a];
+		int cur = (int)i;
+		for (;;)
+		{
+			const int parent = parents[cur];
+			if (parent < 0)
+				break;
+			if (flags[parent]++ == 0u)
+				break;
+			const int l = nodes[parent].left_first;
+			for (int a = 0; a < 3; a++)
+			{
+				nodes[parent].bmin[a] = fminf(nodes[l].bmin[a], nodes[l + 1].bmin[a]);
+				nodes[parent].bmax[a] = fmaxf(nodes[l].bmax[a], nodes[l + 1].bmax[a]);
+			}
+			cur = parent;
+		}
+	}
+}
+
+#endif
+
+} // namespace rtk

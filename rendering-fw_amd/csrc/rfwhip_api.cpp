@@ -1,0 +1,1497 @@
+// rfwhip_api.cpp — the C ABI of include/rfwhip.h: scene residency in HBM, BVH construction, wave scheduling.
+//
+// Host-side responsibilities (the kernels are in kernels.hip):
+//   * copy every borrowed host buffer into device memory inside the call (context.h ownership rules),
+//   * build one BVH2 per mesh (bvh_build.cpp), concatenate all meshes into the flat arrays of rt::SceneView,
+//     build the top-level BVH over instances in update(), refit instead of rebuild when a mesh keeps its counts,
+//   * enqueue the wavefront stages of a frame on the context's HIP stream without any host read-back between
+//     bounces (contrast CUDART/src/Context.cpp:98,145), gather stage timings with hipEvents.
+#include "rfwhip.h"
+
+#include "bvh_build.h"
+#include "kernels.h"
+#include "rt_types.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#if !defined(RFWHIP_HOST_EMULATION)
+#include <hip/hip_runtime.h>
+#endif
+
+using rt::f4;
+
+// =================================================================================================================
+// error reporting
+// =================================================================================================================
+static thread_local char g_error[1024] = "";
+static int set_error(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	return code;
+}
+extern "C" const char *rfwhip_last_error(void) { return g_error; }
+extern "C" const char *rfwhip_version(void)
+{
+#if defined(RFWHIP_HOST_EMULATION)
+	return "rfwhip 0.1 (HOST EMULATION BUILD — tests only)";
+#else
+	return "rfwhip 0.1 (gfx950 HIP)";
+#endif
+}
+
+// =================================================================================================================
+// device memory / stream abstraction
+// =================================================================================================================
+namespace dm
+{
+#if !defined(RFWHIP_HOST_EMULATION)
+#define DM_CHECK(x)                                                                                      \
+	do                                                                                                   \
+	{                                                                                                    \
+		hipError_t e_ = (x);                                                                             \
+		if (e_ != hipSuccess)                                                                            \
+			return set_error(RFWHIP_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+static int init(int device, int *cus)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return set_error(RFWHIP_ERR_NO_DEVICE, "no HIP device visible: the rendercore has no CPU path");
+	if (device < 0 || device >= n)
+		return set_error(RFWHIP_ERR_NO_DEVICE, "device ordinal %d out of range (%d devices)", device, n);
+	DM_CHECK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	DM_CHECK(hipGetDeviceProperties(&prop, device));
+	*cus = prop.multiProcessorCount;
+	return 0;
+}
+static int use(int device)
+{
+	DM_CHECK(hipSetDevice(device));
+	return 0;
+}
+static int alloc(void **p, size_t bytes)
+{
+	DM_CHECK(hipMalloc(p, bytes ? bytes : 16));
+	return 0;
+}
+static void release(void *p)
+{
+	if (p)
+		(void)hipFree(p);
+}
+static int h2d(void *d, const void *h, size_t n, void *s)
+{
+	if (n)
+		DM_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+	return 0;
+}
+static int d2h(void *h, const void *d, size_t n, void *s)
+{
+	if (n)
+	{
+		DM_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+		DM_CHECK(hipStreamSynchronize((hipStream_t)s));
+	}
+	return 0;
+}
+static int d2d(void *dst, const void *src, size_t n, void *s)
+{
+	if (n)
+		DM_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+	return 0;
+}
+static int zero(void *d, size_t n, void *s)
+{
+	if (n)
+		DM_CHECK(hipMemsetAsync(d, 0, n, (hipStream_t)s));
+	return 0;
+}
+static int sync(void *s)
+{
+	DM_CHECK(hipStreamSynchronize((hipStream_t)s));
+	return 0;
+}
+static int stream_create(void **s)
+{
+	hipStream_t st;
+	DM_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	*s = st;
+	return 0;
+}
+static void stream_destroy(void *s)
+{
+	if (s)
+		(void)hipStreamDestroy((hipStream_t)s);
+}
+static int last_launch_error()
+{
+	DM_CHECK(hipGetLastError());
+	return 0;
+}
+typedef hipEvent_t event_t;
+static int event_create(event_t *e)
+{
+	DM_CHECK(hipEventCreate(e));
+	return 0;
+}
+static void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+static int event_record(event_t e, void *s)
+{
+	DM_CHECK(hipEventRecord(e, (hipStream_t)s));
+	return 0;
+}
+static float event_ms(event_t a, event_t b)
+{
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, a, b) != hipSuccess)
+		return 0.0f;
+	return ms;
+}
+#else
+// ---- host emulation (tests/emu): plain heap memory, "streams" are immediate ----
+static int init(int, int *cus)
+{
+	*cus = 1;
+	return 0;
+}
+static int use(int) { return 0; }
+static int alloc(void **p, size_t bytes)
+{
+	*p = calloc(bytes ? bytes : 16, 1);
+	return *p ? 0 : set_error(RFWHIP_ERR_HIP, "out of memory");
+}
+static void release(void *p) { free(p); }
+static int h2d(void *d, const void *h, size_t n, void *)
+{
+	memcpy(d, h, n);
+	return 0;
+}
+static int d2h(void *h, const void *d, size_t n, void *)
+{
+	memcpy(h, d, n);
+	return 0;
+}
+static int d2d(void *dst, const void *src, size_t n, void *)
+{
+	memmove(dst, src, n);
+	return 0;
+}
+static int zero(void *d, size_t n, void *)
+{
+	memset(d, 0, n);
+	return 0;
+}
+static int sync(void *) { return 0; }
+static int stream_create(void **s)
+{
+	*s = nullptr;
+	return 0;
+}
+static void stream_destroy(void *) {}
+static int last_launch_error() { return 0; }
+typedef std::chrono::steady_clock::time_point event_t;
+static int event_create(event_t *) { return 0; }
+static void event_destroy(event_t) {}
+static int event_record(event_t &e, void *)
+{
+	e = std::chrono::steady_clock::now();
+	return 0;
+}
+static float event_ms(event_t a, event_t b) { return std::chrono::duration<float, std::milli>(b - a).count(); }
+#endif
+} // namespace dm
+
+#define RF_TRY(x)            \
+	do                       \
+	{                        \
+		const int rc_ = (x); \
+		if (rc_)             \
+			return rc_;      \
+	} while (0)
+
+struct DevBuf
+{
+	void *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap && p)
+			return 0;
+		dm::release(p);
+		p = nullptr, cap = 0;
+		// grow with headroom so animation / resize do not reallocate every call
+		const size_t want = bytes + bytes / 8 + 256;
+		RF_TRY(dm::alloc(&p, want));
+		cap = want;
+		return 0;
+	}
+	void free_()
+	{
+		dm::release(p);
+		p = nullptr, cap = 0;
+	}
+	template <typename T> T *as() const { return (T *)p; }
+};
+
+// =================================================================================================================
+// context
+// =================================================================================================================
+struct MeshRec
+{
+	bool used = false;
+	size_t vertexCount = 0, triCount = 0;
+	bool indexed = false;
+	bvh::Result bvh;				   // host copy of the topology as built
+	std::vector<f4> leaf_verts;		   // 3 per leaf slot (host staging for (re)upload)
+	std::vector<rt::TriShade> shade;   // mesh order
+	float bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};
+	DevBuf d_verts, d_indices;		   // raw vertices / indices (kept for refit)
+	DevBuf d_parents, d_flags;		   // refit helpers
+	uint32_t node_base = 0, tri_base = 0, shade_base = 0;
+	bool resident = false; // placed in the global arrays by the last update()
+	bool dirty = true;	   // host staging newer than the global arrays
+	bool refit_pending = false;
+};
+
+struct InstRec
+{
+	bool used = false;
+	size_t mesh = 0;
+	float transform[16];
+	float normal[9];
+};
+
+enum KernelFamily
+{
+	KF_GENERATE = 0,
+	KF_EXTEND = 1,
+	KF_SHADE = 2,
+	KF_CONNECT = 3,
+	KF_FINALIZE = 4,
+	KF_REFIT = 5,
+	KF_COUNT = 6
+};
+
+struct TimedSpan
+{
+	dm::event_t a, b;
+	int family;
+	int depth; // wave depth for extend spans, -1 otherwise
+};
+
+struct rfwhip_context
+{
+	int device = 0, rank = 0, world = 1, cus = 256;
+	void *stream = nullptr;
+	bool cleaned = false;
+	uint32_t W = 0, H = 0;
+
+	// settings
+	int integrator = 0; // 0 parity, 1 pt
+	int spp = 1;
+	int max_depth = 2;
+	int jitter = 0; // 0 xor128, 1 center
+	int stage_timing = 0;
+	int count_traversal = 0;
+	int lds_nodes = 0;
+
+	// scene (host side)
+	std::vector<MeshRec> meshes;
+	std::vector<InstRec> instances;
+	rfwhip_light_count lc = {0, 0, 0, 0};
+	bool scene_dirty = true;
+
+	// scene (device side)
+	DevBuf d_nodes, d_tri_verts, d_tri_shade, d_tlas_nodes, d_tlas_prims, d_instances;
+	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
+	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
+	uint32_t tlas_root_entry = 0, instance_count = 0;
+	rt::SceneView sv;
+
+	// wave state
+	DevBuf d_org[2], d_dir2[2], d_thr[2], d_hit, d_hit_inst, d_hit0, d_hit0_inst, d_sh_org, d_sh_dir, d_sh_rad, d_rad,
+		d_acc, d_counters, d_packet_rng, d_jump_table, d_present;
+	uint32_t samples_done = 0;
+	size_t wave_capacity = 0; // path slots the wave buffers can hold
+	rt::FrameView fr;
+	bool jump_table_uploaded = false;
+
+	// xor128 stream position (EmbreeRT's m_Rng persists across frames, Context.h:78)
+	uint32_t rng_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+	std::vector<uint32_t> jump_table; // 64 x 128 x 4
+
+	uint32_t probe_x = 0, probe_y = 0;
+	uint32_t probe_inst = 0, probe_prim = 0;
+	float probe_dist = 0;
+
+	// timing
+	std::vector<TimedSpan> spans;
+	std::vector<dm::event_t> event_pool;
+	size_t events_used = 0;
+	float kernel_ms[KF_COUNT] = {0, 0, 0, 0, 0, 0};
+	uint32_t kernel_launches[KF_COUNT] = {0, 0, 0, 0, 0, 0};
+	rfwhip_render_stats stats;
+	std::chrono::steady_clock::time_point render_t0;
+	bool render_pending = false;
+	rfwhip_counters totals;
+};
+
+// =================================================================================================================
+// small math
+// =================================================================================================================
+static void mat4_inverse(const float *m, float *inv)
+{
+	float t[16];
+	t[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+	t[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+	t[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+	t[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+	t[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+	t[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+	t[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+	t[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+	t[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+	t[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+	t[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+	t[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+	t[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+	t[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+	t[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+	t[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+	float det = m[0] * t[0] + m[1] * t[4] + m[2] * t[8] + m[3] * t[12];
+	det = 1.0f / det;
+	for (int i = 0; i < 16; i++)
+		inv[i] = t[i] * det;
+}
+
+// xor128 is GF(2)-linear: jump_table[k] = M^(2^k), 128 columns of 4 words each.
+static uint32_t xor128_step(uint32_t s[4])
+{
+	const uint32_t t = s[0] ^ (s[0] << 11);
+	s[0] = s[1], s[1] = s[2], s[2] = s[3];
+	s[3] = s[3] ^ (s[3] >> 19) ^ (t ^ (t >> 8));
+	return s[3];
+}
+static void gf2_apply(const uint32_t *m, uint32_t s[4])
+{
+	uint32_t r[4] = {0, 0, 0, 0};
+	for (int w = 0; w < 4; w++)
+		for (int b = 0; b < 32; b++)
+			if ((s[w] >> b) & 1u)
+			{
+				const uint32_t *c = m + 4 * (w * 32 + b);
+				r[0] ^= c[0], r[1] ^= c[1], r[2] ^= c[2], r[3] ^= c[3];
+			}
+	memcpy(s, r, 16);
+}
+static void build_jump_table(std::vector<uint32_t> &tab)
+{
+	tab.assign(64 * 512, 0u);
+	for (int i = 0; i < 128; i++)
+	{
+		uint32_t e[4] = {0, 0, 0, 0};
+		e[i / 32] = 1u << (i % 32);
+		xor128_step(e);
+		memcpy(&tab[4 * i], e, 16);
+	}
+	for (int k = 1; k < 64; k++)
+		for (int i = 0; i < 128; i++)
+		{
+			uint32_t c[4];
+			memcpy(c, &tab[512 * (k - 1) + 4 * i], 16);
+			gf2_apply(&tab[512 * (k - 1)], c);
+			memcpy(&tab[512 * k + 4 * i], c, 16);
+		}
+}
+static void xor128_jump(const std::vector<uint32_t> &tab, uint32_t s[4], unsigned long long draws)
+{
+	for (int k = 0; k < 64; k++)
+		if ((draws >> k) & 1ull)
+			gf2_apply(&tab[512 * k], s);
+}
+
+static uint32_t total_light_count(const rfwhip_context *c)
+{
+	return c->lc.areaLightCount + c->lc.pointLightCount + c->lc.spotLightCount + c->lc.directionalLightCount;
+}
+
+static uint32_t local_rows_of(const rfwhip_context *c)
+{
+	const uint32_t strips = (c->H + rt::STRIP_ROWS - 1) / rt::STRIP_ROWS;
+	return ((strips + c->world - 1) / c->world) * rt::STRIP_ROWS;
+}
+
+// =================================================================================================================
+// lifetime
+// =================================================================================================================
+extern "C" int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_context **out)
+{
+	if (!out || world < 1 || rank < 0 || rank >= world)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_create: bad arguments (rank %d, world %d)", rank, world);
+	int cus = 0;
+	RF_TRY(dm::init(device_ordinal, &cus));
+	rfwhip_context *c = new rfwhip_context();
+	c->device = device_ordinal, c->rank = rank, c->world = world, c->cus = cus;
+	rtk::set_device_cus(cus);
+	memset(&c->stats, 0, sizeof(c->stats));
+	memset(&c->totals, 0, sizeof(c->totals));
+	memset(&c->sv, 0, sizeof(c->sv));
+	memset(&c->fr, 0, sizeof(c->fr));
+	if (dm::stream_create(&c->stream))
+	{
+		delete c;
+		return RFWHIP_ERR_HIP;
+	}
+	build_jump_table(c->jump_table);
+	if (c->d_counters.ensure(sizeof(rt::WaveCounters)) || dm::zero(c->d_counters.p, sizeof(rt::WaveCounters), c->stream))
+	{
+		delete c;
+		return RFWHIP_ERR_HIP;
+	}
+	*out = c;
+	return RFWHIP_OK;
+}
+
+static void free_all(rfwhip_context *c)
+{
+	for (auto &m : c->meshes)
+		m.d_verts.free_(), m.d_indices.free_(), m.d_parents.free_(), m.d_flags.free_();
+	DevBuf *bufs[] = {&c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_nodes, &c->d_tlas_prims, &c->d_instances,
+					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
+					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
+					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org, &c->d_sh_dir,
+					  &c->d_sh_rad, &c->d_rad, &c->d_acc, &c->d_counters, &c->d_packet_rng, &c->d_jump_table,
+					  &c->d_present};
+	for (DevBuf *b : bufs)
+		b->free_();
+	for (auto &e : c->event_pool)
+		dm::event_destroy(e);
+	c->event_pool.clear();
+	c->wave_capacity = 0;
+}
+
+extern "C" int rfwhip_cleanup(rfwhip_context *c)
+{
+	if (!c)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null context");
+	if (c->cleaned)
+		return RFWHIP_OK; // the reference calls cleanup() twice on unload
+	dm::use(c->device);
+	if (c->stream)
+		dm::sync(c->stream);
+	free_all(c);
+	c->meshes.clear(), c->instances.clear();
+	c->cleaned = true;
+	return RFWHIP_OK;
+}
+
+extern "C" void rfwhip_destroy(rfwhip_context *c)
+{
+	if (!c)
+		return;
+	rfwhip_cleanup(c);
+	dm::stream_destroy(c->stream);
+	delete c;
+}
+
+#define CTX_ENTER(c)                                                                      \
+	if (!(c))                                                                             \
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null context");                    \
+	if ((c)->cleaned)                                                                     \
+		return set_error(RFWHIP_ERR_STATE, "context already cleaned up");                 \
+	RF_TRY(dm::use((c)->device))
+
+extern "C" int rfwhip_init(rfwhip_context *c, uint32_t width, uint32_t height)
+{
+	CTX_ENTER(c);
+	if (!width || !height || width > 65536 || height > 65536)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_init: bad target size %ux%u", width, height);
+	RF_TRY(dm::sync(c->stream));
+	c->W = width, c->H = height;
+	const uint32_t lr = local_rows_of(c);
+	RF_TRY(c->d_acc.ensure((size_t)lr * width * sizeof(f4)));
+	RF_TRY(dm::zero(c->d_acc.p, (size_t)lr * width * sizeof(f4), c->stream));
+	c->samples_done = 0;
+	c->fr.W = width, c->fr.H = height, c->fr.local_rows = lr;
+	c->fr.tiles_x = (width + rt::TILE - 1) / rt::TILE;
+	c->fr.slots = c->fr.tiles_x * rt::TILE * lr;
+	c->fr.rank = (uint32_t)c->rank, c->fr.world = (uint32_t)c->world;
+	return RFWHIP_OK;
+}
+
+// =================================================================================================================
+// scene
+// =================================================================================================================
+extern "C" int rfwhip_set_sky(rfwhip_context *c, const float *rgb, size_t width, size_t height)
+{
+	CTX_ENTER(c);
+	if (!rgb || !width || !height)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_sky: empty sky");
+	std::vector<f4> px(width * height);
+	for (size_t i = 0; i < width * height; i++)
+		px[i] = f4{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 0.0f};
+	RF_TRY(dm::sync(c->stream));
+	RF_TRY(c->d_sky.ensure(px.size() * sizeof(f4)));
+	RF_TRY(dm::h2d(c->d_sky.p, px.data(), px.size() * sizeof(f4), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->sky_w = (uint32_t)width, c->sky_h = (uint32_t)height;
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_set_textures(rfwhip_context *c, const rfwhip_texture *tex, size_t count)
+{
+	CTX_ENTER(c);
+	if (count && !tex)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_textures: null array");
+	std::vector<rt::TexDesc> desc(count);
+	std::vector<uint32_t> u32;
+	std::vector<f4> f4s;
+	for (size_t i = 0; i < count; i++)
+	{
+		rt::TexDesc &d = desc[i];
+		memset(&d, 0, sizeof(d));
+		d.type = tex[i].type, d.width = tex[i].width, d.height = tex[i].height, d.texelCount = tex[i].texelCount;
+		if (!tex[i].data || !tex[i].texelCount)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_textures: texture %zu has no data", i);
+		if (tex[i].type == RFWHIP_TEX_UINT)
+		{
+			d.offset = (uint32_t)u32.size();
+			const uint32_t *src = (const uint32_t *)tex[i].data;
+			u32.insert(u32.end(), src, src + tex[i].texelCount);
+		}
+		else if (tex[i].type == RFWHIP_TEX_FLOAT4)
+		{
+			d.offset = (uint32_t)f4s.size();
+			const f4 *src = (const f4 *)tex[i].data;
+			f4s.insert(f4s.end(), src, src + tex[i].texelCount);
+		}
+		else
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_textures: texture %zu has unknown type %u", i, tex[i].type);
+	}
+	RF_TRY(dm::sync(c->stream));
+	RF_TRY(c->d_textures.ensure(desc.size() * sizeof(rt::TexDesc)));
+	RF_TRY(c->d_tex_u32.ensure(u32.size() * 4));
+	RF_TRY(c->d_tex_f4.ensure(f4s.size() * sizeof(f4)));
+	RF_TRY(dm::h2d(c->d_textures.p, desc.data(), desc.size() * sizeof(rt::TexDesc), c->stream));
+	RF_TRY(dm::h2d(c->d_tex_u32.p, u32.data(), u32.size() * 4, c->stream));
+	RF_TRY(dm::h2d(c->d_tex_f4.p, f4s.data(), f4s.size() * sizeof(f4), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->texture_count = (uint32_t)count;
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *materials,
+									const rfwhip_material_tex_ids *tex_ids, size_t count)
+{
+	(void)tex_ids; // the CPU-style texaddr (index into the texture array) is what the kernels resolve
+	CTX_ENTER(c);
+	if (count && !materials)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_materials: null array");
+	RF_TRY(dm::sync(c->stream));
+	RF_TRY(c->d_materials.ensure(count * sizeof(rfwhip_material)));
+	RF_TRY(dm::h2d(c->d_materials.p, materials, count * sizeof(rfwhip_material), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->material_count = (uint32_t)count;
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+static void fill_shade_records(MeshRec &m, const rfwhip_triangle *tris)
+{
+	m.shade.resize(m.triCount);
+	for (size_t i = 0; i < m.triCount; i++)
+	{
+		const rfwhip_triangle &t = tris[i];
+		rt::TriShade &s = m.shade[i];
+		s.n0 = f4{t.vN0[0], t.vN0[1], t.vN0[2], t.Nx};
+		s.n1 = f4{t.vN1[0], t.vN1[1], t.vN1[2], t.Ny};
+		s.n2 = f4{t.vN2[0], t.vN2[1], t.vN2[2], t.Nz};
+		float lt, mt;
+		memcpy(&lt, &t.lightTriIdx, 4), memcpy(&mt, &t.material, 4);
+		s.tu = f4{t.u0, t.u1, t.u2, lt};
+		s.tv = f4{t.v0, t.v1, t.v2, mt};
+		s.ex = f4{t.area, t.LOD, 0.0f, 0.0f};
+	}
+}
+
+static inline void tri_indices(const rfwhip_mesh *mesh, size_t i, uint32_t &a, uint32_t &b, uint32_t &cidx)
+{
+	if (mesh->indices)
+		a = mesh->indices[3 * i], b = mesh->indices[3 * i + 1], cidx = mesh->indices[3 * i + 2];
+	else
+		a = (uint32_t)(3 * i), b = a + 1, cidx = a + 2;
+}
+
+constexpr int BLAS_DEPTH_LIMIT = 42;
+constexpr int TLAS_DEPTH_LIMIT = 20; // + 1 sentinel < LDS_STACK + SPILL_STACK = 64
+
+extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mesh *mesh)
+{
+	CTX_ENTER(c);
+	if (!mesh || !mesh->vertices || !mesh->triangles || !mesh->vertexCount || !mesh->triangleCount)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_mesh: empty mesh %zu", index);
+	if (!mesh->indices && mesh->vertexCount < 3 * mesh->triangleCount)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_mesh: non-indexed mesh %zu needs 3 vertices per triangle", index);
+	if (mesh->triangleCount > rt::ENTRY_FIRST_MASK)
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: more than 2^27 triangles in one mesh");
+	if (mesh->indices)
+		for (size_t i = 0; i < 3 * mesh->triangleCount; i++)
+			if (mesh->indices[i] >= mesh->vertexCount)
+				return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_mesh: index %u out of range in mesh %zu", mesh->indices[i], index);
+	if (index >= c->meshes.size())
+		c->meshes.resize(index + 1);
+	MeshRec &m = c->meshes[index];
+	const bool same_topology = m.used && m.resident && !m.dirty && m.vertexCount == mesh->vertexCount &&
+							   m.triCount == mesh->triangleCount && m.indexed == (mesh->indices != nullptr);
+	RF_TRY(dm::sync(c->stream));
+	// vertices / indices always go to the device (the refit kernels read them there)
+	RF_TRY(m.d_verts.ensure(mesh->vertexCount * sizeof(f4)));
+	RF_TRY(dm::h2d(m.d_verts.p, mesh->vertices, mesh->vertexCount * sizeof(f4), c->stream));
+	if (mesh->indices)
+	{
+		RF_TRY(m.d_indices.ensure(mesh->triangleCount * 12));
+		RF_TRY(dm::h2d(m.d_indices.p, mesh->indices, mesh->triangleCount * 12, c->stream));
+	}
+	m.vertexCount = mesh->vertexCount, m.triCount = mesh->triangleCount, m.indexed = mesh->indices != nullptr;
+	m.used = true;
+	fill_shade_records(m, mesh->triangles);
+	// mesh bounds (for the instance boxes of the TLAS)
+	for (int a = 0; a < 3; a++)
+		m.bounds_min[a] = 1e34f, m.bounds_max[a] = -1e34f;
+	const f4 *V = (const f4 *)mesh->vertices;
+	if (same_topology)
+	{
+		// animated mesh: same counts => refit on the device (EmbreeRT/src/Mesh.cpp:33-35, top_level_bvh.cpp:26)
+		for (size_t i = 0; i < mesh->triangleCount; i++)
+		{
+			uint32_t ia, ib, ic;
+			tri_indices(mesh, i, ia, ib, ic);
+			const uint32_t id[3] = {ia, ib, ic};
+			for (int k = 0; k < 3; k++)
+			{
+				const f4 &p = V[id[k]];
+				m.bounds_min[0] = std::min(m.bounds_min[0], p.x), m.bounds_max[0] = std::max(m.bounds_max[0], p.x);
+				m.bounds_min[1] = std::min(m.bounds_min[1], p.y), m.bounds_max[1] = std::max(m.bounds_max[1], p.y);
+				m.bounds_min[2] = std::min(m.bounds_min[2], p.z), m.bounds_max[2] = std::max(m.bounds_max[2], p.z);
+			}
+		}
+		for (int a = 0; a < 3; a++)
+			m.bounds_min[a] -= 2e-5f, m.bounds_max[a] += 2e-5f;
+		RF_TRY(dm::h2d(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.shade.data(), m.shade.size() * sizeof(rt::TriShade), c->stream));
+		dm::event_t ea, eb;
+		const bool timed = c->stage_timing != 0;
+		if (timed)
+		{
+			dm::event_create(&ea), dm::event_create(&eb);
+			dm::event_record(ea, c->stream);
+		}
+		rtk::launch_refit(c->d_nodes.as<rt::Node>() + m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+						  c->d_tri_verts.as<f4>() + 3ull * m.tri_base, m.d_verts.as<f4>(),
+						  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, m.d_flags.as<uint32_t>(),
+						  c->stream);
+		RF_TRY(dm::last_launch_error());
+		if (timed)
+			dm::event_record(eb, c->stream);
+		RF_TRY(dm::sync(c->stream));
+		if (timed)
+		{
+			c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
+			c->kernel_launches[KF_REFIT] += 2;
+			c->stats.animationTime = dm::event_ms(ea, eb);
+			dm::event_destroy(ea), dm::event_destroy(eb);
+		}
+		c->scene_dirty = true; // instance boxes change: the TLAS is rebuilt in update()
+		return RFWHIP_OK;
+	}
+	// (re)build
+	const size_t n = mesh->triangleCount;
+	std::vector<float> bmin(3 * n), bmax(3 * n);
+	for (size_t i = 0; i < n; i++)
+	{
+		uint32_t ia, ib, ic;
+		tri_indices(mesh, i, ia, ib, ic);
+		const f4 &p0 = V[ia], &p1 = V[ib], &p2 = V[ic];
+		// per-triangle box grown by 1e-5 (bvh_tree.cpp:407-412)
+		bmin[3 * i + 0] = std::min(p0.x, std::min(p1.x, p2.x)) - 1e-5f, bmax[3 * i + 0] = std::max(p0.x, std::max(p1.x, p2.x)) + 1e-5f;
+		bmin[3 * i + 1] = std::min(p0.y, std::min(p1.y, p2.y)) - 1e-5f, bmax[3 * i + 1] = std::max(p0.y, std::max(p1.y, p2.y)) + 1e-5f;
+		bmin[3 * i + 2] = std::min(p0.z, std::min(p1.z, p2.z)) - 1e-5f, bmax[3 * i + 2] = std::max(p0.z, std::max(p1.z, p2.z)) + 1e-5f;
+	}
+	bvh::build(bmin.data(), bmax.data(), n, 4, BLAS_DEPTH_LIMIT, m.bvh);
+	if (m.bvh.max_depth > BLAS_DEPTH_LIMIT)
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: BVH depth %d exceeds the traversal stack", m.bvh.max_depth);
+	for (int a = 0; a < 3; a++)
+		m.bounds_min[a] = m.bvh.nodes[0].bmin[a], m.bounds_max[a] = m.bvh.nodes[0].bmax[a];
+	m.leaf_verts.resize(3 * n);
+	for (size_t s = 0; s < n; s++)
+	{
+		const uint32_t prim = m.bvh.order[s];
+		uint32_t ia, ib, ic;
+		tri_indices(mesh, prim, ia, ib, ic);
+		float pw;
+		memcpy(&pw, &prim, 4);
+		m.leaf_verts[3 * s + 0] = f4{V[ia].x, V[ia].y, V[ia].z, pw};
+		m.leaf_verts[3 * s + 1] = f4{V[ib].x, V[ib].y, V[ib].z, 1.0f};
+		m.leaf_verts[3 * s + 2] = f4{V[ic].x, V[ic].y, V[ic].z, 1.0f};
+	}
+	RF_TRY(m.d_parents.ensure(m.bvh.parents.size() * sizeof(int)));
+	RF_TRY(dm::h2d(m.d_parents.p, m.bvh.parents.data(), m.bvh.parents.size() * sizeof(int), c->stream));
+	RF_TRY(m.d_flags.ensure(m.bvh.nodes.size() * sizeof(uint32_t)));
+	RF_TRY(dm::sync(c->stream));
+	m.dirty = true, m.resident = false;
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_set_instance(rfwhip_context *c, size_t index, size_t mesh_index, const float *transform16,
+								   const float *normal_matrix9)
+{
+	CTX_ENTER(c);
+	if (!transform16 || !normal_matrix9)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_instance: null matrix");
+	if (mesh_index >= c->meshes.size() || !c->meshes[mesh_index].used)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_instance: instance %zu refers to unknown mesh %zu", index, mesh_index);
+	if (index >= c->instances.size())
+		c->instances.resize(index + 1);
+	InstRec &in = c->instances[index];
+	in.used = true, in.mesh = mesh_index;
+	memcpy(in.transform, transform16, 64), memcpy(in.normal, normal_matrix9, 36);
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_set_lights(rfwhip_context *c, rfwhip_light_count n, const rfwhip_area_light *area,
+								 const rfwhip_point_light *point, const rfwhip_spot_light *spot,
+								 const rfwhip_directional_light *directional)
+{
+	CTX_ENTER(c);
+	if ((n.areaLightCount && !area) || (n.pointLightCount && !point) || (n.spotLightCount && !spot) ||
+		(n.directionalLightCount && !directional))
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_lights: count > 0 with a null array");
+	RF_TRY(dm::sync(c->stream));
+	RF_TRY(c->d_area.ensure(n.areaLightCount * sizeof(rfwhip_area_light)));
+	RF_TRY(c->d_point.ensure(n.pointLightCount * sizeof(rfwhip_point_light)));
+	RF_TRY(c->d_spot.ensure(n.spotLightCount * sizeof(rfwhip_spot_light)));
+	RF_TRY(c->d_dir.ensure(n.directionalLightCount * sizeof(rfwhip_directional_light)));
+	RF_TRY(dm::h2d(c->d_area.p, area, n.areaLightCount * sizeof(rfwhip_area_light), c->stream));
+	RF_TRY(dm::h2d(c->d_point.p, point, n.pointLightCount * sizeof(rfwhip_point_light), c->stream));
+	RF_TRY(dm::h2d(c->d_spot.p, spot, n.spotLightCount * sizeof(rfwhip_spot_light), c->stream));
+	RF_TRY(dm::h2d(c->d_dir.p, directional, n.directionalLightCount * sizeof(rfwhip_directional_light), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->lc = n;
+	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_update(rfwhip_context *c)
+{
+	CTX_ENTER(c);
+	RF_TRY(dm::sync(c->stream));
+	// ---- place meshes in the global arrays (only when some mesh was rebuilt) ----
+	bool relayout = false;
+	for (auto &m : c->meshes)
+		if (m.used && m.dirty)
+			relayout = true;
+	if (relayout)
+	{
+		size_t nodes = 0, tris = 0;
+		for (auto &m : c->meshes)
+			if (m.used)
+			{
+				m.node_base = (uint32_t)nodes, m.tri_base = (uint32_t)tris, m.shade_base = (uint32_t)tris;
+				nodes += m.bvh.nodes.size(), tris += m.triCount;
+			}
+		// resident meshes were refit on the device: save their current device data before the arrays move
+		std::vector<rt::Node> all_nodes(nodes);
+		std::vector<f4> all_verts(3 * tris);
+		std::vector<rt::TriShade> all_shade(tris);
+		for (auto &m : c->meshes)
+		{
+			if (!m.used)
+				continue;
+			memcpy(&all_nodes[m.node_base], m.bvh.nodes.data(), m.bvh.nodes.size() * sizeof(rt::Node));
+			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
+			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
+		}
+		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
+		RF_TRY(c->d_tri_verts.ensure(all_verts.size() * sizeof(f4)));
+		RF_TRY(c->d_tri_shade.ensure(all_shade.size() * sizeof(rt::TriShade)));
+		RF_TRY(dm::h2d(c->d_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(rt::Node), c->stream));
+		RF_TRY(dm::h2d(c->d_tri_verts.p, all_verts.data(), all_verts.size() * sizeof(f4), c->stream));
+		RF_TRY(dm::h2d(c->d_tri_shade.p, all_shade.data(), all_shade.size() * sizeof(rt::TriShade), c->stream));
+		RF_TRY(dm::sync(c->stream));
+		// meshes that had been refit since their build are re-refit from their device vertices after the move
+		for (auto &m : c->meshes)
+		{
+			if (!m.used)
+				continue;
+			if (m.resident && !m.dirty)
+			{
+				rtk::launch_refit(c->d_nodes.as<rt::Node>() + m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+								  c->d_tri_verts.as<f4>() + 3ull * m.tri_base, m.d_verts.as<f4>(),
+								  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount,
+								  m.d_flags.as<uint32_t>(), c->stream);
+				RF_TRY(dm::last_launch_error());
+			}
+			m.resident = true, m.dirty = false;
+		}
+		RF_TRY(dm::sync(c->stream));
+	}
+	// ---- instances + TLAS ----
+	std::vector<rt::Instance> inst(c->instances.size());
+	std::vector<float> bmin, bmax;
+	std::vector<uint32_t> live;
+	for (size_t i = 0; i < c->instances.size(); i++)
+	{
+		rt::Instance &d = inst[i];
+		memset(&d, 0, sizeof(d));
+		const InstRec &in = c->instances[i];
+		if (!in.used || in.mesh >= c->meshes.size() || !c->meshes[in.mesh].used)
+			continue;
+		const MeshRec &m = c->meshes[in.mesh];
+		float inv[16];
+		mat4_inverse(in.transform, inv);
+		for (int r = 0; r < 3; r++)
+			for (int col = 0; col < 4; col++)
+				d.inv[4 * r + col] = inv[4 * col + r];
+		for (int col = 0; col < 3; col++)
+			for (int r = 0; r < 3; r++)
+				d.nrm[4 * col + r] = in.normal[3 * col + r];
+		d.node_base = m.node_base, d.tri_base = m.tri_base, d.shade_base = m.shade_base;
+		d.root_entry = rt::make_entry(m.bvh.nodes[0].left_first, m.bvh.nodes[0].count, false);
+		float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
+		for (int k = 0; k < 8; k++)
+		{
+			const float p[3] = {k & 1 ? m.bounds_max[0] : m.bounds_min[0], k & 2 ? m.bounds_max[1] : m.bounds_min[1],
+								k & 4 ? m.bounds_max[2] : m.bounds_min[2]};
+			for (int r = 0; r < 3; r++)
+			{
+				const float w = in.transform[r] * p[0] + in.transform[4 + r] * p[1] + in.transform[8 + r] * p[2] + in.transform[12 + r];
+				lo[r] = std::min(lo[r], w), hi[r] = std::max(hi[r], w);
+			}
+		}
+		for (int r = 0; r < 3; r++)
+		{
+			const float pad = 1e-4f + 1e-5f * std::max(std::fabs(lo[r]), std::fabs(hi[r]));
+			bmin.push_back(lo[r] - pad), bmax.push_back(hi[r] + pad);
+		}
+		live.push_back((uint32_t)i);
+	}
+	bvh::Result tl;
+	bvh::build(bmin.data(), bmax.data(), live.size(), 1, TLAS_DEPTH_LIMIT, tl);
+	std::vector<uint32_t> tprims(std::max<size_t>(1, live.size()), 0u);
+	for (size_t k = 0; k < live.size(); k++)
+		tprims[k] = live[tl.order[k]];
+	if (tl.nodes.empty())
+		tl.nodes.resize(2);
+	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
+	RF_TRY(c->d_tlas_nodes.ensure(tl.nodes.size() * sizeof(rt::Node)));
+	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
+	RF_TRY(dm::h2d(c->d_instances.p, inst.data(), inst.size() * sizeof(rt::Instance), c->stream));
+	RF_TRY(dm::h2d(c->d_tlas_nodes.p, tl.nodes.data(), tl.nodes.size() * sizeof(rt::Node), c->stream));
+	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->instance_count = (uint32_t)live.size();
+	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true);
+
+	rt::SceneView &sv = c->sv;
+	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
+	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
+	sv.tlas_nodes = c->d_tlas_nodes.as<rt::Node>(), sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();
+	sv.instances = c->d_instances.as<rt::Instance>();
+	sv.tlas_root_entry = c->tlas_root_entry, sv.instance_count = c->instance_count;
+	sv.materials = c->d_materials.as<rt::MaterialRec>(), sv.material_count = c->material_count;
+	sv.textures = c->d_textures.as<rt::TexDesc>(), sv.texture_count = c->texture_count;
+	sv.tex_u32 = c->d_tex_u32.as<uint32_t>(), sv.tex_f4 = c->d_tex_f4.as<f4>();
+	sv.sky = c->d_sky.as<f4>(), sv.sky_w = c->sky_w, sv.sky_h = c->sky_h;
+	sv.area = c->d_area.as<rt::AreaLight>(), sv.point = c->d_point.as<rt::PointLight>();
+	sv.spot = c->d_spot.as<rt::SpotLight>(), sv.dir = c->d_dir.as<rt::DirectionalLight>();
+	sv.n_area = c->lc.areaLightCount, sv.n_point = c->lc.pointLightCount, sv.n_spot = c->lc.spotLightCount;
+	sv.n_dir = c->lc.directionalLightCount;
+	c->scene_dirty = false;
+	return RFWHIP_OK;
+}
+
+// =================================================================================================================
+// camera
+// =================================================================================================================
+extern "C" void rfwhip_camera_get_view(const rfwhip_camera *cam, rfwhip_camera_view *view)
+{
+	// Camera::get_view, Camera.cpp:74-88 + calculate_matrix :109-115
+	const float dx = cam->direction[0], dy = cam->direction[1], dz = cam->direction[2];
+	// x = normalize(cross(z, (0,1,0)))
+	float rx = dy * 0.0f - 1.0f * dz, ry = dz * 0.0f - 0.0f * dx, rz = dx * 1.0f - 0.0f * dy;
+	const float rl = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+	rx *= rl, ry *= rl, rz *= rl;
+	// y = cross(x, z)
+	const float ux = ry * dz - dy * rz, uy = rz * dx - dz * rx, uz = rx * dy - dx * ry;
+	const float pi = 3.14159265358979323846f;
+	view->spreadAngle = (cam->FOV * pi / 180) / (float)cam->pixelCount[1];
+	const float screenSize = tanf(cam->FOV / 2.0f / (180.0f / pi));
+	const float cx = cam->position[0] + cam->focalDistance * dx, cy = cam->position[1] + cam->focalDistance * dy,
+				cz = cam->position[2] + cam->focalDistance * dz;
+	const float hx = ((screenSize * rx) * cam->focalDistance) * cam->aspectRatio,
+				hy = ((screenSize * ry) * cam->focalDistance) * cam->aspectRatio,
+				hz = ((screenSize * rz) * cam->focalDistance) * cam->aspectRatio;
+	const float sv = screenSize * cam->focalDistance;
+	const float vx = sv * ux, vy = sv * uy, vz = sv * uz;
+	view->pos[0] = cam->position[0], view->pos[1] = cam->position[1], view->pos[2] = cam->position[2];
+	view->p1[0] = (cx - hx) + vx, view->p1[1] = (cy - hy) + vy, view->p1[2] = (cz - hz) + vz;
+	view->p2[0] = (cx + hx) + vx, view->p2[1] = (cy + hy) + vy, view->p2[2] = (cz + hz) + vz;
+	view->p3[0] = (cx - hx) - vx, view->p3[1] = (cy - hy) - vy, view->p3[2] = (cz - hz) - vz;
+	view->aperture = cam->aperture;
+}
+
+// =================================================================================================================
+// render
+// =================================================================================================================
+static int ensure_wave_buffers(rfwhip_context *c, size_t paths)
+{
+	if (paths <= c->wave_capacity)
+		return 0;
+	RF_TRY(dm::sync(c->stream));
+	const size_t b16 = paths * sizeof(f4);
+	for (int k = 0; k < 2; k++)
+	{
+		RF_TRY(c->d_org[k].ensure(b16));
+		RF_TRY(c->d_dir2[k].ensure(b16));
+		RF_TRY(c->d_thr[k].ensure(b16));
+	}
+	RF_TRY(c->d_hit.ensure(b16));
+	RF_TRY(c->d_hit_inst.ensure(paths * 4));
+	RF_TRY(c->d_hit0.ensure(b16));
+	RF_TRY(c->d_hit0_inst.ensure(paths * 4));
+	RF_TRY(c->d_sh_org.ensure(b16));
+	RF_TRY(c->d_sh_dir.ensure(b16));
+	RF_TRY(c->d_sh_rad.ensure(b16));
+	RF_TRY(c->d_rad.ensure(b16));
+	c->wave_capacity = paths;
+	return 0;
+}
+
+static dm::event_t *next_event(rfwhip_context *c)
+{
+	if (c->events_used == c->event_pool.size())
+	{
+		dm::event_t e;
+		dm::event_create(&e);
+		c->event_pool.push_back(e);
+	}
+	return &c->event_pool[c->events_used++];
+}
+
+struct StageTimer
+{
+	rfwhip_context *c;
+	size_t ia = 0, ib = 0;
+	bool on;
+	StageTimer(rfwhip_context *ctx, int family, int depth) : c(ctx), on(ctx->stage_timing != 0)
+	{
+		if (!on)
+			return;
+		next_event(c), ia = c->events_used - 1;
+		next_event(c), ib = c->events_used - 1;
+		dm::event_record(c->event_pool[ia], c->stream);
+		fam = family, dep = depth;
+	}
+	int fam = 0, dep = 0;
+	void stop(int launches = 1)
+	{
+		if (!on)
+			return;
+		dm::event_record(c->event_pool[ib], c->stream);
+		TimedSpan s;
+		s.a = c->event_pool[ia], s.b = c->event_pool[ib], s.family = fam, s.depth = dep;
+		c->spans.push_back(s);
+		c->kernel_launches[fam] += (uint32_t)launches;
+	}
+};
+
+static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params &p)
+{
+	memset(&p, 0, sizeof(p));
+	p.sc = c->sv;
+	rt::WaveView &wv = p.wv;
+	for (int k = 0; k < 2; k++)
+		wv.org[k] = c->d_org[k].as<f4>(), wv.dir[k] = c->d_dir2[k].as<f4>(), wv.thr[k] = c->d_thr[k].as<f4>();
+	wv.hit = c->d_hit.as<f4>(), wv.hit_inst = c->d_hit_inst.as<int>();
+	wv.hit0 = c->d_hit0.as<f4>(), wv.hit0_inst = c->d_hit0_inst.as<int>();
+	wv.sh_org = c->d_sh_org.as<f4>(), wv.sh_dir = c->d_sh_dir.as<f4>(), wv.sh_rad = c->d_sh_rad.as<f4>();
+	wv.rad = c->d_rad.as<f4>(), wv.acc = c->d_acc.as<f4>();
+	wv.packet_rng = c->d_packet_rng.as<uint32_t>();
+	wv.counters = c->d_counters.as<rt::WaveCounters>();
+	if (cam)
+	{
+		rfwhip_camera_view v;
+		rfwhip_camera_get_view(cam, &v);
+		p.cam.pos = rt::f3{v.pos[0], v.pos[1], v.pos[2]};
+		p.cam.p1 = rt::f3{v.p1[0], v.p1[1], v.p1[2]};
+		p.cam.right = rt::f3{v.p2[0] - v.p1[0], v.p2[1] - v.p1[1], v.p2[2] - v.p1[2]};
+		p.cam.up = rt::f3{v.p3[0] - v.p1[0], v.p3[1] - v.p1[1], v.p3[2] - v.p1[2]};
+		p.cam.aperture = v.aperture, p.cam.spread_angle = v.spreadAngle, p.cam.clamp_value = cam->clampValue;
+	}
+	p.fr = c->fr;
+	p.fr.spp = (uint32_t)c->spp;
+	p.fr.sample_base = c->samples_done;
+	p.fr.probe_pixel = c->probe_y * c->W + c->probe_x;
+	p.max_depth = (uint32_t)c->max_depth;
+	p.parity_no_jitter = c->jitter == 1;
+	p.lds_pairs = (uint32_t)c->lds_nodes;
+}
+
+extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int status)
+{
+	CTX_ENTER(c);
+	if (!cam)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_render: null camera");
+	if (!c->W || !c->H)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_render before rfwhip_init");
+	if (c->scene_dirty)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_render: scene changed since the last rfwhip_update()");
+	if (c->max_depth + 2 > rt::MAX_DEPTH_SLOTS)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "max_depth %d too large", c->max_depth);
+	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
+	if (paths >= (1ull << 31))
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "spp batch too large: %zu path slots (limit 2^31)", paths);
+	RF_TRY(ensure_wave_buffers(c, paths));
+	if (!c->render_pending)
+	{
+		c->render_t0 = std::chrono::steady_clock::now();
+		c->render_pending = true;
+	}
+	void *s = c->stream;
+	if (status == RFWHIP_RESET)
+	{
+		RF_TRY(dm::zero(c->d_acc.p, (size_t)c->fr.local_rows * c->W * sizeof(f4), s));
+		c->samples_done = 0;
+	}
+	rtk::Params p;
+	fill_params(c, cam, p);
+	const bool count = c->count_traversal != 0;
+	const uint32_t n = (uint32_t)paths;
+	rtk::launch_init_counters(p.wv.counters, n, s);
+	if (c->integrator == 0)
+	{
+		if (c->jitter == 0)
+		{
+			// per-packet xor128 states for the whole batch (global packet order => image independent of world)
+			const uint32_t packets = (c->W / 4u) * (c->H / 2u);
+			StageTimer tg(c, KF_GENERATE, -1);
+			if (!c->jump_table_uploaded)
+			{
+				RF_TRY(c->d_jump_table.ensure(c->jump_table.size() * 4));
+				RF_TRY(dm::h2d(c->d_jump_table.p, c->jump_table.data(), c->jump_table.size() * 4, s));
+				c->jump_table_uploaded = true;
+			}
+			RF_TRY(c->d_packet_rng.ensure((size_t)std::max(1u, packets) * c->spp * 16));
+			p.wv.packet_rng = c->d_packet_rng.as<uint32_t>();
+			if (packets)
+				rtk::launch_rng_states(c->d_packet_rng.as<uint32_t>(), c->rng_state, c->d_jump_table.as<uint32_t>(), packets,
+									   (uint32_t)c->spp, s);
+			tg.stop();
+			xor128_jump(c->jump_table, c->rng_state, (unsigned long long)packets * 32ull * (unsigned long long)c->spp);
+		}
+		p.depth = 0;
+		StageTimer te(c, KF_EXTEND, 0);
+		rtk::launch_extend(p, rtk::GEN_PARITY, count, n, s);
+		te.stop();
+		StageTimer ts(c, KF_SHADE, -1);
+		rtk::launch_shade_parity(p, count, n, s);
+		ts.stop();
+	}
+	else
+	{
+		for (int d = 0; d <= c->max_depth; d++)
+		{
+			p.depth = (uint32_t)d;
+			StageTimer te(c, KF_EXTEND, d);
+			rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+			te.stop();
+			StageTimer ts(c, KF_SHADE, -1);
+			rtk::launch_shade_pt(p, n, s);
+			ts.stop();
+			if (total_light_count(c))
+			{
+				StageTimer tc(c, KF_CONNECT, -1);
+				rtk::launch_connect(p, count, n, s);
+				tc.stop();
+			}
+		}
+	}
+	{
+		StageTimer tf(c, KF_FINALIZE, -1);
+		rtk::launch_resolve(p, s);
+		tf.stop();
+	}
+	RF_TRY(dm::last_launch_error());
+	c->samples_done += (uint32_t)c->spp;
+	c->totals.samples += (uint64_t)c->W * c->H * (uint64_t)c->spp / (uint64_t)c->world;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_wait(rfwhip_context *c)
+{
+	CTX_ENTER(c);
+	RF_TRY(dm::sync(c->stream));
+	// wave counters of the last frame
+	rt::WaveCounters wc;
+	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	if (wc.probe_valid)
+		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
+	rfwhip_render_stats &st = c->stats;
+	const float anim = st.animationTime;
+	memset(&st, 0, sizeof(st));
+	st.animationTime = anim;
+	st.primaryCount = wc.ext[0];
+	st.secondaryCount = wc.ext[1];
+	for (int d = 2; d < rt::MAX_DEPTH_SLOTS; d++)
+		st.deepCount += wc.ext[d];
+	for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+		st.shadowCount += wc.shadow[d];
+	for (const TimedSpan &sp : c->spans)
+	{
+		const float ms = dm::event_ms(sp.a, sp.b);
+		c->kernel_ms[sp.family] += ms;
+		switch (sp.family)
+		{
+		case KF_EXTEND:
+			if (sp.depth == 0)
+				st.primaryTime += ms;
+			else if (sp.depth == 1)
+				st.secondaryTime += ms;
+			else
+				st.deepTime += ms;
+			break;
+		case KF_GENERATE:
+			st.primaryTime += ms;
+			break;
+		case KF_SHADE:
+			st.shadeTime += ms;
+			break;
+		case KF_CONNECT:
+			st.shadowTime += ms;
+			break;
+		case KF_FINALIZE:
+			st.finalizeTime += ms;
+			break;
+		default:
+			break;
+		}
+	}
+	c->spans.clear();
+	c->events_used = 0;
+	if (c->render_pending)
+	{
+		st.renderTime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->render_t0).count();
+		c->render_pending = false;
+	}
+	return RFWHIP_OK;
+}
+
+// =================================================================================================================
+// present
+// =================================================================================================================
+extern "C" uint32_t rfwhip_local_rows(const rfwhip_context *c) { return c ? local_rows_of(c) : 0u; }
+
+static int present(rfwhip_context *c, f4 *dst_device, int full)
+{
+	rtk::Params p;
+	fill_params(c, nullptr, p);
+	const float scale = c->samples_done ? 1.0f / (float)c->samples_done : 0.0f;
+	rtk::launch_present(p, dst_device, scale, full, c->stream);
+	RF_TRY(dm::last_launch_error());
+	return 0;
+}
+
+extern "C" int rfwhip_read_framebuffer_device(rfwhip_context *c, void *rgba_device)
+{
+	CTX_ENTER(c);
+	if (!rgba_device)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null destination");
+	if (c->world != 1)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_read_framebuffer*: this rank owns 1/%d of the image; gather local "
+											"framebuffers and call rfwhip_deinterleave_device", c->world);
+	if (!c->W)
+		return set_error(RFWHIP_ERR_STATE, "no render target");
+	RF_TRY(present(c, (f4 *)rgba_device, 1));
+	return dm::sync(c->stream);
+}
+
+extern "C" int rfwhip_read_framebuffer(rfwhip_context *c, float *rgba_host)
+{
+	CTX_ENTER(c);
+	if (!rgba_host)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null destination");
+	const size_t bytes = (size_t)c->W * c->H * sizeof(f4);
+	RF_TRY(c->d_present.ensure(bytes));
+	RF_TRY(dm::zero(c->d_present.p, bytes, c->stream));
+	RF_TRY(rfwhip_read_framebuffer_device(c, c->d_present.p));
+	return dm::d2h(rgba_host, c->d_present.p, bytes, c->stream);
+}
+
+extern "C" int rfwhip_read_local_framebuffer_device(rfwhip_context *c, void *rgba_device)
+{
+	CTX_ENTER(c);
+	if (!rgba_device)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null destination");
+	if (!c->W)
+		return set_error(RFWHIP_ERR_STATE, "no render target");
+	RF_TRY(present(c, (f4 *)rgba_device, 0));
+	return dm::sync(c->stream);
+}
+
+extern "C" int rfwhip_deinterleave_device(rfwhip_context *c, const void *gathered_device, void *rgba_device)
+{
+	CTX_ENTER(c);
+	if (!gathered_device || !rgba_device)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null buffer");
+	rtk::launch_deinterleave((const f4 *)gathered_device, (f4 *)rgba_device, c->W, c->H, local_rows_of(c), (uint32_t)c->world, c->stream);
+	RF_TRY(dm::last_launch_error());
+	return dm::sync(c->stream);
+}
+
+// =================================================================================================================
+// probe / stats / settings / hooks
+// =================================================================================================================
+extern "C" int rfwhip_set_probe_index(rfwhip_context *c, uint32_t x, uint32_t y)
+{
+	CTX_ENTER(c);
+	c->probe_x = x, c->probe_y = y;
+	return RFWHIP_OK;
+}
+extern "C" int rfwhip_get_probe_results(rfwhip_context *c, uint32_t *inst, uint32_t *prim, float *dist)
+{
+	CTX_ENTER(c);
+	if (inst)
+		*inst = c->probe_inst;
+	if (prim)
+		*prim = c->probe_prim;
+	if (dist)
+		*dist = c->probe_dist;
+	return RFWHIP_OK;
+}
+extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
+{
+	CTX_ENTER(c);
+	if (!stats)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null stats");
+	*stats = c->stats;
+	return RFWHIP_OK;
+}
+
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes"};
+
+extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
+{
+	CTX_ENTER(c);
+	if (!key || !value)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null key/value");
+	const std::string k(key), v(value);
+	if (k == "integrator")
+	{
+		if (v == "parity")
+			c->integrator = 0;
+		else if (v == "pt")
+			c->integrator = 1;
+		else
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "integrator must be \"parity\" or \"pt\", got \"%s\"", value);
+	}
+	else if (k == "spp")
+	{
+		const int n = atoi(value);
+		if (n < 1 || n > 4096)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "spp must be in [1, 4096]");
+		c->spp = n;
+	}
+	else if (k == "max_depth")
+	{
+		const int n = atoi(value);
+		if (n < 0 || n + 2 > rt::MAX_DEPTH_SLOTS)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "max_depth must be in [0, %d]", rt::MAX_DEPTH_SLOTS - 2);
+		c->max_depth = n;
+	}
+	else if (k == "jitter")
+	{
+		if (v == "xor128")
+			c->jitter = 0;
+		else if (v == "center")
+			c->jitter = 1;
+		else
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "jitter must be \"xor128\" or \"center\"");
+	}
+	else if (k == "stage_timing")
+		c->stage_timing = atoi(value) != 0;
+	else if (k == "count_traversal")
+		c->count_traversal = atoi(value) != 0;
+	else if (k == "lds_nodes")
+		c->lds_nodes = std::max(0, atoi(value));
+	else
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *value, size_t cap)
+{
+	CTX_ENTER(c);
+	if (!key || !value || !cap)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null key/value");
+	const std::string k(key);
+	if (k == "integrator")
+		snprintf(value, cap, "%s", c->integrator ? "pt" : "parity");
+	else if (k == "spp")
+		snprintf(value, cap, "%d", c->spp);
+	else if (k == "max_depth")
+		snprintf(value, cap, "%d", c->max_depth);
+	else if (k == "jitter")
+		snprintf(value, cap, "%s", c->jitter ? "center" : "xor128");
+	else if (k == "stage_timing")
+		snprintf(value, cap, "%d", c->stage_timing);
+	else if (k == "count_traversal")
+		snprintf(value, cap, "%d", c->count_traversal);
+	else if (k == "lds_nodes")
+		snprintf(value, cap, "%d", c->lds_nodes);
+	else
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_get_settings(rfwhip_context *c, const char **keys, size_t cap)
+{
+	(void)c;
+	const size_t n = sizeof(k_setting_keys) / sizeof(k_setting_keys[0]);
+	for (size_t i = 0; i < n && i < cap && keys; i++)
+		keys[i] = k_setting_keys[i];
+	return (int)n;
+}
+
+extern "C" int rfwhip_get_counters(rfwhip_context *c, rfwhip_counters *out, int reset)
+{
+	CTX_ENTER(c);
+	if (!out)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null counters");
+	RF_TRY(dm::sync(c->stream));
+	rt::WaveCounters wc;
+	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	out->rays_extend = wc.rays_extend, out->rays_shadow = wc.rays_shadow;
+	out->inner_extend = wc.inner_extend, out->tris_extend = wc.tris_extend;
+	out->inner_shadow = wc.inner_shadow, out->tris_shadow = wc.tris_shadow;
+	out->shaded = wc.shaded, out->samples = c->totals.samples;
+	if (reset)
+	{
+		wc.rays_extend = wc.rays_shadow = wc.inner_extend = wc.tris_extend = wc.inner_shadow = wc.tris_shadow = wc.shaded = 0;
+		RF_TRY(dm::h2d(c->d_counters.p, &wc, sizeof(wc), c->stream));
+		RF_TRY(dm::sync(c->stream));
+		c->totals.samples = 0;
+	}
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_get_kernel_time(rfwhip_context *c, int which, float *ms, uint32_t *launches, int reset)
+{
+	CTX_ENTER(c);
+	if (which < 0 || which >= KF_COUNT)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "kernel family %d out of range", which);
+	if (ms)
+		*ms = c->kernel_ms[which];
+	if (launches)
+		*launches = c->kernel_launches[which];
+	if (reset)
+		c->kernel_ms[which] = 0.0f, c->kernel_launches[which] = 0;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *prim, int32_t *inst, float *u, float *v)
+{
+	CTX_ENTER(c);
+	if (!c->W || c->wave_capacity == 0)
+		return set_error(RFWHIP_ERR_STATE, "no frame rendered yet");
+	RF_TRY(dm::sync(c->stream));
+	const size_t slots = c->fr.slots;
+	std::vector<f4> h(slots);
+	std::vector<int> hi(slots);
+	RF_TRY(dm::d2h(h.data(), c->d_hit0.p, slots * sizeof(f4), c->stream));
+	RF_TRY(dm::d2h(hi.data(), c->d_hit0_inst.p, slots * 4, c->stream));
+	const size_t n = (size_t)c->W * c->H;
+	for (size_t i = 0; i < n; i++)
+	{
+		if (t)
+			t[i] = 1e34f;
+		if (prim)
+			prim[i] = -1;
+		if (inst)
+			inst[i] = -1;
+		if (u)
+			u[i] = 0;
+		if (v)
+			v[i] = 0;
+	}
+	const bool parity = c->integrator == 0;
+	for (uint32_t yl = 0; yl < c->fr.local_rows; yl++)
+	{
+		const uint32_t y = ((yl / rt::STRIP_ROWS) * c->world + c->rank) * rt::STRIP_ROWS + yl % rt::STRIP_ROWS;
+		if (y >= c->H)
+			continue;
+		for (uint32_t x = 0; x < c->W; x++)
+		{
+			if (parity && (x >= (c->W / 4u) * 4u || y >= (c->H / 2u) * 2u))
+				continue;
+			const uint32_t tile = (yl / rt::TILE) * c->fr.tiles_x + x / rt::TILE;
+			const uint32_t slot = tile * 64u + (yl % rt::TILE) * rt::TILE + (x % rt::TILE);
+			const size_t o = (size_t)y * c->W + x;
+			int pr;
+			memcpy(&pr, &h[slot].w, 4);
+			if (t)
+				t[o] = h[slot].x;
+			if (u)
+				u[o] = h[slot].y;
+			if (v)
+				v[o] = h[slot].z;
+			if (prim)
+				prim[o] = pr;
+			if (inst)
+				inst[o] = pr >= 0 ? hi[slot] : -1;
+		}
+	}
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,
+							  uint32_t *prim_indices, size_t prim_cap, size_t *node_count, size_t *prim_count)
+{
+	CTX_ENTER(c);
+	if (mesh_index >= c->meshes.size() || !c->meshes[mesh_index].used)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_get_bvh: no mesh %zu", mesh_index);
+	MeshRec &m = c->meshes[mesh_index];
+	if (node_count)
+		*node_count = m.bvh.nodes.size();
+	if (prim_count)
+		*prim_count = m.bvh.order.size();
+	if (nodes && node_cap)
+	{
+		const size_t n = std::min(node_cap, m.bvh.nodes.size());
+		if (m.resident)
+		{
+			RF_TRY(dm::sync(c->stream));
+			RF_TRY(dm::d2h(nodes, c->d_nodes.as<rt::Node>() + m.node_base, n * sizeof(rt::Node), c->stream));
+		}
+		else
+			memcpy(nodes, m.bvh.nodes.data(), n * sizeof(rt::Node));
+	}
+	if (prim_indices && prim_cap)
+		memcpy(prim_indices, m.bvh.order.data(), std::min(prim_cap, m.bvh.order.size()) * 4);
+	return RFWHIP_OK;
+}

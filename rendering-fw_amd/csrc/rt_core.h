@@ -1,0 +1,1235 @@
+// rt_core.h — the per-ray / per-path arithmetic of the HIP rendercore: primary-ray generation, two-level BVH2
+// traversal with Möller–Trumbore, the parity integrator's shade loop and the wavefront path tracer's shade step
+// (next-event estimation + Disney BSDF).  Pure functions over SceneView/WaveView pointers; the kernels in
+// kernels.hip add the thread mapping, the LDS traversal stack and the wave-level compaction around them.
+//
+// Behavioural spec (reference file:line under /root/reference):
+//   primary rays (parity)     RFW/backends/EmbreeRT/src/Ray.cpp:16-47, :176-384
+//   primary rays (pt)         RFW/backends/CUDART/src/Kernels.cu:383-426
+//   slab test                 RFW/system/bvh/src/aabb.cpp:39-77
+//   BVH2 traversal            RFW/system/bvh/include/bvh/bvh_node.h:317-448, CUDART/src/CUDAIntersect.h:199-268
+//   Möller–Trumbore           RFW/system/bvh/src/bvh_tree.cpp:166-196, CUDAIntersect.h:48-94
+//   instancing                RFW/system/bvh/src/top_level_bvh.cpp:104-191, Kernels.cu:267-301
+//   parity shade              RFW/backends/EmbreeRT/src/Context.cpp:179-282, :417-476
+//   pt shade                  RFW/backends/CUDART/src/Kernels.cu:571-794, lights.h, getShadingData.h
+//   BSDF                      RFW/system/context/rfw/bsdf/disney.h, tools.h, compat.h:47-74
+#pragma once
+#include "rt_types.h"
+#include <math.h>
+
+namespace rt
+{
+
+// ---------------------------------------------------------------------------------------------------------------
+// small vector algebra
+// ---------------------------------------------------------------------------------------------------------------
+RT_FN f3 mk3(float x, float y, float z)
+{
+	f3 r;
+	r.x = x, r.y = y, r.z = z;
+	return r;
+}
+RT_FN f4 mk4(float x, float y, float z, float w)
+{
+	f4 r;
+	r.x = x, r.y = y, r.z = z, r.w = w;
+	return r;
+}
+RT_FN f3 xyz(const f4 &a) { return mk3(a.x, a.y, a.z); }
+RT_FN f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+RT_FN f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_FN f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_FN f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_FN f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_FN float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_FN f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+RT_FN float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_FN f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+RT_FN f3 lerp3(f3 a, f3 b, float t) { return a + (b - a) * t; }
+RT_FN float lerp1(float a, float b, float t) { return a + t * (b - a); }
+RT_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+RT_FN bool any_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
+RT_FN float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+RT_FN uint32_t f2u_sat(float f)
+{
+	if (!(f > 0.0f))
+		return 0u;
+	if (f >= 4294967296.0f)
+		return 0xFFFFFFFFu;
+	return (uint32_t)f;
+}
+RT_FN uint32_t fbits(float f)
+{
+	union
+	{
+		float f;
+		uint32_t u;
+	} c;
+	c.f = f;
+	return c.u;
+}
+RT_FN float ubits(uint32_t u)
+{
+	union
+	{
+		float f;
+		uint32_t u;
+	} c;
+	c.u = u;
+	return c.f;
+}
+
+RT_FN float half_to_float(uint16_t h)
+{
+	const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+	const uint32_t exp = (h >> 10) & 0x1Fu;
+	uint32_t man = h & 0x3FFu;
+	uint32_t bits;
+	if (exp == 0)
+	{
+		if (man == 0)
+			bits = sign;
+		else
+		{
+			int e = -1;
+			do
+			{
+				man <<= 1;
+				e++;
+			} while (!(man & 0x400u));
+			bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+		}
+	}
+	else if (exp == 31)
+		bits = sign | 0x7F800000u | (man << 13);
+	else
+		bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+	return ubits(bits);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RNGs: utils/xor128.h:20-27, utils/rng.h:14, bsdf/tools.h:218-235
+// ---------------------------------------------------------------------------------------------------------------
+RT_FN uint32_t xor128_next(uint32_t s[4])
+{
+	const uint32_t t = s[0] ^ (s[0] << 11);
+	s[0] = s[1];
+	s[1] = s[2];
+	s[2] = s[3];
+	s[3] = s[3] ^ (s[3] >> 19) ^ (t ^ (t >> 8));
+	return s[3];
+}
+RT_FN float u32_to_unit(uint32_t v) { return (float)v * 2.3283064365387e-10f; }
+RT_FN uint32_t wang_hash(uint32_t s)
+{
+	s = (s ^ 61u) ^ (s >> 16);
+	s *= 9u;
+	s = s ^ (s >> 4);
+	s *= 0x27d4eb2du;
+	s = s ^ (s >> 15);
+	return s;
+}
+RT_FN float random_float(uint32_t &s)
+{
+	s ^= s << 13;
+	s ^= s >> 17;
+	s ^= s << 5;
+	return (float)s * 2.3283064365387e-10f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pixel <-> path-slot mapping.  Within one sample, slots run over 8x8 tiles (one tile per wave), tiles row-major
+// over the rank's compacted local image; samples of a batch are stacked: slot = s * frame.slots + tile*64 + lane.
+// ---------------------------------------------------------------------------------------------------------------
+struct PixelRef
+{
+	uint32_t x, y;		// global pixel
+	uint32_t local;		// local row-major index (ylocal * W + x)
+	uint32_t sample;	// sample index within the batch
+	bool valid;
+};
+RT_FN uint32_t local_to_global_row(const FrameView &fr, uint32_t yl)
+{
+	return ((yl / STRIP_ROWS) * fr.world + fr.rank) * STRIP_ROWS + (yl % STRIP_ROWS);
+}
+RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
+{
+	PixelRef p;
+	p.sample = slot / fr.slots;
+	const uint32_t lp = slot - p.sample * fr.slots;
+	const uint32_t tile = lp >> 6, lane = lp & 63u;
+	const uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+	p.x = tx * TILE + (lane & 7u);
+	const uint32_t yl = ty * TILE + (lane >> 3);
+	p.y = local_to_global_row(fr, yl);
+	p.local = yl * fr.W + p.x;
+	p.valid = p.x < fr.W && p.y < fr.H;
+	return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// primary rays
+// ---------------------------------------------------------------------------------------------------------------
+// EmbreeRT: u = (x + r0)/W, v = (y + r1)/H, point = p1 + (u*right + v*up), dir = (point - org) * (1/sqrt(len2)) with
+// len2 accumulated x, y, z (Ray.cpp:318-373).  The lens sample follows the scalar form Ray.cpp:16-47.
+RT_FN void parity_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float r0, float r1,
+							  float r2, float r3, f3 &O, f3 &D)
+{
+	f3 org = cam.pos;
+	if (cam.aperture != 0.0f)
+	{
+		const float blade = (float)(int)(r0 * 9);
+		r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+		const float piOver4point5 = 3.14159265359f / 4.5f;
+		const float x1 = cosf(blade * piOver4point5), y1 = sinf(blade * piOver4point5);
+		const float x2 = cosf((blade + 1.0f) * piOver4point5), y2 = sinf((blade + 1.0f) * piOver4point5);
+		if ((r2 + r3) > 1.0f)
+			r2 = 1.0f - r2, r3 = 1.0f - r3;
+		const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
+		org = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
+	}
+	const float u = ((float)x + r0) * (1.0f / (float)W);
+	const float v = ((float)y + r1) * (1.0f / (float)H);
+	const f3 pix = cam.p1 + (cam.right * u + cam.up * v);
+	const f3 d = pix - org;
+	float l2 = d.x * d.x;
+	l2 = d.y * d.y + l2;
+	l2 = d.z * d.z + l2;
+	const float inv = 1.0f / sqrtf(l2);
+	O = org;
+	D = d * inv;
+}
+
+// CUDART generatePrimaryRay with its hash-RNG branch: seed = WangHash(pixel*16789 + sample*1791), four RandomFloat.
+RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sampleIdx,
+						  f3 &O, f3 &D)
+{
+	const uint32_t pixel = y * W + x;
+	uint32_t seed = wang_hash(pixel * 16789u + sampleIdx * 1791u);
+	const float r0 = random_float(seed), r1 = random_float(seed);
+	float r2 = random_float(seed), r3 = random_float(seed);
+	const float blade = (float)(int)(r0 * 9);
+	r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+	const float piOver4point5 = 3.14159265359f / 4.5f;
+	// __sincosf(a, &x1, &y1): x1 = sin, y1 = cos (Kernels.cu:407-408)
+	const float x1 = sinf(blade * piOver4point5), y1 = cosf(blade * piOver4point5);
+	const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
+	if ((r2 + r3) > 1.0f)
+		r2 = 1.0f - r2, r3 = 1.0f - r3;
+	const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
+	O = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
+	const float u = ((float)x + r0) * (1.0f / (float)W), v = ((float)y + r1) * (1.0f / (float)H);
+	D = normalize(((cam.p1 + cam.right * u) + cam.up * v) - O);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------------------------------------------
+struct Hit
+{
+	float t, u, v;
+	int prim, inst;
+};
+struct TStat
+{
+	uint32_t inner, tris;
+};
+
+constexpr int LDS_STACK = 24;	// entries per lane kept in LDS
+constexpr int SPILL_STACK = 40; // further entries in private memory (touched only by pathological rays)
+
+struct TravStack
+{
+	uint32_t *lds; // lane's column of the workgroup's LDS stack
+	int stride;	   // distance between consecutive entries of one lane (= workgroup size)
+	uint32_t spill[SPILL_STACK];
+};
+RT_FN void stack_push(TravStack &s, int &sp, uint32_t e)
+{
+	if (sp < LDS_STACK)
+		s.lds[sp * s.stride] = e;
+	else if (sp < LDS_STACK + SPILL_STACK)
+		s.spill[sp - LDS_STACK] = e;
+	sp++;
+}
+RT_FN uint32_t stack_pop(TravStack &s, int &sp)
+{
+	sp--;
+	if (sp < LDS_STACK)
+		return s.lds[sp * s.stride];
+	if (sp < LDS_STACK + SPILL_STACK)
+		return s.spill[sp - LDS_STACK];
+	return ENTRY_SENTINEL; // unreachable: the builders bound the depth (bvh_build.cpp)
+}
+
+RT_FN bool slab(const f4 &a, const f4 &b, f3 o, f3 id, float t, float &tnear)
+{
+	// a = bmin.xyz, bmax.x ; b = bmax.y, bmax.z, left_first, count          (aabb.cpp:39-77)
+	const float tx1 = (a.x - o.x) * id.x, tx2 = (a.w - o.x) * id.x;
+	const float ty1 = (a.y - o.y) * id.y, ty2 = (b.x - o.y) * id.y;
+	const float tz1 = (a.z - o.z) * id.z, tz2 = (b.y - o.z) * id.z;
+	const float tmin = fmaxf(fminf(tx1, tx2), fmaxf(fminf(ty1, ty2), fminf(tz1, tz2)));
+	const float tmax = fminf(fmaxf(tx1, tx2), fminf(fmaxf(ty1, ty2), fmaxf(tz1, tz2)));
+	tnear = tmin;
+	// the reference accepts tmax > tmin && tmin < t; boxes entirely behind the origin (tmax < 0) cannot contain an
+	// accepted hit (t > t_min >= 0) and are culled here as well
+	return tmax > tmin && tmin < t && tmax >= 0.0f;
+}
+
+// Möller–Trumbore with the reference's rejections: |a| < 1e-6, u outside [0,1], v < 0, u+v > 1, t <= t_min, t >= t.
+RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo)
+{
+	const f3 e1 = p1 - p0, e2 = p2 - p0;
+	const f3 h = cross(d, e2);
+	const float a = dot(e1, h);
+	if (a > -1e-6f && a < 1e-6f)
+		return false;
+	const float f = 1.f / a;
+	const f3 s = o - p0;
+	const float u = f * dot(s, h);
+	if (u < 0.0f || u > 1.0f)
+		return false;
+	const f3 q = cross(s, e1);
+	const float v = f * dot(d, q);
+	if (v < 0.0f || u + v > 1.0f)
+		return false;
+	const float tt = f * dot(e2, q);
+	if (tt > t_min && t > tt)
+	{
+		t = tt, uo = u, vo = v;
+		return true;
+	}
+	return false;
+}
+
+// Two-level traversal in one loop.  Stack entries: inner node = index of its left child (children are adjacent),
+// leaf = first/count packed, ENTRY_TLAS marks top-level entries, ENTRY_SENTINEL marks "leave the instance".
+// ANY = true: occlusion query, returns on the first accepted hit in (t_min, t_max).
+template <bool ANY, bool COUNT>
+RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit &hit, TravStack &stk, TStat &st)
+{
+	hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
+	if (sc.instance_count == 0)
+		return false;
+	f3 o = O, d = D;
+	f3 id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+	const Node *nodes = sc.tlas_nodes;
+	uint32_t tri_base = 0;
+	int cur_inst = -1;
+	int sp = 0;
+	uint32_t cur = sc.tlas_root_entry;
+	for (;;)
+	{
+		bool need_pop = true;
+		if (!(cur & ENTRY_LEAF))
+		{
+			const f4 *p = (const f4 *)(nodes + (cur & ENTRY_INDEX_MASK));
+			const f4 a0 = p[0], b0 = p[1], a1 = p[2], b1 = p[3];
+			if (COUNT)
+				st.inner++;
+			float n0, n1;
+			const bool h0 = slab(a0, b0, o, id, hit.t, n0);
+			const bool h1 = slab(a1, b1, o, id, hit.t, n1);
+			const uint32_t tl = cur & ENTRY_TLAS;
+			const uint32_t e0 = make_entry((int)fbits(b0.z), (int)fbits(b0.w), tl != 0);
+			const uint32_t e1 = make_entry((int)fbits(b1.z), (int)fbits(b1.w), tl != 0);
+			if (h0 && h1)
+			{
+				const bool first0 = n0 < n1;
+				stack_push(stk, sp, first0 ? e1 : e0);
+				cur = first0 ? e0 : e1;
+				need_pop = false;
+			}
+			else if (h0 || h1)
+			{
+				cur = h0 ? e0 : e1;
+				need_pop = false;
+			}
+		}
+		else if (cur & ENTRY_TLAS)
+		{
+			// top-level leaf: exactly one instance (the TLAS builder never merges)
+			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
+			const Instance &in = sc.instances[ii];
+			stack_push(stk, sp, ENTRY_SENTINEL);
+			o = mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
+					in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
+					in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]);
+			d = mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z, in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
+					in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z);
+			id = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+			nodes = sc.nodes + in.node_base;
+			tri_base = in.tri_base;
+			cur_inst = (int)ii;
+			cur = in.root_entry;
+			need_pop = false;
+		}
+		else
+		{
+			const uint32_t first = tri_base + (cur & ENTRY_FIRST_MASK);
+			const uint32_t count = ((cur >> 27) & 7u) + 1u;
+			for (uint32_t i = 0; i < count; i++)
+			{
+				const f4 *tv = sc.tri_verts + 3u * (first + i);
+				const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+				if (COUNT)
+					st.tris++;
+				if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
+				{
+					hit.prim = (int)fbits(v0.w);
+					hit.inst = cur_inst;
+					if (ANY)
+						return true;
+				}
+			}
+		}
+		while (need_pop)
+		{
+			if (sp == 0)
+				return hit.prim >= 0;
+			cur = stack_pop(stk, sp);
+			if (cur == ENTRY_SENTINEL)
+			{
+				o = O, d = D;
+				id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+				nodes = sc.tlas_nodes;
+				cur_inst = -1;
+			}
+			else
+				need_pop = false;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// materials / textures
+// ---------------------------------------------------------------------------------------------------------------
+RT_FN f3 material_color(const MaterialRec &m)
+{
+	return mk3(half_to_float(m.diffuse[0]), half_to_float(m.diffuse[1]), half_to_float(m.diffuse[2]));
+}
+RT_FN bool mat_flag(uint32_t flags, int bit) { return ((flags >> bit) & 1u) != 0; }
+enum
+{
+	MF_DIFFUSE_MAP = 2,
+	MF_SMOOTH_NORMALS = 11
+};
+
+RT_FN f3 mul_normal(const Instance &in, f3 n)
+{
+	return mk3(in.nrm[0] * n.x + in.nrm[4] * n.y + in.nrm[8] * n.z, in.nrm[1] * n.x + in.nrm[5] * n.y + in.nrm[9] * n.z,
+			   in.nrm[2] * n.x + in.nrm[6] * n.y + in.nrm[10] * n.z);
+}
+
+RT_FN f4 decode_rgba8(uint32_t t)
+{
+	const float r = 1.0f / 256.0f;
+	return mk4((float)(t & 255u) * r, (float)((t >> 8) & 255u) * r, (float)((t >> 16) & 255u) * r, (float)(t >> 24) * r);
+}
+RT_FN f4 load_texel(const SceneView &sc, const TexDesc &td, uint32_t i)
+{
+	if (i >= td.texelCount)
+		i = td.texelCount - 1;
+	if (td.type == 1u)
+		return decode_rgba8(sc.tex_u32[td.offset + i]);
+	return sc.tex_f4[td.offset + i];
+}
+// getShadingData.h:25-60 — bilinear, wrap
+RT_FN f4 fetch_texel(const SceneView &sc, const TexDesc &td, float tu, float tv, uint32_t o, int w, int h)
+{
+	const float tcx = (fmaxf(tu + 1000, 0.0f) * w) - 0.5f, tcy = (fmaxf(tv + 1000, 0.0f) * h) - 0.5f;
+	const int iu = (int)tcx % w, iv = (int)tcy % h;
+	const float fu = tcx - floorf(tcx), fv = tcy - floorf(tcy);
+	const float w0 = (1 - fu) * (1 - fv), w1 = fu * (1 - fv), w2 = (1 - fu) * fv, w3 = 1 - (w0 + w1 + w2);
+	const int iu1 = (iu + 1) % w, iv1 = (iv + 1) % h;
+	const f4 p0 = load_texel(sc, td, o + iu + (uint32_t)iv * w), p1 = load_texel(sc, td, o + iu1 + (uint32_t)iv * w);
+	const f4 p2 = load_texel(sc, td, o + iu + (uint32_t)iv1 * w), p3 = load_texel(sc, td, o + iu1 + (uint32_t)iv1 * w);
+	f4 r;
+	r.x = 0.0f + p0.x * w0 + p1.x * w1 + p2.x * w2 + p3.x * w3;
+	r.y = 0.0f + p0.y * w0 + p1.y * w1 + p2.y * w2 + p3.y * w3;
+	r.z = 0.0f + p0.z * w0 + p1.z * w1 + p2.z * w2 + p3.z * w3;
+	r.w = 0.0f + p0.w * w0 + p1.w * w1 + p2.w * w2 + p3.w * w3;
+	return r;
+}
+// getShadingData.h:61-98 — MIPLEVELCOUNT 5; a texture without the appended chain is read at level 0 only
+RT_FN f4 fetch_trilinear(const SceneView &sc, const TexDesc &td, float lambda, float tu, float tv, int width, int height)
+{
+	uint32_t chain = 0;
+	{
+		int w = width, h = height;
+		for (int i = 0; i < 5; i++)
+			chain += (uint32_t)w * h, w >>= 1, h >>= 1;
+	}
+	const bool has_mips = td.texelCount >= chain;
+	int level0 = (int)lambda;
+	if (level0 > 4)
+		level0 = 4;
+	if (level0 < 0 || !has_mips)
+		level0 = 0;
+	int level1 = level0 + 1 > 4 ? 4 : level0 + 1;
+	if (!has_mips)
+		level1 = 0;
+	const float f = lambda - floorf(lambda);
+	uint32_t o0 = 0, o1 = 0;
+	int w0 = width, h0 = height, w1 = width, h1 = height;
+	for (int i = 0; i < level0; i++)
+		o0 += (uint32_t)w0 * h0, w0 >>= 1, h0 >>= 1;
+	for (int i = 0; i < level1; i++)
+		o1 += (uint32_t)w1 * h1, w1 >>= 1, h1 >>= 1;
+	const f4 p0 = fetch_texel(sc, td, tu, tv, o0, w0 > 0 ? w0 : 1, h0 > 0 ? h0 : 1);
+	const f4 p1 = fetch_texel(sc, td, tu, tv, o1, w1 > 0 ? w1 : 1, h1 > 0 ? h1 : 1);
+	return mk4((1.0f - f) * p0.x + f * p1.x, (1.0f - f) * p0.y + f * p1.y, (1.0f - f) * p0.z + f * p1.z,
+			   (1.0f - f) * p0.w + f * p1.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sky
+// ---------------------------------------------------------------------------------------------------------------
+#define RT_INV_PI 0.318309886183790671538f
+// EmbreeRT/src/Context.cpp:187-196: nearest texel at uv * (size - 1)
+RT_FN f3 parity_sky(const SceneView &sc, f3 D)
+{
+	if (!sc.sky_w || !sc.sky_h)
+		return mk3(0, 0, 0);
+	const float ux = 0.5f * (1.0f + atan2f(D.x, -D.z) * RT_INV_PI);
+	const float uy = acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI;
+	uint32_t px = f2u_sat(ux * (float)(sc.sky_w - 1)), py = f2u_sat(uy * (float)(sc.sky_h - 1));
+	if (px >= sc.sky_w)
+		px = sc.sky_w - 1;
+	if (py >= sc.sky_h)
+		py = sc.sky_h - 1;
+	return xyz(sc.sky[py * sc.sky_w + px]);
+}
+// CUDART/src/Kernels.cu:593-600: texel at uv * size, black when out of range
+RT_FN f3 pt_sky(const SceneView &sc, f3 D)
+{
+	if (!sc.sky_w || !sc.sky_h)
+		return mk3(0, 0, 0);
+	const uint32_t u = f2u_sat((float)sc.sky_w * 0.5f * (1.0f + atan2f(D.x, -D.z) * RT_INV_PI));
+	const uint32_t v = f2u_sat((float)sc.sky_h * acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI);
+	const unsigned long long idx = (unsigned long long)u + (unsigned long long)v * sc.sky_w;
+	if (idx < (unsigned long long)sc.sky_w * sc.sky_h)
+		return xyz(sc.sky[idx]);
+	return mk3(0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PARITY INTEGRATOR shade: EmbreeRT/src/Context.cpp:198-281 + retrieve_material :417-476
+// ---------------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+RT_FN f4 parity_shade(const SceneView &sc, f3 O, f3 D, const Hit &h, TravStack &stk, TStat &st, uint32_t &nshadow)
+{
+	const Instance &in = sc.instances[h.inst];
+	const TriShade &ts = sc.tri_shade[in.shade_base + (uint32_t)h.prim];
+	const f3 bary = mk3(1.0f - h.u - h.v, h.u, h.v);
+	const f3 p = O + D * h.t;
+	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, tv4 = ts.tv;
+	const MaterialRec &mat = sc.materials[fbits(tv4.w)];
+	const f3 iNl = (xyz(n0) * bary.x + xyz(n1) * bary.y) + xyz(n2) * bary.z;
+	const f3 iN = normalize(mul_normal(in, iNl));
+	f3 color = material_color(mat);
+	const uint32_t mflags = mat.flags;
+	if (mat_flag(mflags, MF_DIFFUSE_MAP))
+	{
+		const f4 tu4 = ts.tu;
+		const float tu = bary.x * tu4.x + bary.y * tu4.y + bary.z * tu4.z;
+		const float tv = bary.x * tv4.x + bary.y * tv4.y + bary.z * tv4.z;
+		const float uu = (tu + half_to_float(mat.map[0].uoffs)) * half_to_float(mat.map[0].uscale);
+		const float vv = (tv + half_to_float(mat.map[0].voffs)) * half_to_float(mat.map[0].vscale);
+		float tx = fmodf(uu, 1.0f), ty = fmodf(vv, 1.0f);
+		if (tx < 0.f)
+			tx = 1.f + tx;
+		if (ty < 0.f)
+			ty = 1.f + ty;
+		const uint32_t ti = mat.map[0].addr;
+		if (ti < sc.texture_count)
+		{
+			const TexDesc td = sc.textures[ti];
+			const uint32_t ix = f2u_sat(tx * (float)(td.width - 1)), iy = f2u_sat(ty * (float)(td.height - 1));
+			const uint32_t id = iy * td.width + ix;
+			uint32_t tc;
+			if (td.type == 0u)
+			{
+				const f4 px = sc.tex_f4[td.offset + id];
+				color = color * xyz(px);
+				// Context.cpp:458-472: no break — the float4 data is then decoded once more as packed RGBA8
+				const float *raw = (const float *)(sc.tex_f4 + td.offset);
+				tc = fbits(raw[id]);
+			}
+			else
+				tc = sc.tex_u32[td.offset + id];
+			const float s = 1.0f / 256.0f;
+			color = (color * s) * mk3((float)(tc & 0xFFu), (float)((tc >> 8) & 0xFFu), (float)((tc >> 16) & 0xFFu));
+		}
+	}
+	if (color.x > 1.0f || color.y > 1.0f || color.z > 1.0f)
+		return mk4(color.x, color.y, color.z, 1.0f);
+	f3 contrib = mk3(0.1f, 0.1f, 0.1f);
+	Hit sh;
+	for (uint32_t i = 0; i < sc.n_area; i++)
+	{
+		const AreaLight &l = sc.area[i];
+		f3 L = ld3(l.position) - p;
+		const float sq = dot(L, L), dist = sqrtf(sq);
+		L = mk3(L.x / dist, L.y / dist, L.z / dist);
+		const float NdotL = dot(iN, L), LNdotL = -dot(ld3(l.normal), L);
+		if (NdotL <= 0 || LNdotL <= 0)
+			continue;
+		nshadow++;
+		if (!trace<true, COUNT>(sc, p, L, 1e-4f, dist, sh, stk, st))
+		{
+			f3 r = ld3(l.radiance) * l.area;
+			r = mk3(r.x / sq, r.y / sq, r.z / sq);
+			contrib = contrib + (r * NdotL) * LNdotL;
+		}
+	}
+	for (uint32_t i = 0; i < sc.n_point; i++)
+	{
+		const PointLight &l = sc.point[i];
+		f3 L = ld3(l.position) - p;
+		const float sq = dot(L, L), dist = sqrtf(sq);
+		L = mk3(L.x / dist, L.y / dist, L.z / dist);
+		const float NdotL = dot(iN, L);
+		if (NdotL <= 0)
+			continue;
+		nshadow++;
+		if (!trace<true, COUNT>(sc, p, L, 1e-4f, dist, sh, stk, st))
+		{
+			const f3 r = mk3(l.radiance[0] / sq, l.radiance[1] / sq, l.radiance[2] / sq);
+			contrib = contrib + r * NdotL;
+		}
+	}
+	const f3 c = color * contrib;
+	return mk4(c.x, c.y, c.z, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Disney BSDF (bsdf/disney.h) on the 16 packed 8-bit parameters (bsdf/compat.h:47-74)
+// ---------------------------------------------------------------------------------------------------------------
+struct Shading
+{
+	f3 color, absorption;
+	uint32_t p0, p1, p2;
+};
+RT_FN float chan(uint32_t v, int shift) { return (float)((v >> shift) & 255u) * (1.0f / 255.0f); }
+RT_FN float sd_metallic(const Shading &s) { return chan(s.p0, 0); }
+RT_FN float sd_subsurface(const Shading &s) { return chan(s.p0, 8); }
+RT_FN float sd_specular(const Shading &s) { return chan(s.p0, 16); }
+RT_FN float sd_roughness(const Shading &s) { return fmaxf(0.001f, chan(s.p0, 24)); }
+RT_FN float sd_spectint(const Shading &s) { return chan(s.p1, 0); }
+RT_FN float sd_clearcoat(const Shading &s) { return chan(s.p2, 0); }
+RT_FN float sd_clearcoatgloss(const Shading &s) { return chan(s.p2, 8); }
+RT_FN float sd_transmission(const Shading &s) { return chan(s.p2, 16); }
+RT_FN float sd_eta(const Shading &s) { return chan(s.p2, 24); }
+
+#define RT_INVPI 0.318309886183790671537767526745028724f
+#define RT_PI 3.14159265358979323846264338327950288f
+#define RT_INV2PI 0.159154943091895335768883763372514362f
+#define RT_TWOPI 6.28318530717958647692528676655900576f
+
+RT_FN float sqr(float x) { return x * x; }
+RT_FN float schlick_fresnel(float u)
+{
+	const float m = clampf(1.0f - u, 0.0f, 1.0f);
+	return (m * m) * (m * m) * m;
+}
+RT_FN float gtr1(float NDotH, float a)
+{
+	if (a >= 1.0f)
+		return RT_INVPI;
+	const float a2 = a * a;
+	const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+	return (a2 - 1.0f) / (RT_PI * logf(a2) * t);
+}
+RT_FN float gtr2(float NDotH, float a)
+{
+	const float a2 = a * a;
+	const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+	return a2 / (RT_PI * t * t);
+}
+RT_FN float smith_ggx(float NDotv, float alphaG)
+{
+	const float a = alphaG * alphaG;
+	const float b = NDotv * NDotv;
+	return 1.0f / (NDotv + sqrtf(a + b - a * b));
+}
+RT_FN float fresnel_fr(float VDotN, float eio)
+{
+	const float SinThetaT2 = sqr(eio) * (1.0f - VDotN * VDotN);
+	if (SinThetaT2 > 1.0f)
+		return 1.0f;
+	const float LDotN = sqrtf(1.0f - SinThetaT2);
+	const float eta = 1.0f / eio;
+	const float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
+	const float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+	return 0.5f * (sqr(r1) + sqr(r2));
+}
+RT_FN f3 safe_normalize(f3 a)
+{
+	const float ls = dot(a, a);
+	if (ls > 0.0f)
+		return a * (1.0f / sqrtf(ls));
+	return mk3(0, 0, 0);
+}
+RT_FN bool refract_dir(f3 wi, f3 n, float eta, f3 &wt)
+{
+	const float cosThetaI = dot(n, wi);
+	const float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
+	const float sin2ThetaT = eta * eta * sin2ThetaI;
+	if (sin2ThetaT >= 1.0f)
+		return false;
+	const float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+	wt = (wi * -1.0f) * eta + n * (eta * cosThetaI - cosThetaT);
+	return true;
+}
+// disney.h:83-101
+RT_FN float bsdf_pdf(const Shading &sd, f3 N, f3 wo, f3 wi)
+{
+	float bsdfPdf = 0.0f, brdfPdf;
+	if (dot(wi, N) <= 0.0f)
+		brdfPdf = RT_INV2PI * sd_subsurface(sd) * 0.5f;
+	else
+	{
+		const float F = fresnel_fr(dot(N, wo), sd_eta(sd));
+		const f3 halfway = safe_normalize(wi + wo);
+		const float cosThetaHalf = fabsf(dot(halfway, N));
+		const float pdfHalf = gtr2(cosThetaHalf, sd_roughness(sd)) * cosThetaHalf;
+		const float pdfSpec = 0.25f * pdfHalf / fmaxf(1.e-6f, dot(wi, halfway));
+		const float pdfDiff = fabsf(dot(wi, N)) * RT_INVPI * (1.0f - sd_subsurface(sd));
+		bsdfPdf = pdfSpec * F;
+		brdfPdf = lerp1(pdfDiff, pdfSpec, 0.5f);
+	}
+	return lerp1(brdfPdf, bsdfPdf, sd_transmission(sd));
+}
+// disney.h:104-185
+RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfacing)
+{
+	const float NDotL = dot(N, wi);
+	const float NDotV = dot(N, wo);
+	const f3 H = normalize(wi + wo);
+	const float NDotH = dot(N, H);
+	const float LDotH = dot(wi, H);
+	const f3 Cdlin = sd.color;
+	const float Cdlum = .3f * Cdlin.x + .6f * Cdlin.y + .1f * Cdlin.z;
+	const f3 Ctint = Cdlum > 0.0f ? Cdlin * (1.0f / Cdlum) : mk3(1, 1, 1);
+	const float METALLIC = sd_metallic(sd), TRANSMISSION = sd_transmission(sd), SUBSURFACE = sd_subsurface(sd);
+	const float ROUGHNESS = sd_roughness(sd), ETA = sd_eta(sd);
+	const f3 Cspec0 = lerp3(lerp3(mk3(1, 1, 1), Ctint, sd_spectint(sd)) * (sd_specular(sd) * .08f), Cdlin, METALLIC);
+	f3 bsdf = mk3(0, 0, 0), brdf = mk3(0, 0, 0);
+	if (TRANSMISSION > 0.0f)
+	{
+		if (NDotL <= 0)
+		{
+			const float F = fresnel_fr(NDotV, ETA);
+			const float s = (1.0f - F) / fabsf(NDotL) * (1.0f - METALLIC) * TRANSMISSION;
+			bsdf = mk3(s, s, s);
+		}
+		else
+		{
+			const float a = ROUGHNESS;
+			const float Ds = gtr2(NDotH, a);
+			const float FH = fresnel_fr(LDotH, ETA);
+			const f3 Fs = lerp3(Cspec0, mk3(1, 1, 1), FH);
+			const float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+			bsdf = Fs * (Gs * Ds);
+		}
+	}
+	if (TRANSMISSION < 1.0f)
+	{
+		if (NDotL <= 0)
+		{
+			if (SUBSURFACE > 0.0f)
+			{
+				const f3 s = mk3(sqrtf(sd.color.x), sqrtf(sd.color.y), sqrtf(sd.color.z));
+				const float FL = schlick_fresnel(fabsf(NDotL)), FV = schlick_fresnel(NDotV);
+				const float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+				brdf = (((s * RT_INVPI) * SUBSURFACE) * Fd) * (1.0f - METALLIC);
+			}
+		}
+		else
+		{
+			const float a = ROUGHNESS;
+			const float Ds = gtr2(NDotH, a);
+			const float FH = schlick_fresnel(LDotH);
+			const f3 Fs = lerp3(Cspec0, mk3(1, 1, 1), FH);
+			const float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+			const float FL = schlick_fresnel(NDotL), FV = schlick_fresnel(NDotV);
+			const float Fd90 = 0.5f + 2.0f * LDotH * LDotH * a;
+			const float Fd = lerp1(1.0f, Fd90, FL) * lerp1(1.0f, Fd90, FV);
+			const float Dr = gtr1(NDotH, lerp1(.1f, .001f, sd_clearcoatgloss(sd)));
+			const float Fc = lerp1(.04f, 1.0f, FH);
+			const float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
+			const f3 diff = ((Cdlin * (RT_INVPI * Fd)) * (1.0f - METALLIC)) * (1.0f - SUBSURFACE);
+			const f3 spec = (Fs * Gs) * Ds;
+			const float cc = sd_clearcoat(sd) * Gr * Fc * Dr;
+			brdf = (diff + spec) + mk3(cc, cc, cc);
+		}
+	}
+	const f3 fin = lerp3(brdf, bsdf, TRANSMISSION);
+	if (backfacing)
+		return fin * mk3(expf(-sd.absorption.x * t), expf(-sd.absorption.y * t), expf(-sd.absorption.z * t));
+	return fin;
+}
+RT_FN f3 reflect_dir(f3 I, f3 N) { return I - N * (dot(N, I) * 2.0f); }
+RT_FN f3 diffuse_reflection_uniform(float r0, float r1)
+{
+	const float term1 = RT_TWOPI * r0, term2 = sqrtf(1.0f - r1 * r1);
+	return mk3(cosf(term1) * term2, sinf(term1) * term2, r1);
+}
+RT_FN f3 diffuse_reflection_cos_weighted(float r0, float r1)
+{
+	const float term1 = RT_TWOPI * r0;
+	const float term2 = (float)sqrt(1.0 - (double)r1); // tools.h:113 computes this term in double
+	return normalize(mk3(cosf(term1) * term2, sinf(term1) * term2, sqrtf(r1)));
+}
+RT_FN f3 ggx_halfway(f3 T, f3 B, f3 N, f3 wo, float rough, float r1, float r2)
+{
+	const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(rough) - 1.0f) * r2));
+	const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
+	const float sinPhiHalf = sinf(r1 * RT_TWOPI);
+	const float cosPhiHalf = cosf(r1 * RT_TWOPI);
+	f3 halfway = (T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf)) + N * cosThetaHalf;
+	if (dot(halfway, wo) <= 0.0f)
+		halfway = halfway * -1.0f;
+	return halfway;
+}
+// disney.h:188-262; pdf keeps its incoming value (0) on the Fresnel-reflection branch like the reference
+RT_FN void bsdf_sample(const Shading &sd, f3 T, f3 B, f3 N, f3 wo, f3 &wi, float &pdf, float r3, float r4)
+{
+	const float transmission = sd_transmission(sd);
+	const float ROUGHNESS = sd_roughness(sd);
+	if (r3 < transmission)
+	{
+		const float F = fresnel_fr(dot(N, wo), sd_eta(sd));
+		if (r4 < F)
+		{
+			const float r1 = r3 / transmission;
+			const float r2 = r4 / F;
+			wi = reflect_dir(wo * -1.0f, ggx_halfway(T, B, N, wo, ROUGHNESS, r1, r2));
+		}
+		else
+		{
+			pdf = 0;
+			if (refract_dir(wo, N, sd_eta(sd), wi))
+				pdf = (1.0f - F) * transmission;
+		}
+		return;
+	}
+	const float r1 = (r3 - transmission) / (1 - transmission);
+	if (r4 < 0.5f)
+	{
+		const float r2 = r4 * 2;
+		const float subsurface = sd_subsurface(sd);
+		f3 d;
+		if (r2 < subsurface)
+		{
+			const float r5 = r2 / subsurface;
+			d = diffuse_reflection_uniform(r1, r5);
+			d.z *= -1.0f;
+		}
+		else
+		{
+			const float r5 = (r2 - subsurface) / (1.0f - subsurface);
+			d = diffuse_reflection_cos_weighted(r1, r5);
+		}
+		wi = (T * d.x + B * d.y) + N * d.z;
+	}
+	else
+	{
+		const float r2 = (r4 - 0.5f) * 2.0f;
+		wi = reflect_dir(wo * -1.0f, ggx_halfway(T, B, N, wo, ROUGHNESS, r1, r2));
+	}
+	pdf = bsdf_pdf(sd, N, wo, wi);
+}
+
+// bsdf/tools.h
+RT_FN uint32_t pack_normal(f3 N)
+{
+	const float f = 65535.0f / fmaxf(sqrtf(8.0f * N.z + 8.0f), 0.0001f);
+	return f2u_sat(N.x * f + 32767.0f) + (f2u_sat(N.y * f + 32767.0f) << 16);
+}
+RT_FN f3 unpack_normal(uint32_t p)
+{
+	float nx = (float)(p & 65535u) * (2.0f / 65535.0f), ny = (float)(p >> 16) * (2.0f / 65535.0f);
+	nx += -1.0f, ny += -1.0f;
+	const float nz0 = 1.0f, nw = -1.0f;
+	float l = nx * -nx + ny * -ny + nz0 * -nw;
+	const float nz = l;
+	l = sqrtf(l);
+	nx *= l, ny *= l;
+	return mk3(nx * 2.0f, ny * 2.0f, nz * 2.0f - 1.0f);
+}
+RT_FN float survival_probability(f3 d) { return fminf(1.0f, fmaxf(fmaxf(d.x, d.y), d.z)); }
+RT_FN f3 clamp_intensity(f3 v, float clampValue)
+{
+	const float m = fmaxf(v.x, fmaxf(v.y, v.z));
+	if (m > clampValue)
+		return v * (clampValue / m);
+	return v;
+}
+RT_FN void create_tangent_space(f3 N, f3 &T, f3 &B)
+{
+	const float s = signf(N.z);
+	const float a = -1.0f / (s + N.z);
+	const float b = N.x * N.y * a;
+	T = mk3(1.0f + s * N.x * N.x * a, s * b, -s * N.x);
+	B = mk3(b, s + N.y * N.y * a, -N.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// light sampling: CUDART/src/lights.h
+// ---------------------------------------------------------------------------------------------------------------
+RT_FN float pot_area(const SceneView &sc, uint32_t idx, f3 O, f3 N, f3 I, f3 bary)
+{
+	const AreaLight &l = sc.area[idx];
+	f3 L = I;
+	if (bary.x >= 0)
+		L = (ld3(l.vertex0) * bary.x + ld3(l.vertex1) * bary.y) + ld3(l.vertex2) * bary.z;
+	L = L - O;
+	const float att = 1.0f / dot(L, L);
+	L = normalize(L);
+	const float LNdotL = fmaxf(0.0f, -dot(ld3(l.normal), L));
+	const float NdotL = fmaxf(0.0f, dot(N, L));
+	return l.energy * LNdotL * NdotL * att;
+}
+RT_FN float pot_point(const SceneView &sc, uint32_t idx, f3 I, f3 N)
+{
+	const PointLight &l = sc.point[idx];
+	const f3 L = ld3(l.position) - I;
+	const float NdotL = fmaxf(0.0f, dot(N, L));
+	const float att = 1.0f / dot(L, L);
+	return l.energy * NdotL * att;
+}
+RT_FN float pot_spot(const SceneView &sc, uint32_t idx, f3 I, f3 N)
+{
+	const SpotLight &l = sc.spot[idx];
+	f3 L = ld3(l.position) - I;
+	const float att = 1.0f / dot(L, L);
+	L = normalize(L);
+	const float d = (fmaxf(0.0f, -dot(L, ld3(l.direction))) - l.cosOuter) / (l.cosInner - l.cosOuter);
+	const float NdotL = fmaxf(0.0f, dot(N, L));
+	const float LNdotL = fmaxf(0.0f, fminf(1.0f, d));
+	return l.energy * LNdotL * NdotL * att;
+}
+RT_FN float pot_dir(const SceneView &sc, uint32_t idx, f3 N)
+{
+	const DirectionalLight &l = sc.dir[idx];
+	return l.energy * fmaxf(0.0f, -dot(ld3(l.direction), N));
+}
+RT_FN uint32_t total_lights(const SceneView &sc) { return sc.n_area + sc.n_point + sc.n_spot + sc.n_dir; }
+RT_FN float pot_any(const SceneView &sc, uint32_t k, f3 I, f3 N, f3 bary)
+{
+	if (k < sc.n_area)
+		return pot_area(sc, k, I, N, mk3(0, 0, 0), bary);
+	k -= sc.n_area;
+	if (k < sc.n_point)
+		return pot_point(sc, k, I, N);
+	k -= sc.n_point;
+	if (k < sc.n_spot)
+		return pot_spot(sc, k, I, N);
+	k -= sc.n_spot;
+	return pot_dir(sc, k, N);
+}
+// lights.h:83-116
+RT_FN float light_pick_prob(const SceneView &sc, int idx, f3 O, f3 N, f3 I)
+{
+	float sum = 0, mine = 0;
+	for (uint32_t i = 0; i < sc.n_area; i++)
+	{
+		const float p = pot_area(sc, i, O, N, I, mk3(-1, -1, -1));
+		if ((int)i == idx)
+			mine = p;
+		sum += p;
+	}
+	for (uint32_t i = 0; i < sc.n_point; i++)
+		sum += pot_point(sc, i, O, N);
+	for (uint32_t i = 0; i < sc.n_spot; i++)
+		sum += pot_spot(sc, i, O, N);
+	for (uint32_t i = 0; i < sc.n_dir; i++)
+		sum += pot_dir(sc, i, N);
+	if (sum <= 0)
+		return 0;
+	return mine / sum;
+}
+// lights.h:119-157
+RT_FN f3 random_barycentrics(float r0)
+{
+	const uint32_t uf = f2u_sat(r0 * 4294967295.0f);
+	float Ax = 1.f, Ay = 0.f, Bx = 0.f, By = 1.f, Cx = 0.f, Cy = 0.f;
+	for (int i = 0; i < 16; ++i)
+	{
+		const int d = (int)((uf >> (2 * (15 - i))) & 0x3u);
+		float Anx, Any, Bnx, Bny, Cnx, Cny;
+		if (d == 0)
+		{
+			Anx = (Bx + Cx) * 0.5f, Any = (By + Cy) * 0.5f;
+			Bnx = (Ax + Cx) * 0.5f, Bny = (Ay + Cy) * 0.5f;
+			Cnx = (Ax + Bx) * 0.5f, Cny = (Ay + By) * 0.5f;
+		}
+		else if (d == 1)
+		{
+			Anx = Ax, Any = Ay;
+			Bnx = (Ax + Bx) * 0.5f, Bny = (Ay + By) * 0.5f;
+			Cnx = (Ax + Cx) * 0.5f, Cny = (Ay + Cy) * 0.5f;
+		}
+		else if (d == 2)
+		{
+			Anx = (Bx + Ax) * 0.5f, Any = (By + Ay) * 0.5f;
+			Bnx = Bx, Bny = By;
+			Cnx = (Bx + Cx) * 0.5f, Cny = (By + Cy) * 0.5f;
+		}
+		else
+		{
+			Anx = (Cx + Ax) * 0.5f, Any = (Cy + Ay) * 0.5f;
+			Bnx = (Cx + Bx) * 0.5f, Bny = (Cy + By) * 0.5f;
+			Cnx = Cx, Cny = Cy;
+		}
+		Ax = Anx, Ay = Any, Bx = Bnx, By = Bny, Cx = Cnx, Cy = Cny;
+	}
+	const float rx = (Ax + Bx + Cx) * 0.3333333f, ry = (Ay + By + Cy) * 0.3333333f;
+	return mk3(rx, ry, 1.0f - rx - ry);
+}
+// lights.h:159-265 with importance sampling over the potential contribution of every light.  The potentials are
+// recomputed in the selection pass instead of being kept in a MAX_IS_LIGHTS array, so any light count is valid.
+RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3 N, float &pickProb, float &lightPdf,
+							   f3 &lightColor)
+{
+	const uint32_t lights = total_lights(sc);
+	const f3 bary = random_barycentrics(r0);
+	float sum = 0;
+	for (uint32_t k = 0; k < lights; k++)
+		sum += pot_any(sc, k, I, N, bary);
+	if (sum <= 0)
+	{
+		lightPdf = 0;
+		return mk3(1, 1, 1);
+	}
+	r1 *= sum;
+	float total = 0, chosen = 0, first = 0;
+	uint32_t li = 0;
+	for (uint32_t k = 0; k < lights; k++)
+	{
+		const float p = pot_any(sc, k, I, N, bary);
+		if (k == 0)
+			first = p;
+		total += p;
+		if (total >= r1)
+		{
+			li = k, chosen = p;
+			break;
+		}
+		if (k == lights - 1)
+			li = 0, chosen = first;
+	}
+	pickProb = chosen / sum;
+	if (li < sc.n_area)
+	{
+		const AreaLight &l = sc.area[li];
+		lightColor = ld3(l.radiance);
+		const f3 LN = ld3(l.normal);
+		const f3 P = (ld3(l.vertex0) * bary.x + ld3(l.vertex1) * bary.y) + ld3(l.vertex2) * bary.z;
+		f3 L = I - P;
+		const float sqDist = dot(L, L);
+		L = normalize(L);
+		const float LNdotL = dot(L, LN);
+		const float reciSolidAngle = sqDist / (l.area * LNdotL);
+		const float energy = length(ld3(l.radiance)); // DeviceAreaLight::getEnergy, device_structs.h:115
+		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? (reciSolidAngle * (1.0f / energy)) : 0;
+		return P;
+	}
+	li -= sc.n_area;
+	if (li < sc.n_point)
+	{
+		const PointLight &l = sc.point[li];
+		const f3 pos = ld3(l.position);
+		lightColor = ld3(l.radiance);
+		const f3 L = I - pos;
+		const float sqDist = dot(L, L);
+		lightPdf = dot(L, N) < 0 ? (sqDist / l.energy) : 0;
+		return pos;
+	}
+	li -= sc.n_point;
+	if (li < sc.n_spot)
+	{
+		const SpotLight &l = sc.spot[li];
+		const f3 P = ld3(l.position);
+		f3 L = I - P;
+		const float sqDist = dot(L, L);
+		L = normalize(L);
+		const float d = fmaxf(0.0f, dot(L, ld3(l.direction)) - l.cosOuter) / (l.cosInner - l.cosOuter);
+		const float LNdotL = fminf(1.0f, d);
+		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? (sqDist / (LNdotL * l.energy)) : 0;
+		lightColor = ld3(l.radiance);
+		return P;
+	}
+	li -= sc.n_spot;
+	const DirectionalLight &l = sc.dir[li];
+	const f3 L = ld3(l.direction);
+	lightColor = ld3(l.radiance);
+	const float NdotL = dot(L, N);
+	lightPdf = NdotL < 0 ? (1.0f / l.energy) : 0;
+	return I - L * 1000.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PATH-TRACING shade step for one path vertex: CUDART/src/Kernels.cu:571-794
+// ---------------------------------------------------------------------------------------------------------------
+struct PathIn
+{
+	f3 O, D, T;
+	float bsdfPdf;
+	uint32_t slot, flags, packedN;
+	uint32_t pixel;		// global pixel id y*W + x (RNG key)
+	uint32_t sampleIdx; // global sample index (RNG key)
+	uint32_t depth;		// pathLength
+};
+struct ShadeOut
+{
+	f3 radiance; // to add to the path's slot
+	bool emit_shadow, emit_ext;
+	f4 so, sd, se; // shadow ray: origin|slot, dir|tmax, contribution
+	f4 eo, ed, et; // extension ray: origin|slot<<1|flags, dir|packedN, throughput|pdf
+};
+
+RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
+					ShadeOut &out)
+{
+	out.radiance = mk3(0, 0, 0);
+	out.emit_shadow = false, out.emit_ext = false;
+	const f3 O = in.O, D = in.D;
+	f3 T = in.T;
+	if (h.prim < 0)
+	{
+		f3 contribution = (T * (1.0f / in.bsdfPdf)) * pt_sky(sc, D);
+		if (any_nan(contribution))
+			return;
+		out.radiance = clamp_intensity(contribution, cam.clamp_value);
+		return;
+	}
+	const f3 I = O + D * h.t;
+	const Instance &inst = sc.instances[h.inst];
+	const TriShade &ts = sc.tri_shade[inst.shade_base + (uint32_t)h.prim];
+	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, tu4 = ts.tu, tv4 = ts.tv, ex = ts.ex;
+	const MaterialRec &mat = sc.materials[fbits(tv4.w)];
+	const uint32_t mflags = mat.flags;
+	// getShadingData.h:100-217 (its u,v,w weight vertex 0,1,2)
+	const float bw0 = 1.0f - h.u - h.v, bw1 = h.u, bw2 = h.v;
+	Shading sd;
+	sd.color = material_color(mat);
+	sd.absorption = mk3(half_to_float(mat.transmittance[0]), half_to_float(mat.transmittance[1]),
+						half_to_float(mat.transmittance[2]));
+	sd.p0 = mat.parameters[0], sd.p1 = mat.parameters[1], sd.p2 = mat.parameters[2];
+	f3 N = mk3(n0.w, n1.w, n2.w), iN = N;
+	if (mat_flag(mflags, MF_SMOOTH_NORMALS))
+		iN = normalize((xyz(n0) * bw0 + xyz(n1) * bw1) + xyz(n2) * bw2);
+	N = normalize(mul_normal(inst, N));
+	iN = normalize(mul_normal(inst, iN));
+	f3 Tg, Bt;
+	create_tangent_space(iN, Tg, Bt);
+	if (mat_flag(mflags, MF_DIFFUSE_MAP) && mat.map[0].addr < sc.texture_count)
+	{
+		const float tu = bw0 * tu4.x + bw1 * tu4.y + bw2 * tu4.z;
+		const float tv = bw0 * tv4.x + bw1 * tv4.y + bw2 * tv4.z;
+		const float coneWidth = cam.spread_angle * h.t;
+		const float lambda = ex.y + log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, N))));
+		const TexDesc td = sc.textures[mat.map[0].addr];
+		const f4 texel = fetch_trilinear(sc, td, lambda,
+										 half_to_float(mat.map[0].uscale) * (half_to_float(mat.map[0].uoffs) + tu),
+										 half_to_float(mat.map[0].vscale) * (half_to_float(mat.map[0].voffs) + tv),
+										 mat.map[0].width, mat.map[0].height);
+		// getShadingData.h:150 and :206 both multiply by the texel
+		sd.color = sd.color * xyz(texel);
+		sd.color = sd.color * xyz(texel);
+	}
+	// emissive surface: Kernels.cu:650-692
+	if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f)
+	{
+		const float DdotNL = -dot(D, N);
+		f3 contribution = mk3(0, 0, 0);
+		if (DdotNL > 0)
+		{
+			if (in.depth == 0)
+				contribution = sd.color;
+			else if (in.flags & 1u)
+				contribution = (T * sd.color) * (1.0f / in.bsdfPdf);
+			else
+			{
+				const f3 lastN = unpack_normal(in.packedN);
+				const float lightPdf = (h.t * h.t) / (-dot(D, N) * ex.x); // lights.h:78-81
+				const int ltri = (int)fbits(tu4.w);
+				// the reference reads the material id as light index (device_structs.h:37,40); lightTriIdx is meant
+				const float pickProb =
+					(ltri >= 0 && (uint32_t)ltri < sc.n_area) ? light_pick_prob(sc, ltri, O, lastN, I) : 0.0f;
+				if ((in.bsdfPdf + lightPdf * pickProb) <= 0)
+					return;
+				contribution = (T * sd.color) * (1.0f / (in.bsdfPdf + lightPdf * pickProb));
+			}
+		}
+		if (any_nan(contribution))
+			contribution = mk3(0, 0, 0);
+		out.radiance = clamp_intensity(contribution, cam.clamp_value);
+		return;
+	}
+	uint32_t flags = in.flags;
+	if (sd_roughness(sd) < 0.01f)
+		flags |= 1u;
+	else
+		flags &= ~1u;
+	uint32_t seed = wang_hash(in.pixel * 16789u + in.sampleIdx * 1791u + in.depth * 720898027u);
+	const float flip = (dot(D, N) > 0) ? -1.0f : 1.0f;
+	N = N * flip;
+	iN = iN * flip;
+	T = T * (1.0f / in.bsdfPdf);
+	const f3 wo = D * -1.0f;
+	// next-event estimation: Kernels.cu:702-755
+	if ((flags & 1u) == 0 && total_lights(sc) > 0)
+	{
+		f3 lightColor = mk3(0, 0, 0);
+		float pickProb = 0, lightPdf = 0;
+		const float q0 = random_float(seed), q1 = random_float(seed);
+		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor) - I;
+		const float dist = length(L);
+		L = L * (1.0f / dist);
+		const float NdotL = dot(L, iN);
+		if (NdotL > 0 && lightPdf > 0)
+		{
+			const f3 bs = bsdf_eval(sd, iN, wo, L, 0.0f, false);
+			const float shadowPdf = bsdf_pdf(sd, iN, wo, L);
+			if (shadowPdf > 0)
+			{
+				f3 contribution = ((T * bs) * lightColor) * (NdotL / (shadowPdf + lightPdf * pickProb));
+				contribution = clamp_intensity(contribution, cam.clamp_value);
+				if (!any_nan(contribution))
+				{
+					const f3 so = I + N * 1e-5f; // SafeOrigin, tools.h:119-123
+					out.emit_shadow = true;
+					out.so = mk4(so.x, so.y, so.z, ubits(in.slot));
+					out.sd = mk4(L.x, L.y, L.z, dist - 2.0f * 1e-5f);
+					out.se = mk4(contribution.x, contribution.y, contribution.z, 0.0f);
+				}
+			}
+		}
+	}
+	if (in.depth >= max_depth)
+		return;
+	f3 R = mk3(0, 0, 1);
+	float newPdf = 0.0f;
+	const float q3 = random_float(seed), q4 = random_float(seed);
+	bsdf_sample(sd, Tg, Bt, iN, wo, R, newPdf, q3, q4);
+	const f3 bs = bsdf_eval(sd, iN, wo, R, h.t, flip < 0);
+	{
+		// throughput * 1.0f / SurvivalProbability(throughput) * bsdf * abs(dot(iN, R))   (Kernels.cu:783)
+		const float surv = survival_probability(T);
+		T = ((mk3(T.x / surv, T.y / surv, T.z / surv)) * bs) * fabsf(dot(iN, R));
+	}
+	if (newPdf < 1e-6f || (newPdf != newPdf) || T.x < 0.0f || T.y < 0.0f || T.z < 0.0f)
+		return;
+	const f3 eo = I + N * 1e-5f;
+	out.emit_ext = true;
+	out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (flags & 1u)));
+	out.ed = mk4(R.x, R.y, R.z, ubits(pack_normal(iN)));
+	out.et = mk4(T.x, T.y, T.z, newPdf);
+}
+
+} // namespace rt

@@ -1,0 +1,210 @@
+// rt_types.h — data layout of the HIP rendercore in HBM (shared by host code and kernels).
+//
+// Everything the kernels touch lives in a handful of flat device arrays, described by SceneView / WaveView.
+// Layout decisions:
+//   * BVH2 nodes keep the reference's 32-byte layout (RFW/system/bvh/include/bvh/bvh_node.h:23-28) so that the two
+//     children of an inner node (always adjacent, pair-aligned to 64 B) arrive as four 16-byte loads.
+//   * Triangles are stored TWICE: `tri_verts` in BVH-leaf order for intersection (3 x float4, w of vertex 0 carries
+//     the original primitive id, so no index indirection at test time), and `tri_shade` in mesh order for shading
+//     (6 x float4 = 96 B instead of the reference's 160-byte AoS Triangle, structs.h:24-60).
+//   * Ray / hit / throughput records are arrays of float4 indexed by the (compacted) path index: one 16-byte
+//     access per lane per attribute, 1 KiB per wave instruction.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) && !defined(RFWHIP_HOST_EMULATION)
+#include <hip/hip_runtime.h>
+#define RT_FN __host__ __device__ __forceinline__
+#define RT_DEVICE_BUILD 1
+#else
+#define RT_FN inline
+#endif
+
+namespace rt
+{
+
+struct alignas(16) f4
+{
+	float x, y, z, w;
+};
+struct f3
+{
+	float x, y, z;
+};
+
+constexpr uint32_t STRIP_ROWS = 8;	  // rows per ownership strip
+constexpr uint32_t TILE = 8;		  // 8x8 pixel tile = one wave64
+constexpr uint32_t ENTRY_LEAF = 0x80000000u;
+constexpr uint32_t ENTRY_TLAS = 0x40000000u;
+constexpr uint32_t ENTRY_SENTINEL = 0xFFFFFFFFu;
+constexpr uint32_t ENTRY_FIRST_MASK = 0x07FFFFFFu; // 27 bits: first primitive of a leaf
+constexpr uint32_t ENTRY_INDEX_MASK = 0x3FFFFFFFu; // 30 bits: left child of an inner node
+constexpr int MAX_LEAF_PRIMS = 8;				   // 3 bits of (count-1) in a leaf entry
+constexpr int STACK_DEPTH = 48;					   // traversal stack entries per lane (LDS)
+
+RT_FN uint32_t make_entry(int left_first, int count, bool tlas)
+{
+	const uint32_t t = tlas ? ENTRY_TLAS : 0u;
+	if (count >= 0)
+		return ENTRY_LEAF | t | ((uint32_t)(count - 1) << 27) | ((uint32_t)left_first & ENTRY_FIRST_MASK);
+	return t | ((uint32_t)left_first & ENTRY_INDEX_MASK);
+}
+
+// One BVH2 node, byte-compatible with rfw::bvh::BVHNode (32 B).
+struct alignas(16) Node
+{
+	float bmin[3];
+	float bmax[3];
+	int left_first;
+	int count;
+};
+
+// Per-instance record (set_instance): inverse transform for rays, normal matrix for shading, BLAS location.
+struct alignas(16) Instance
+{
+	float inv[12];		 // rows 0..2 of M^-1 (row-major 3x4)
+	float nrm[12];		 // normal matrix, 3 columns padded to float4 (column-major like glm::mat3)
+	uint32_t root_entry; // stack entry of the BLAS root
+	uint32_t node_base;	 // first node of the BLAS in SceneView::nodes
+	uint32_t tri_base;	 // first leaf-ordered triangle of the BLAS in SceneView::tri_verts
+	uint32_t shade_base; // first mesh-ordered shading record in SceneView::tri_shade
+};
+
+// Shading record per triangle (mesh order), 96 B.
+struct alignas(16) TriShade
+{
+	f4 n0; // vN0.xyz, Nx
+	f4 n1; // vN1.xyz, Ny
+	f4 n2; // vN2.xyz, Nz
+	f4 tu; // u0,u1,u2, bits(lightTriIdx)
+	f4 tv; // v0,v1,v2, bits(material)
+	f4 ex; // area, LOD, 0, 0
+};
+
+struct TexDesc
+{
+	uint32_t type, width, height, texelCount;
+	uint32_t offset; // first texel in tex_u32 (UINT) or tex_f4 (FLOAT4)
+	uint32_t pad[3];
+};
+
+// 192-byte material exactly as handed over (structs.h:85-127).
+struct alignas(16) MaterialRec
+{
+	uint16_t diffuse[3];
+	uint16_t transmittance[3];
+	uint32_t flags;
+	uint32_t parameters[4];
+	struct
+	{
+		int16_t width, height;
+		uint16_t uscale, vscale, uoffs, voffs;
+		uint32_t addr;
+	} map[10];
+};
+static_assert(sizeof(MaterialRec) == 192, "material layout");
+
+struct AreaLight
+{
+	float position[3], energy, normal[3], area, radiance[3];
+	int dummy0;
+	float vertex0[3];
+	int triIdx;
+	float vertex1[3];
+	int instIdx;
+	float vertex2[3];
+	int dummy1;
+};
+struct PointLight
+{
+	float position[3], energy, radiance[3];
+	int dummy;
+};
+struct SpotLight
+{
+	float position[3], cosInner, radiance[3], cosOuter, direction[3], energy;
+};
+struct DirectionalLight
+{
+	float direction[3], energy, radiance[3];
+	int dummy;
+};
+
+struct SceneView
+{
+	const Node *nodes;		 // all BLAS nodes, concatenated
+	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
+	const TriShade *tri_shade;
+	const Node *tlas_nodes;
+	const uint32_t *tlas_prims; // instance index per TLAS leaf slot
+	const Instance *instances;
+	uint32_t tlas_root_entry;
+	uint32_t instance_count;
+	const MaterialRec *materials;
+	uint32_t material_count;
+	const TexDesc *textures;
+	uint32_t texture_count;
+	const uint32_t *tex_u32;
+	const f4 *tex_f4;
+	const f4 *sky; // rgb + pad per texel
+	uint32_t sky_w, sky_h;
+	const AreaLight *area;
+	const PointLight *point;
+	const SpotLight *spot;
+	const DirectionalLight *dir;
+	uint32_t n_area, n_point, n_spot, n_dir;
+};
+
+// Camera as the kernels need it (EmbreeRT/src/Ray.cpp:3-14: right = p2-p1, up = p3-p1).
+struct CamView
+{
+	f3 pos, p1, right, up;
+	float aperture, spread_angle, clamp_value;
+};
+
+// Which image rows this rank owns, and how path slots map to pixels.
+struct FrameView
+{
+	uint32_t W, H;		   // full image
+	uint32_t local_rows;   // padded rows on this rank (multiple of STRIP_ROWS)
+	uint32_t tiles_x;	   // ceil(W / 8)
+	uint32_t slots;		   // tiles_x*8 * local_rows  = path slots per sample
+	uint32_t rank, world;
+	uint32_t spp;		   // samples in this batch
+	uint32_t sample_base;  // index of the first sample of the batch
+	uint32_t probe_pixel;  // y*W + x
+};
+
+// Device counters, zeroed per render call.  ext[d] = number of paths entering depth d (ext[0] is set by the host),
+// shadow[d] = shadow rays emitted by the shade stage of depth d.
+constexpr int MAX_DEPTH_SLOTS = 16;
+struct WaveCounters
+{
+	uint32_t ext[MAX_DEPTH_SLOTS];
+	uint32_t shadow[MAX_DEPTH_SLOTS];
+	unsigned long long rays_extend, rays_shadow, inner_extend, tris_extend, inner_shadow, tris_shadow, shaded, samples;
+	uint32_t probe_inst, probe_prim;
+	float probe_dist;
+	uint32_t probe_valid;
+};
+
+// The wavefront state in HBM.
+struct WaveView
+{
+	f4 *org[2];	 // origin.xyz, bits(slot << 1 | specular)
+	f4 *dir[2];	 // direction.xyz, bits(packed normal of the previous vertex)
+	f4 *thr[2];	 // throughput.rgb, pending bsdf pdf
+	f4 *hit;	 // t, u, v, bits(prim)       (depth >= 1)
+	int *hit_inst;
+	f4 *hit0;	 // same, primary wave (kept for read_primary_hits / probe)
+	int *hit0_inst;
+	f4 *sh_org;	 // shadow ray origin.xyz, bits(slot)
+	f4 *sh_dir;	 // direction.xyz, tmax
+	f4 *sh_rad;	 // contribution.rgb
+	f4 *rad;	 // per-slot radiance of the batch (rgb, alpha)
+	f4 *acc;	 // per local pixel accumulator (row-major local_rows x W)
+	const uint32_t *packet_rng; // parity integrator: xor128 state per (sample, packet), 4 x u32
+	WaveCounters *counters;
+};
+
+} // namespace rt

@@ -110,39 +110,43 @@ def triangle_area(v0, v1, v2):
 
 
 def make_triangles(vertices, indices=None, normals=None, uvs=None, material=0):
-    """Per-face Triangle records for a mesh; vertices (N,3|4), indices (M,3) or None (non-indexed)."""
+    """Per-face Triangle records for a mesh; vertices (N,3|4), indices (M,3) or None (non-indexed).
+    Built as a flat (M, 40) float32 table (the 160-byte record is 40 dwords) and viewed as TRIANGLE_DTYPE."""
     v = np.asarray(vertices, np.float32)[:, :3]
     if indices is None:
         idx = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
     else:
         idx = np.asarray(indices, np.uint32).reshape(-1, 3)
+    m = len(idx)
     p0, p1, p2 = v[idx[:, 0]], v[idx[:, 1]], v[idx[:, 2]]
     n = np.cross(p1 - p0, p2 - p0).astype(np.float32)
     ln = np.linalg.norm(n, axis=1, keepdims=True)
     n = (n / np.maximum(ln, 1e-30)).astype(np.float32)
-    t = np.zeros(len(idx), dtype=abi.TRIANGLE_DTYPE)
-    t["lightTriIdx"] = -1
-    t["material"] = np.asarray(material, np.uint32)
-    t["Nx"], t["Ny"], t["Nz"] = n[:, 0], n[:, 1], n[:, 2]
-    if normals is None:
-        t["vN0"] = t["vN1"] = t["vN2"] = n
-    else:
-        vn = np.asarray(normals, np.float32)
-        t["vN0"], t["vN1"], t["vN2"] = vn[idx[:, 0]], vn[idx[:, 1]], vn[idx[:, 2]]
+    # filled column-wise in a (40, M) table (contiguous rows), transposed once at the end
+    tt = np.zeros((40, m), np.float32)
+    it, ut = tt.view(np.int32), tt.view(np.uint32)
+    it[3] = -1                                             # lightTriIdx
+    ut[7] = np.asarray(material, np.uint32)                # material
     if uvs is not None:
         uv = np.asarray(uvs, np.float32)
-        t["u"] = np.stack([uv[idx[:, 0], 0], uv[idx[:, 1], 0], uv[idx[:, 2], 0]], 1)
-        t["v"] = np.stack([uv[idx[:, 0], 1], uv[idx[:, 1], 1], uv[idx[:, 2], 1]], 1)
-    e = (p1 - p0)
-    le = np.linalg.norm(e, axis=1, keepdims=True)
-    tang = (e / np.maximum(le, 1e-30)).astype(np.float32)
-    t["T"] = tang
-    t["B"] = np.cross(n, tang).astype(np.float32)
-    t["area"] = triangle_area(p0, p1, p2)
-    t["LOD"] = 0.0
-    t["vertex0"], t["vertex1"], t["vertex2"] = p0, p1, p2
-    t["dummy1"] = t["dummy2"] = t["dummy3"] = 1.0
-    return t
+        for k in range(3):
+            tt[k] = uv[idx[:, k], 0]                       # u0,u1,u2
+            tt[4 + k] = uv[idx[:, k], 1]                   # v0,v1,v2
+    if normals is None:
+        tt[8:11] = tt[12:15] = tt[16:19] = n.T             # vN0, vN1, vN2
+    else:
+        vn = np.asarray(normals, np.float32)
+        tt[8:11], tt[12:15], tt[16:19] = vn[idx[:, 0]].T, vn[idx[:, 1]].T, vn[idx[:, 2]].T
+    tt[11], tt[15], tt[19] = n[:, 0], n[:, 1], n[:, 2]     # Nx, Ny, Nz
+    e = p1 - p0
+    tang = (e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    tt[20:23] = tang.T                                     # T
+    tt[23] = triangle_area(p0, p1, p2)                     # area
+    tt[24:27] = np.cross(n, tang).T                        # B
+    tt[28:31], tt[32:35], tt[36:39] = p0.T, p1.T, p2.T
+    tt[31] = tt[35] = tt[39] = 1.0
+    tab = np.ascontiguousarray(tt.T)
+    return tab.view(abi.TRIANGLE_DTYPE).reshape(m)
 
 
 def quad(normal, pos, width, height):
@@ -245,16 +249,19 @@ class Scene:
 
     def set_gradient_sky(self, width=2048, height=1024):
         """Synthetic HDR equirect: horizon gradient + a sun disc + two bright patches."""
-        v = (np.arange(height, dtype=np.float32) + 0.5) / height
-        u = (np.arange(width, dtype=np.float32) + 0.5) / width
-        zen = np.clip(1.0 - v * 2.0, 0, 1)[:, None]
-        px = np.zeros((height, width, 3), np.float32)
-        px[..., 0] = 0.35 + 0.25 * (1 - zen)
-        px[..., 1] = 0.45 + 0.30 * (1 - zen)
-        px[..., 2] = 0.95 - 0.25 * (1 - zen)
-        px[v > 0.5] *= 0.15
-        du, dv = u[None, :] - 0.30, v[:, None] - 0.22
-        px[(du * du * 4 + dv * dv) < 0.0004] = (60.0, 55.0, 40.0)
+        v = ((np.arange(height, dtype=np.float32) + 0.5) / height)[:, None]
+        u = ((np.arange(width, dtype=np.float32) + 0.5) / width)[None, :]
+        hz = 1.0 - np.clip(1.0 - v * 2.0, 0, 1)
+        dim = np.where(v > 0.5, np.float32(0.15), np.float32(1.0))
+        px = np.empty((height, width, 3), np.float32)
+        px[..., 0] = (0.35 + 0.25 * hz) * dim
+        px[..., 1] = (0.45 + 0.30 * hz) * dim
+        px[..., 2] = (0.95 - 0.25 * hz) * dim
+        y0, y1 = int(height * 0.18), int(height * 0.26)
+        x0, x1 = int(width * 0.28), int(width * 0.32)
+        du, dv = u[:, x0:x1] - 0.30, v[y0:y1] - 0.22
+        sun = (du * du * 4 + dv * dv) < 0.0004
+        px[y0:y1, x0:x1][sun] = (20.0, 18.0, 13.0)
         px[int(height * 0.30):int(height * 0.34), int(width * 0.70):int(width * 0.74)] = (8.0, 2.0, 1.0)
         px[int(height * 0.10):int(height * 0.13), int(width * 0.55):int(width * 0.58)] = (1.0, 6.0, 9.0)
         self.sky = (px.reshape(-1, 3), width, height)
@@ -403,6 +410,15 @@ def cornell(width=512, height=512, geometric_emitter=False, point_light=True):
     return s
 
 
+def _accumulate_vertex_normals(nverts, idx, face_normals):
+    """Area-weighted smooth vertex normals (sum of the incident un-normalised face normals)."""
+    vn = np.zeros((nverts, 3), np.float64)
+    for k in range(3):
+        for a in range(3):
+            vn[:, a] += np.bincount(idx[:, k], weights=face_normals[:, a], minlength=nverts)
+    return (vn / np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+
+
 def _hash01(ix, iz, seed):
     """Deterministic uniform [0,1) per lattice point (integer hash; seed 0x5EED for the displaced grid)."""
     h = (ix.astype(np.uint64) * np.uint64(0x9E3779B1) + iz.astype(np.uint64) * np.uint64(0x85EBCA77) +
@@ -447,17 +463,14 @@ def terrain(n=708, extent=100.0, height=6.0, seed=0x5EED, width=1920, height_px=
     # smooth normals
     p0, p1, p2 = verts[idx[:, 0]], verts[idx[:, 1]], verts[idx[:, 2]]
     fn = np.cross(p1 - p0, p2 - p0)
-    vn = np.zeros_like(verts, dtype=np.float64)
-    for k in range(3):
-        np.add.at(vn, idx[:, k], fn)
-    vn = (vn / np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    vn = _accumulate_vertex_normals(len(verts), idx, fn)
     cellx = (np.arange(2 * n * n) // 2) % n
     cellz = (np.arange(2 * n * n) // 2) // n
     mats = np.where(((cellx // max(1, n // 12)) + (cellz // max(1, n // 12))) % 5 == 0, glossy, ground).astype(np.uint32)
     mesh = s.add_mesh(verts, idx, normals=vn, material=mats)
     s.add_instance(mesh)
     if lights:
-        em = s.add_material(color=(30.0, 26.0, 20.0), roughness=1.0)
+        em = s.add_material(color=(12.0, 10.4, 8.0), roughness=1.0)
         qs = []
         for (px, pz) in ((-0.25, -0.2), (0.22, 0.05), (-0.05, 0.3), (0.3, -0.3)):
             qs.append(quad((0.0, -1.0, 0.0), (px * extent, height * 2.2, pz * extent), extent * 0.04, extent * 0.04))
@@ -465,11 +478,11 @@ def terrain(n=708, extent=100.0, height=6.0, seed=0x5EED, width=1920, height_px=
         qm = s.add_mesh(qv, None, material=em)
         s.add_instance(qm)
         s.update_area_lights()
-        s.add_point_light((0.0, height * 3.0, 0.0), (400.0, 380.0, 350.0))
-        s.add_point_light((extent * 0.3, height * 2.0, extent * 0.25), (150.0, 200.0, 260.0))
+        s.add_point_light((0.0, height * 3.0, 0.0), (60.0, 57.0, 52.0))
+        s.add_point_light((extent * 0.3, height * 2.0, extent * 0.25), (25.0, 33.0, 43.0))
     s.set_gradient_sky(2048, 1024)
     cam = Camera(aperture=0.0, FOV=40.0, focalDistance=5.0)
-    cam.look_at((0.0, height * 4.5, -extent * 0.62), (0.0, -height * 0.5, 0.0))
+    cam.look_at((0.0, height * 3.0, -extent * 0.62), (0.0, height * 0.6, 0.0))
     cam.resize(width, height_px)
     s.camera = cam
     return s
@@ -604,8 +617,5 @@ def skinned_tube_pose(frame, rings=160, seg=96):
             ci += [(a, a + seg, b), (b, a + seg, b + seg)]
     idx = np.asarray(ci, np.uint32)
     fn = np.cross(pos[idx[:, 1]] - pos[idx[:, 0]], pos[idx[:, 2]] - pos[idx[:, 0]])
-    vn = np.zeros_like(pos, dtype=np.float64)
-    for k in range(3):
-        np.add.at(vn, idx[:, k], fn)
-    vn = (vn / np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    vn = _accumulate_vertex_normals(len(pos), idx, fn)
     return pos, idx, vn
