@@ -29,6 +29,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy peak)
 
 
+def usable_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +196,7 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from __graft_entry__ import load_oracle
         orc = load_oracle()
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         ref = orc.OracleContext(pkg)
         ref.init(W, H)
         t0 = time.time()

@@ -63,6 +63,13 @@ class CoreBinding:
         for name, (res, args) in sig.items():
             f = self._fn(name)
             f.restype, f.argtypes = res, args
+        # device-side presents: only the rendercore (and its emulation build) export these
+        for name, (res, args) in {"read_framebuffer_device": (i32, [vp, vp]),
+                                  "read_local_framebuffer_device": (i32, [vp, vp]),
+                                  "deinterleave_device": (i32, [vp, vp, vp])}.items():
+            if self._has(name):
+                f = self._fn(name)
+                f.restype, f.argtypes = res, args
 
     def _check(self, code):
         if code != 0:
@@ -185,6 +192,18 @@ class CoreBinding:
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self._fn("read_framebuffer")(self._ctx, out.ctypes.data))
         return out
+
+    def read_framebuffer_device(self, device_ptr):
+        self._check(self._fn("read_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
+
+    def read_local_framebuffer_device(self, device_ptr):
+        """This rank's strips (local_rows() x width float4) into caller-owned device memory (a torch tensor's
+        data_ptr())."""
+        self._check(self._fn("read_local_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
+
+    def deinterleave_device(self, gathered_ptr, out_ptr):
+        """Root side of the multi-GPU gather: [world][local_rows][width] float4 -> [height][width] float4."""
+        self._check(self._fn("deinterleave_device")(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr)))
 
     def local_rows(self):
         return int(self._fn("local_rows")(self._ctx))

@@ -30,9 +30,6 @@ class RenderContext(CoreBinding):
         super().__init__(load_library(), "rfwhip_", device, rank, world)
         vp, u32, i32, fp = C.c_void_p, C.c_uint32, C.c_int, C.c_float
         for name, res, args in [
-            ("read_framebuffer_device", i32, [vp, vp]),
-            ("read_local_framebuffer_device", i32, [vp, vp]),
-            ("deinterleave_device", i32, [vp, vp, vp]),
             ("get_counters", i32, [vp, C.POINTER(abi.Counters), i32]),
             ("get_kernel_time", i32, [vp, i32, C.POINTER(fp), C.POINTER(u32), i32]),
             ("get_setting", i32, [vp, C.c_char_p, C.c_char_p, C.c_size_t]),
@@ -41,16 +38,6 @@ class RenderContext(CoreBinding):
         ]:
             f = self._fn(name)
             f.restype, f.argtypes = res, args
-
-    # ---- device-side presents (torch tensors hand over data_ptr()) ---------------------------------------------------
-    def read_framebuffer_device(self, device_ptr):
-        self._check(self._fn("read_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
-
-    def read_local_framebuffer_device(self, device_ptr):
-        self._check(self._fn("read_local_framebuffer_device")(self._ctx, C.c_void_p(device_ptr)))
-
-    def deinterleave_device(self, gathered_ptr, out_ptr):
-        self._check(self._fn("deinterleave_device")(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr)))
 
     # ---- measurement hooks -------------------------------------------------------------------------------------------
     def get_counters(self, reset=False):

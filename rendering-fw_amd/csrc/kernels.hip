@@ -215,6 +215,10 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	out.emit_shadow = false, out.emit_ext = false;
 	uint32_t slot = 0;
 	bool write_rad = false;
+	// the primary wave has one entry per path slot, including the padding slots of partial tiles / strips whose
+	// records were never written: validity comes from the slot index, not from the buffers
+	if (p.depth == 0 && active)
+		active = slot_to_pixel(p.fr, i).valid;
 	if (active)
 	{
 		const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
@@ -233,9 +237,6 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 			in.T = xyz(t4), in.bsdfPdf = t4.w;
 		}
 		const PixelRef pr = slot_to_pixel(p.fr, in.slot);
-		if (p.depth == 0 && !pr.valid)
-			active = false;
-		else
 		{
 			in.pixel = pr.y * p.fr.W + pr.x;
 			in.sampleIdx = p.fr.sample_base + pr.sample;

@@ -1,0 +1,165 @@
+"""CPU tier of the parity tests: the product sources in their host-emulation build (tests/emu/build_emu.py — same
+C ABI, same host logic, same per-ray arithmetic, loops instead of kernel launches) against the oracle.
+The GPU tier (test_parity_gpu.py) repeats the important ones on the real kernels."""
+import numpy as np
+import pytest
+
+from conftest import image_stats
+
+
+def _run(pkg, ctxs, scene, w, h, settings, frames=1):
+    for ctx in ctxs:
+        ctx.init(w, h)
+        scene.upload(ctx)
+        for k, v in settings.items():
+            ctx.set_setting(k, v)
+        for f in range(frames):
+            ctx.render_frame(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+    return [c.framebuffer() for c in ctxs]
+
+
+def test_cornell_parity_xor128_multi_frame(pkg, make_emu, make_oracle):
+    """The xor128 stream persists across frames (EmbreeRT's m_Rng is never reseeded); 3 batches of 2 samples on the
+    core == 6 single frames on the oracle."""
+    scene = pkg.scenes.cornell(128, 96)
+    e, o = make_emu(), make_oracle()
+    a = _run(pkg, [e], scene, 128, 96, {"integrator": "parity", "spp": 2}, frames=3)[0]
+    b = _run(pkg, [o], scene, 128, 96, {"integrator": "parity", "spp": 1}, frames=6)[0]
+    frac, rmse, _ = image_stats(a, b, 1e-3)
+    assert frac <= 1e-3 and rmse <= 5e-4, (frac, rmse)
+    assert e.get_probe_results()[:2] == o.get_probe_results()[:2]
+
+
+def test_unrendered_remainder_pixels(pkg, make_emu, make_oracle):
+    """EmbreeRT renders whole 4x2 packets only (Context.cpp:137-139): columns beyond W//4*4 and rows beyond H//2*2
+    keep their initial zeros."""
+    scene = pkg.scenes.cornell(70, 51)
+    a, b = _run(pkg, [make_emu(), make_oracle()], scene, 70, 51, {"integrator": "parity", "jitter": "center"})
+    for img in (a, b):
+        assert np.all(img[:, 68:] == 0) and np.all(img[50:, :] == 0)
+        assert img[:50, :68, :3].max() > 0
+    frac, rmse, _ = image_stats(a, b, 1e-3)
+    assert frac <= 1e-3
+
+
+def test_cornell_path_tracer(pkg, make_emu, make_oracle):
+    scene = pkg.scenes.cornell(96, 64, geometric_emitter=True)
+    a, b = _run(pkg, [make_emu(), make_oracle()], scene, 96, 64, {"integrator": "pt", "spp": 8})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 1e-2 and rmse <= 3e-2, (frac, rmse)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_path_tracer_depths_and_wave_counts(pkg, make_emu, make_oracle, depth):
+    scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
+    e, o = make_emu(), make_oracle()
+    a, b = _run(pkg, [e, o], scene, 64, 48, {"integrator": "pt", "spp": 4, "max_depth": depth, "count_traversal": 1})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 2e-2, (frac, rmse)
+    st = e.get_stats()
+    oc = o.get_counters()
+    # ray counts of the compacted waves equal the oracle's per-path counts (same discrete decisions)
+    total_ext = st.primaryCount + st.secondaryCount + st.deepCount
+    assert abs(total_ext - oc["rays_extend"]) <= 0.002 * oc["rays_extend"]
+    assert abs(st.shadowCount - oc["rays_shadow"]) <= 0.002 * max(1, oc["rays_shadow"])
+    if depth == 0:
+        assert st.secondaryCount == 0 and st.deepCount == 0
+
+
+def test_spot_and_directional_lights_in_the_path_tracer(pkg, make_emu, make_oracle):
+    scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
+    scene.add_spot_light((0.0, 9.0, 0.0), 20.0, (80.0, 80.0, 70.0), 35.0, (0.1, -1.0, 0.2))
+    scene.add_directional_light((0.3, -1.0, 0.6), (1.5, 1.4, 1.2))
+    a, b = _run(pkg, [make_emu(), make_oracle()], scene, 64, 48, {"integrator": "pt", "spp": 8})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 2e-2, (frac, rmse)
+
+
+def test_textured_materials_both_integrators(pkg, make_emu, make_oracle):
+    """UINT (RGBA8 + 5 mips) and FLOAT4 diffuse maps: nearest/level-0 with the (w-1) scaling and the switch
+    fall-through in the parity integrator (Context.cpp:439-473), trilinear in the path tracer
+    (getShadingData.h:61-98)."""
+    sc = pkg.scenes
+    s = sc.Scene()
+    rng = np.random.default_rng(11)
+    tex_u = s.add_texture(sc.make_texture_rgba8(rng.integers(0, 256, (32, 32, 4), dtype=np.uint8)))
+    tex_f = s.add_texture(sc.make_texture_float4(rng.uniform(0.2, 1.0, (16, 16, 4)).astype(np.float32)))
+    m0 = s.add_material(color=(0.9, 0.8, 0.7), roughness=0.8, texture=tex_u, uvscale=(2.0, 3.0), uvoffset=(0.25, -0.5))
+    m1 = s.add_material(color=(0.6, 0.9, 0.6), roughness=0.5, texture=tex_f)
+    v = np.array([[-4, 0, -4], [4, 0, -4], [4, 0, 4], [-4, 0, 4], [-4, 5, 4], [4, 5, 4]], np.float32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0, 2], [1, 2]], np.float32)
+    idx = np.array([[0, 2, 1], [0, 3, 2], [3, 4, 5], [3, 5, 2]], np.uint32)
+    s.add_instance(s.add_mesh(v, idx, uvs=uv, material=np.array([m0, m0, m1, m1], np.uint32)))
+    s.add_point_light((0.0, 4.0, -1.0), (30.0, 30.0, 30.0))
+    s.add_area_light_quad((0.0, -1.0, 0.0), (0.0, 8.0, 0.0), 2.0, 2.0, (10.0, 10.0, 10.0))
+    s.set_test_sky(64, 32)
+    cam = pkg.Camera(aperture=0.0)
+    cam.look_at((0.3, 3.0, -9.0), (0.0, 1.5, 0.0))
+    cam.resize(96, 64)
+    s.camera = cam
+    a, b = _run(pkg, [make_emu(), make_oracle()], s, 96, 64, {"integrator": "parity", "jitter": "center"})
+    frac, rmse, _ = image_stats(a, b, 1e-3)
+    assert frac <= 2e-3, (frac, rmse)
+    a, b = _run(pkg, [make_emu(), make_oracle()], s, 96, 64, {"integrator": "pt", "spp": 4})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 2e-2, (frac, rmse)
+
+
+def test_instancing_with_scale_rotation(pkg, make_emu, make_oracle):
+    """Non-uniformly scaled, rotated instances of one mesh: ray transform by M^-1 without renormalisation keeps t
+    (top_level_bvh.cpp:104-168); normals go through the supplied inverse-transpose."""
+    scene = pkg.scenes.cornell(96, 64)
+    e, o = make_emu(), make_oracle()
+    _run(pkg, [e, o], scene, 96, 64, {"integrator": "parity", "jitter": "center"})
+    a, b = e.primary_hits(), o.primary_hits()
+    assert (a["inst"] != b["inst"]).sum() == 0 and (a["prim"] != b["prim"]).sum() == 0
+    assert {1, 2} <= set(np.unique(a["inst"]))
+    m = a["prim"] >= 0
+    assert np.abs(a["t"] - b["t"])[m].max() < 1e-4
+
+
+def test_aperture_lens_sampling(pkg, make_emu, make_oracle):
+    scene = pkg.scenes.cornell(64, 48)
+    scene.camera.aperture = 0.05
+    a, b = _run(pkg, [make_emu(), make_oracle()], scene, 64, 48, {"integrator": "parity", "spp": 2})
+    frac, rmse, _ = image_stats(a, b, 1e-3)
+    assert frac <= 5e-3, (frac, rmse)
+
+
+def test_empty_scene_and_sky_only(pkg, make_emu, make_oracle):
+    s = pkg.scenes.Scene()
+    s.add_material(color=(1, 1, 1))
+    s.set_test_sky(64, 32)
+    cam = pkg.Camera(aperture=0.0)
+    cam.look_at((0, 0, 0), (0.2, 0.1, 1.0))
+    cam.resize(32, 16)
+    s.camera = cam
+    for integ in ("parity", "pt"):
+        a, b = _run(pkg, [make_emu(), make_oracle()], s, 32, 16, {"integrator": integ, "jitter": "center"})
+        assert np.isfinite(a).all()
+        frac, rmse, _ = image_stats(a, b, 1e-4)
+        assert frac == 0.0
+
+
+def test_settings_and_errors(pkg, make_emu):
+    e = make_emu()
+    with pytest.raises(RuntimeError):
+        e.render_frame(pkg.Camera(), pkg.RESET)          # no render target
+    with pytest.raises(RuntimeError):
+        e.set_setting("integrator", "bogus")
+    with pytest.raises(RuntimeError):
+        e.set_setting("nope", "1")
+    scene = pkg.scenes.cornell(32, 32)
+    e.init(32, 32)
+    scene.upload(e)
+    e.set_instance(0, 0, np.eye(4))                       # scene changed, update() missing
+    with pytest.raises(RuntimeError):
+        e.render_frame(scene.camera, pkg.RESET)
+    e.update()
+    e.render_frame(scene.camera, pkg.RESET)
+    with pytest.raises(RuntimeError):
+        e.set_instance(5, 99, np.eye(4))                   # unknown mesh
+    e.cleanup()
+    e.cleanup()                                            # idempotent
+    with pytest.raises(RuntimeError):
+        e.update()
