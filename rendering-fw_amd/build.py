@@ -55,6 +55,14 @@ def build(force=False, verbose=False):
                   "-I" + os.path.join(CSRC, "plugin"), plugin_src, "-o", plugin, "-L" + HERE, "-lrfwhip",
                   "-Wl,-rpath,$ORIGIN"], verbose)
         outs.append(plugin)
+        # stand-in for rfw::system's side of the boundary (tests/plugin/plugin_host.cpp), used by the gpu tests
+        host_src = os.path.join(os.path.dirname(HERE), "tests", "plugin", "plugin_host.cpp")
+        if os.path.exists(host_src):
+            host = os.path.join(os.path.dirname(HERE), "tests", "plugin", "plugin_host")
+            if force or _stale(host, deps + [host_src]):
+                _run(["g++", "-O1", "-std=c++17", "-I" + INCLUDE, "-I" + os.path.join(CSRC, "plugin"), host_src, "-o", host,
+                      "-ldl"], verbose)
+            outs.append(host)
     return outs
 
 
