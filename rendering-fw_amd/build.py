@@ -11,7 +11,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 CORE_SOURCES = ["rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + INCLUDE, "-I" + CSRC,
-          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+          "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("RFWHIP_EXTRA_FLAGS", "").split()
 
 
 def _stale(out, deps):

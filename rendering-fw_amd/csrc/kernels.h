@@ -15,6 +15,8 @@ struct Params
 	uint32_t max_depth; // MAX_PATH_LENGTH
 	uint32_t parity_no_jitter;
 	uint32_t lds_pairs; // number of top-of-tree node pairs staged in LDS (0 = off)
+	uint32_t queue;		// which WaveCounters::work[] row this launch pulls its chunks from
+	uint32_t group;		// chunks per XCD group (one row of tiles for the primary wave)
 };
 
 enum GenMode

@@ -31,6 +31,13 @@ namespace rtk
 {
 
 constexpr int BLOCK = 256;
+// minimum waves per SIMD the register allocator must leave room for in the traversal kernels (tuned on MI355X)
+#ifndef RT_TRAVERSAL_WAVES
+#define RT_TRAVERSAL_WAVES 4
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
 
 // ================================================================================================================
 // per-thread context: traversal stack + compaction + statistics.  Device and host-emulation flavours.
@@ -72,11 +79,7 @@ struct Ctx
 {
 	TravStack stk;
 	uint32_t lds[LDS_STACK];
-	Ctx()
-	{
-		stk.lds = lds;
-		stk.stride = 1;
-	}
+	Ctx() { stk.lds = lds; }
 	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
 	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
 };
@@ -312,6 +315,9 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
 {
 	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
 		c->ext[d] = 0u, c->shadow[d] = 0u;
+	for (int q = 0; q < WORK_QUEUES; q++)
+		for (int x = 0; x < 8; x++)
+			c->work[q][x] = 0u;
 	c->ext[0] = primary_count;
 	c->probe_valid = 0u;
 }
@@ -411,10 +417,11 @@ RT_FN void refit_tris_item(f4 *tri_verts, const f4 *verts, const uint32_t *indic
 RT_FN void leaf_bounds(const Node &n, const f4 *tri_verts, float mn[3], float mx[3])
 {
 	mn[0] = mn[1] = mn[2] = 1e34f, mx[0] = mx[1] = mx[2] = -1e34f;
+	const uint32_t first = (uint32_t)n.left_first & ENTRY_FIRST_MASK; // device nodes carry packed entries
 	for (int k = 0; k < n.count; k++)
 		for (int v = 0; v < 3; v++)
 		{
-			const f4 q = tri_verts[3ull * (uint32_t)(n.left_first + k) + v];
+			const f4 q = tri_verts[3ull * (first + (uint32_t)k) + v];
 			mn[0] = fminf(mn[0], q.x), mn[1] = fminf(mn[1], q.y), mn[2] = fminf(mn[2], q.z);
 			mx[0] = fmaxf(mx[0], q.x), mx[1] = fmaxf(mx[1], q.y), mx[2] = fmaxf(mx[2], q.z);
 		}
@@ -430,41 +437,52 @@ RT_FN void leaf_bounds(const Node &n, const f4 *tri_verts, float mn[3], float mx
 static int g_cus = 256;
 void set_device_cus(int cus) { g_cus = cus > 0 ? cus : 256; }
 
-// XCD-aware chunk walk of a persistent grid: iteration k of block b handles chunk  xcd*cpx + k*bpx + j,
-// with xcd = b % 8, j = b / 8, bpx = gridDim/8 blocks per XCD, cpx = ceil(nchunks/8) chunks per XCD.
-struct ChunkWalk
+// XCD-aware dynamic chunk queue of a persistent grid.  Chunk = 256 consecutive items.  Chunks are dealt to the 8
+// XCDs in groups of `group` consecutive chunks (for the primary wave: one row of 8x8 tiles), so each XCD owns every
+// 8th tile row — balanced whatever the image content — and the workgroups of one XCD (workgroup b runs on XCD b % 8)
+// pull consecutive chunks of that XCD's sequence from one device-scope counter: at any time they work on
+// neighbouring tiles whose BVH nodes and triangles meet in that XCD's 4 MiB L2.  The mapping only affects speed.
+struct ChunkQueue
 {
-	uint32_t xcd, j, bpx, cpx, nchunks;
-	__device__ __forceinline__ ChunkWalk(uint32_t count)
+	uint32_t xcd, nchunks, group;
+	uint32_t *head;
+	__device__ __forceinline__ ChunkQueue(const Params &p, uint32_t count)
 	{
 		nchunks = (count + BLOCK - 1) / BLOCK;
-		xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-		cpx = (nchunks + 7u) >> 3;
+		xcd = blockIdx.x & 7u;
+		group = p.group ? p.group : 16u;
+		head = &p.wv.counters->work[p.queue][xcd];
 	}
-	__device__ __forceinline__ bool chunk(uint32_t k, uint32_t &c) const
+	// workgroup-uniform; false when this XCD's share is exhausted
+	__device__ __forceinline__ bool next(uint32_t &c)
 	{
-		const uint32_t q = k * bpx + j;
-		if (q >= cpx)
-			return false;
-		c = xcd * cpx + q;
-		return true;
+		__shared__ uint32_t s_q;
+		__syncthreads();
+		if (threadIdx.x == 0)
+			s_q = atomicAdd(head, 1u);
+		__syncthreads();
+		const uint32_t q = s_q;
+		const uint32_t g = q / group, w = q - g * group;
+		const uint32_t base = (g * 8u + xcd) * group;
+		c = base + w;
+		return base < nchunks;
 	}
 };
 
+static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of the workgroup]");
 #define RT_STACK_DECL                                        \
 	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];          \
 	Ctx ctx;                                                 \
-	ctx.stk.lds = s_stack + threadIdx.x;                     \
-	ctx.stk.stride = BLOCK;
+	ctx.stk.lds = s_stack + threadIdx.x;
 
 template <int GEN, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_extend(const Params p, const uint32_t fixed_count)
+__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
 	RT_STACK_DECL
 	const uint32_t count = GEN == GEN_BUFFER ? p.wv.counters->ext[p.depth] : fixed_count;
-	const ChunkWalk w(count);
+	ChunkQueue w(p, count);
 	uint32_t c;
-	for (uint32_t k = 0; w.chunk(k, c); k++)
+	while (w.next(c))
 	{
 		const uint32_t i = c * BLOCK + threadIdx.x;
 		if (c < w.nchunks)
@@ -473,12 +491,12 @@ __global__ void __launch_bounds__(BLOCK) k_extend(const Params p, const uint32_t
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_shade_parity(const Params p, const uint32_t count)
+__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(const Params p, const uint32_t count)
 {
 	RT_STACK_DECL
-	const ChunkWalk w(count);
+	ChunkQueue w(p, count);
 	uint32_t c;
-	for (uint32_t k = 0; w.chunk(k, c); k++)
+	while (w.next(c))
 	{
 		const uint32_t i = c * BLOCK + threadIdx.x;
 		if (c < w.nchunks)
@@ -486,10 +504,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade_parity(const Params p, const ui
 	}
 }
 
-__global__ void __launch_bounds__(BLOCK) k_shade_pt(const Params p)
+__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params p)
 {
 	Ctx ctx;
-	ctx.stk.lds = nullptr, ctx.stk.stride = 0;
+	ctx.stk.lds = nullptr;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
@@ -500,15 +518,17 @@ __global__ void __launch_bounds__(BLOCK) k_shade_pt(const Params p)
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_connect(const Params p)
+__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_connect(const Params p)
 {
 	RT_STACK_DECL
 	const uint32_t count = p.wv.counters->shadow[p.depth];
-	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
-	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+	ChunkQueue w(p, count);
+	uint32_t c;
+	while (w.next(c))
 	{
 		const uint32_t i = c * BLOCK + threadIdx.x;
-		connect_item<COUNT>(p, i, i < count, ctx);
+		if (c < w.nchunks)
+			connect_item<COUNT>(p, i, i < count, ctx);
 	}
 }
 
@@ -582,7 +602,7 @@ __global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *nodes, const int *p
 		if (atomicAdd(&flags[parent], 1u) == 0u)
 			break;		 // first arrival: the sibling will continue
 		__threadfence(); // acquire the sibling's box
-		const int l = nodes[parent].left_first;
+		const int l = (int)((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK);
 		for (int a = 0; a < 3; a++)
 		{
 			const float lo0 = __hip_atomic_load(&nodes[l].bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -789,7 +809,7 @@ void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_
 				break;
 			if (flags[parent]++ == 0u)
 				break;
-			const int l = nodes[parent].left_first;
+			const int l = (int)((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK);
 			for (int a = 0; a < 3; a++)
 			{
 				nodes[parent].bmin[a] = fminf(nodes[l].bmin[a], nodes[l + 1].bmin[a]);

@@ -824,6 +824,13 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			if (!m.used)
 				continue;
 			memcpy(&all_nodes[m.node_base], m.bvh.nodes.data(), m.bvh.nodes.size() * sizeof(rt::Node));
+			// device form: left_first carries the ready-made stack entry (rt::make_entry), count is kept
+			for (size_t k = 0; k < m.bvh.nodes.size(); k++)
+			{
+				rt::Node &nd = all_nodes[m.node_base + k];
+				if (nd.count != 0)
+					nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, false);
+			}
 			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
 			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
 		}
@@ -898,6 +905,10 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		tprims[k] = live[tl.order[k]];
 	if (tl.nodes.empty())
 		tl.nodes.resize(2);
+	const int tl_root_left = tl.nodes[0].left_first, tl_root_count = tl.nodes[0].count;
+	for (rt::Node &nd : tl.nodes)
+		if (nd.count != 0)
+			nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, true);
 	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
 	RF_TRY(c->d_tlas_nodes.ensure(tl.nodes.size() * sizeof(rt::Node)));
 	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
@@ -906,7 +917,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
-	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true);
+	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl_root_left, tl_root_count, true);
 
 	rt::SceneView &sv = c->sv;
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
@@ -1084,6 +1095,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const bool count = c->count_traversal != 0;
 	const uint32_t n = (uint32_t)paths;
 	rtk::launch_init_counters(p.wv.counters, n, s);
+	uint32_t queue = 0;						   // every traversal launch pulls from its own chunk queue
+	const uint32_t row_group = std::max(1u, c->fr.tiles_x / 4u); // primary wave: one row of 8x8 tiles per XCD group
 	if (c->integrator == 0)
 	{
 		if (c->jitter == 0)
@@ -1106,9 +1119,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			xor128_jump(c->jump_table, c->rng_state, (unsigned long long)packets * 32ull * (unsigned long long)c->spp);
 		}
 		p.depth = 0;
+		p.group = row_group;
+		p.queue = queue++;
 		StageTimer te(c, KF_EXTEND, 0);
 		rtk::launch_extend(p, rtk::GEN_PARITY, count, n, s);
 		te.stop();
+		p.queue = queue++;
 		StageTimer ts(c, KF_SHADE, -1);
 		rtk::launch_shade_parity(p, count, n, s);
 		ts.stop();
@@ -1118,6 +1134,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		for (int d = 0; d <= c->max_depth; d++)
 		{
 			p.depth = (uint32_t)d;
+			p.group = d == 0 ? row_group : 16u;
+			p.queue = queue++;
 			StageTimer te(c, KF_EXTEND, d);
 			rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
 			te.stop();
@@ -1126,6 +1144,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			ts.stop();
 			if (total_light_count(c))
 			{
+				p.group = 16u;
+				p.queue = queue++;
 				StageTimer tc(c, KF_CONNECT, -1);
 				rtk::launch_connect(p, count, n, s);
 				tc.stop();
@@ -1487,6 +1507,8 @@ extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_n
 		{
 			RF_TRY(dm::sync(c->stream));
 			RF_TRY(dm::d2h(nodes, c->d_nodes.as<rt::Node>() + m.node_base, n * sizeof(rt::Node), c->stream));
+			for (size_t k = 0; k < n; k++) // device nodes carry packed entries: hand out the reference layout
+				nodes[k].left_first = m.bvh.nodes[k].left_first;
 		}
 		else
 			memcpy(nodes, m.bvh.nodes.data(), n * sizeof(rt::Node));

@@ -238,42 +238,38 @@ struct TStat
 
 constexpr int LDS_STACK = 24;	// entries per lane kept in LDS
 constexpr int SPILL_STACK = 40; // further entries in private memory (touched only by pathological rays)
+#if defined(RT_DEVICE_BUILD)
+constexpr int STACK_STRIDE = 256; // = workgroup size: stack[entry][thread], bank = thread % 32, conflict-free
+#else
+constexpr int STACK_STRIDE = 1;
+#endif
+constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 
 struct TravStack
 {
-	uint32_t *lds; // lane's column of the workgroup's LDS stack
-	int stride;	   // distance between consecutive entries of one lane (= workgroup size)
-	uint32_t spill[SPILL_STACK];
+	uint32_t *lds; // this lane's column of the workgroup's LDS stack
 };
-RT_FN void stack_push(TravStack &s, int &sp, uint32_t e)
+
+RT_FN float fast_rcp(float x)
 {
-	if (sp < LDS_STACK)
-		s.lds[sp * s.stride] = e;
-	else if (sp < LDS_STACK + SPILL_STACK)
-		s.spill[sp - LDS_STACK] = e;
-	sp++;
-}
-RT_FN uint32_t stack_pop(TravStack &s, int &sp)
-{
-	sp--;
-	if (sp < LDS_STACK)
-		return s.lds[sp * s.stride];
-	if (sp < LDS_STACK + SPILL_STACK)
-		return s.spill[sp - LDS_STACK];
-	return ENTRY_SENTINEL; // unreachable: the builders bound the depth (bvh_build.cpp)
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+#else
+	return 1.0f / x;
+#endif
 }
 
-RT_FN bool slab(const f4 &a, const f4 &b, f3 o, f3 id, float t, float &tnear)
+// Slab test (aabb.cpp:39-77) in fma form: t = b * (1/d) - o * (1/d).  a = bmin.xyz, bmax.x ; b = bmax.y, bmax.z, ...
+// The reference accepts tmax > tmin && tmin < t; boxes entirely behind the origin (tmax < 0) cannot contain an
+// accepted hit (t > t_min >= 0) and are culled as well.
+RT_FN bool slab(const f4 &a, const f4 &b, f3 id, f3 oid, float t, float &tnear)
 {
-	// a = bmin.xyz, bmax.x ; b = bmax.y, bmax.z, left_first, count          (aabb.cpp:39-77)
-	const float tx1 = (a.x - o.x) * id.x, tx2 = (a.w - o.x) * id.x;
-	const float ty1 = (a.y - o.y) * id.y, ty2 = (b.x - o.y) * id.y;
-	const float tz1 = (a.z - o.z) * id.z, tz2 = (b.y - o.z) * id.z;
-	const float tmin = fmaxf(fminf(tx1, tx2), fmaxf(fminf(ty1, ty2), fminf(tz1, tz2)));
-	const float tmax = fminf(fmaxf(tx1, tx2), fminf(fmaxf(ty1, ty2), fmaxf(tz1, tz2)));
+	const float tx1 = fmaf(a.x, id.x, -oid.x), tx2 = fmaf(a.w, id.x, -oid.x);
+	const float ty1 = fmaf(a.y, id.y, -oid.y), ty2 = fmaf(b.x, id.y, -oid.y);
+	const float tz1 = fmaf(a.z, id.z, -oid.z), tz2 = fmaf(b.y, id.z, -oid.z);
+	const float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+	const float tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
 	tnear = tmin;
-	// the reference accepts tmax > tmin && tmin < t; boxes entirely behind the origin (tmax < 0) cannot contain an
-	// accepted hit (t > t_min >= 0) and are culled here as well
 	return tmax > tmin && tmin < t && tmax >= 0.0f;
 }
 
@@ -285,7 +281,7 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 	const float a = dot(e1, h);
 	if (a > -1e-6f && a < 1e-6f)
 		return false;
-	const float f = 1.f / a;
+	const float f = fast_rcp(a);
 	const f3 s = o - p0;
 	const float u = f * dot(s, h);
 	if (u < 0.0f || u > 1.0f)
@@ -303,103 +299,125 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 	return false;
 }
 
-// Two-level traversal in one loop.  Stack entries: inner node = index of its left child (children are adjacent),
-// leaf = first/count packed, ENTRY_TLAS marks top-level entries, ENTRY_SENTINEL marks "leave the instance".
+// Two-level traversal, "while-while" form for wave64: every lane first descends through inner nodes until it holds
+// a leaf (lanes that already found one wait), then the wave processes leaves together.  With incoherent rays an
+// if-inner/if-leaf loop would execute the triangle code in nearly every iteration for a handful of lanes.
+//
+// Node::left_first holds the ready-made stack entry of the node on the device (see make_entry): inner node = index
+// of its left child (children are adjacent), leaf = first/count packed, ENTRY_TLAS marks top-level entries,
+// ENTRY_SENTINEL on the stack marks "leave the instance".
 // ANY = true: occlusion query, returns on the first accepted hit in (t_min, t_max).
 template <bool ANY, bool COUNT>
-RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit &hit, TravStack &stk, TStat &st)
+RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit &hit, const TravStack stk, TStat &st)
 {
 	hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
 	if (sc.instance_count == 0)
 		return false;
+	uint32_t spill[SPILL_STACK];
+	uint32_t *const lds = stk.lds;
 	f3 o = O, d = D;
 	f3 id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+	f3 oid = o * id;
 	const Node *nodes = sc.tlas_nodes;
 	uint32_t tri_base = 0;
 	int cur_inst = -1;
 	int sp = 0;
 	uint32_t cur = sc.tlas_root_entry;
+
+	auto push = [&](uint32_t e) {
+		if (sp < LDS_STACK)
+			lds[sp * STACK_STRIDE] = e;
+		else if (sp < LDS_STACK + SPILL_STACK)
+			spill[sp - LDS_STACK] = e;
+		sp++;
+	};
+	auto pop_next = [&]() -> uint32_t {
+		for (;;)
+		{
+			if (sp == 0)
+				return ENTRY_DONE;
+			sp--;
+			uint32_t e;
+			if (sp < LDS_STACK)
+				e = lds[sp * STACK_STRIDE];
+			else if (sp < LDS_STACK + SPILL_STACK)
+				e = spill[sp - LDS_STACK];
+			else
+				e = ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
+			if (e != ENTRY_SENTINEL)
+				return e;
+			// leaving an instance: back to the world-space ray and the top-level nodes
+			o = O, d = D;
+			id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+			oid = o * id;
+			nodes = sc.tlas_nodes;
+			cur_inst = -1;
+		}
+	};
+
 	for (;;)
 	{
-		bool need_pop = true;
-		if (!(cur & ENTRY_LEAF))
+		while (!(cur & ENTRY_LEAF))
 		{
 			const f4 *p = (const f4 *)(nodes + (cur & ENTRY_INDEX_MASK));
 			const f4 a0 = p[0], b0 = p[1], a1 = p[2], b1 = p[3];
 			if (COUNT)
 				st.inner++;
 			float n0, n1;
-			const bool h0 = slab(a0, b0, o, id, hit.t, n0);
-			const bool h1 = slab(a1, b1, o, id, hit.t, n1);
-			const uint32_t tl = cur & ENTRY_TLAS;
-			const uint32_t e0 = make_entry((int)fbits(b0.z), (int)fbits(b0.w), tl != 0);
-			const uint32_t e1 = make_entry((int)fbits(b1.z), (int)fbits(b1.w), tl != 0);
+			const bool h0 = slab(a0, b0, id, oid, hit.t, n0);
+			const bool h1 = slab(a1, b1, id, oid, hit.t, n1);
+			const uint32_t e0 = fbits(b0.z), e1 = fbits(b1.z);
 			if (h0 && h1)
 			{
 				const bool first0 = n0 < n1;
-				stack_push(stk, sp, first0 ? e1 : e0);
+				push(first0 ? e1 : e0);
 				cur = first0 ? e0 : e1;
-				need_pop = false;
 			}
 			else if (h0 || h1)
-			{
 				cur = h0 ? e0 : e1;
-				need_pop = false;
-			}
+			else
+				cur = pop_next();
 		}
-		else if (cur & ENTRY_TLAS)
+		if (cur == ENTRY_DONE)
+			break;
+		if (cur & ENTRY_TLAS)
 		{
 			// top-level leaf: exactly one instance (the TLAS builder never merges)
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
 			const Instance &in = sc.instances[ii];
-			stack_push(stk, sp, ENTRY_SENTINEL);
+			push(ENTRY_SENTINEL);
 			o = mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
 					in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
 					in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]);
 			d = mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z, in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
 					in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z);
 			id = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+			oid = o * id;
 			nodes = sc.nodes + in.node_base;
 			tri_base = in.tri_base;
 			cur_inst = (int)ii;
 			cur = in.root_entry;
-			need_pop = false;
+			continue;
 		}
-		else
+		const uint32_t first = tri_base + (cur & ENTRY_FIRST_MASK);
+		const uint32_t count = ((cur >> 27) & 7u) + 1u;
+		for (uint32_t i = 0; i < count; i++)
 		{
-			const uint32_t first = tri_base + (cur & ENTRY_FIRST_MASK);
-			const uint32_t count = ((cur >> 27) & 7u) + 1u;
-			for (uint32_t i = 0; i < count; i++)
+			const f4 *tv = sc.tri_verts + 3u * (first + i);
+			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+			if (COUNT)
+				st.tris++;
+			if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
 			{
-				const f4 *tv = sc.tri_verts + 3u * (first + i);
-				const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-				if (COUNT)
-					st.tris++;
-				if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
-				{
-					hit.prim = (int)fbits(v0.w);
-					hit.inst = cur_inst;
-					if (ANY)
-						return true;
-				}
+				hit.prim = (int)fbits(v0.w);
+				hit.inst = cur_inst;
+				if (ANY)
+					return true;
 			}
 		}
-		while (need_pop)
-		{
-			if (sp == 0)
-				return hit.prim >= 0;
-			cur = stack_pop(stk, sp);
-			if (cur == ENTRY_SENTINEL)
-			{
-				o = O, d = D;
-				id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-				nodes = sc.tlas_nodes;
-				cur_inst = -1;
-			}
-			else
-				need_pop = false;
-		}
+		cur = pop_next();
 	}
+	return hit.prim >= 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -178,10 +178,12 @@ struct FrameView
 // Device counters, zeroed per render call.  ext[d] = number of paths entering depth d (ext[0] is set by the host),
 // shadow[d] = shadow rays emitted by the shade stage of depth d.
 constexpr int MAX_DEPTH_SLOTS = 16;
+constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch of a render call
 struct WaveCounters
 {
 	uint32_t ext[MAX_DEPTH_SLOTS];
 	uint32_t shadow[MAX_DEPTH_SLOTS];
+	uint32_t work[WORK_QUEUES][8]; // per launch, per XCD: head of the chunk queue the persistent workgroups pull from
 	unsigned long long rays_extend, rays_shadow, inner_extend, tris_extend, inner_shadow, tris_shadow, shaded, samples;
 	uint32_t probe_inst, probe_prim;
 	float probe_dist;
