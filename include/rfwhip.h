@@ -139,6 +139,11 @@ RFWHIP_API int rfwhip_get_kernel_time(rfwhip_context *ctx, int which, float *ms,
 RFWHIP_API int rfwhip_read_primary_hits(rfwhip_context *ctx, float *t, int32_t *prim, int32_t *inst, float *u,
 										float *v);
 
+/* Trace n arbitrary world-space rays (org/dir: n x 3 floats, closest hit in (t_min, t_max)) through the resident
+ * scene with the extend kernel; any output pointer may be NULL.  t = t_max on a miss. */
+RFWHIP_API int rfwhip_trace_rays(rfwhip_context *ctx, size_t n, const float *org, const float *dir, float t_min,
+								 float t_max, float *t, int32_t *prim, int32_t *inst, float *u, float *v);
+
 /* BVH of mesh `index` as built on the device side (bvh_node.h layout) + its primitive order. */
 RFWHIP_API int rfwhip_get_bvh(rfwhip_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,
 							  uint32_t *prim_indices, size_t prim_cap, size_t *node_count, size_t *prim_count);

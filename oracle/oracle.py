@@ -50,7 +50,6 @@ def load():
         L.rfwo_evaluate_bsdf.restype, L.rfwo_evaluate_bsdf.argtypes = None, [fp, u32p, fp, fp, fp, fp, fp]
         L.rfwo_sample_bsdf.restype = None
         L.rfwo_sample_bsdf.argtypes = [fp, fp, u32p, fp, fp, C.c_float, C.c_int, C.c_float, C.c_float, fp, fp, fp]
-        L.rfwo_get_counters.restype, L.rfwo_get_counters.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.rfwo_read_local_framebuffer.restype, L.rfwo_read_local_framebuffer.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
     return _lib
 
@@ -68,12 +67,7 @@ def OracleContext(pkg, rank=0, world=1):
         def __init__(self):
             super().__init__(load(), "rfwo_", 0, rank, world)
 
-        def get_counters(self, reset=False):
-            out = (C.c_uint64 * 8)()
-            self._check(self._lib.rfwo_get_counters(self._ctx, out, int(reset)))
-            names = ("rays_extend", "rays_shadow", "inner_extend", "tris_extend", "inner_shadow", "tris_shadow",
-                     "shaded", "samples")
-            return dict(zip(names, [int(v) for v in out]))
+        # get_counters(): the base class reads 8 x uint64 — the oracle fills the same order (rfw_oracle.h)
 
         def local_framebuffer(self):
             out = np.empty((self.local_rows(), self.width, 4), np.float32)

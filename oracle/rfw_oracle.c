@@ -929,6 +929,33 @@ int rfwo_get_bvh(rfwo_context *c, size_t mi, rfwhip_bvh_node *nodes, size_t node
 	return 0;
 }
 
+int rfwo_trace_rays(rfwo_context *c, size_t n, const float *org, const float *dir, float t_min, float t_max, float *t,
+					int32_t *prim, int32_t *inst, float *u, float *v)
+{
+	uint64_t tinner = 0, ttris = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : tinner, ttris)
+	for (long i = 0; i < (long)n; i++)
+	{
+		float tt = t_max, uu = 0, vv = 0;
+		int ii = -1, pp = -1;
+		tstat st = {0, 0};
+		const int hit = scene_closest(c, v3p(org + 3 * i), v3p(dir + 3 * i), t_min, &tt, &ii, &pp, &uu, &vv, &st);
+		tinner += st.inner, ttris += st.tris;
+		if (t)
+			t[i] = tt;
+		if (u)
+			u[i] = uu;
+		if (v)
+			v[i] = vv;
+		if (prim)
+			prim[i] = hit ? pp : -1;
+		if (inst)
+			inst[i] = hit ? ii : -1;
+	}
+	c->cnt[0] += n, c->cnt[2] += tinner, c->cnt[3] += ttris;
+	return 0;
+}
+
 /* =============================================================================================================
  * shading helpers shared by both integrators
  * ========================================================================================================== */

@@ -57,6 +57,8 @@ int rfwo_set_setting(rfwo_context *ctx, const char *key, const char *value);
 int rfwo_read_primary_hits(rfwo_context *ctx, float *t, int32_t *prim, int32_t *inst, float *u, float *v);
 int rfwo_get_bvh(rfwo_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap, uint32_t *prims,
 				 size_t prim_cap, size_t *node_count, size_t *prim_count);
+int rfwo_trace_rays(rfwo_context *ctx, size_t n, const float *org, const float *dir, float t_min, float t_max, float *t,
+					int32_t *prim, int32_t *inst, float *u, float *v);
 /* traversal statistics of everything traced since the last reset: rays/inner/tris for closest + shadow */
 int rfwo_get_counters(rfwo_context *ctx, uint64_t out[8], int reset);
 

@@ -59,6 +59,7 @@ class CoreBinding:
             "set_setting": (i32, [vp, C.c_char_p, C.c_char_p]),
             "read_primary_hits": (i32, [vp, vp, vp, vp, vp, vp]),
             "get_bvh": (i32, [vp, sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+            "trace_rays": (i32, [vp, sz, vp, vp, fp, fp, vp, vp, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             f = self._fn(name)
@@ -66,7 +67,8 @@ class CoreBinding:
         # device-side presents: only the rendercore (and its emulation build) export these
         for name, (res, args) in {"read_framebuffer_device": (i32, [vp, vp]),
                                   "read_local_framebuffer_device": (i32, [vp, vp]),
-                                  "deinterleave_device": (i32, [vp, vp, vp])}.items():
+                                  "deinterleave_device": (i32, [vp, vp, vp]),
+                                  "get_counters": (i32, [vp, C.POINTER(abi.Counters), i32])}.items():
             if self._has(name):
                 f = self._fn(name)
                 f.restype, f.argtypes = res, args
@@ -217,6 +219,22 @@ class CoreBinding:
         shp = (self.height, self.width)
         return {"t": t.reshape(shp), "prim": prim.reshape(shp), "inst": inst.reshape(shp), "u": u.reshape(shp),
                 "v": v.reshape(shp)}
+
+    def trace_rays(self, org, dir, t_min=1e-5, t_max=1e34):
+        """Closest hits of arbitrary world-space rays (n x 3 each) against the resident scene."""
+        o, d = _f32(org).reshape(-1, 3), _f32(dir).reshape(-1, 3)
+        n = len(o)
+        t, u, v = (np.empty(n, np.float32) for _ in range(3))
+        prim, inst = np.empty(n, np.int32), np.empty(n, np.int32)
+        self._check(self._fn("trace_rays")(self._ctx, n, o.ctypes.data, d.ctypes.data, t_min, t_max, t.ctypes.data,
+                                            prim.ctypes.data, inst.ctypes.data, u.ctypes.data, v.ctypes.data))
+        return {"t": t, "prim": prim, "inst": inst, "u": u, "v": v}
+
+    def get_counters(self, reset=False):
+        """Traversal statistics since the last reset (count_traversal=1): rays, popped inner nodes, triangle tests."""
+        c = abi.Counters()
+        self._check(self._fn("get_counters")(self._ctx, C.byref(c), int(reset)))
+        return c.as_dict()
 
     def get_bvh(self, mesh_index):
         nn, np_ = C.c_size_t(), C.c_size_t()

@@ -30,7 +30,6 @@ class RenderContext(CoreBinding):
         super().__init__(load_library(), "rfwhip_", device, rank, world)
         vp, u32, i32, fp = C.c_void_p, C.c_uint32, C.c_int, C.c_float
         for name, res, args in [
-            ("get_counters", i32, [vp, C.POINTER(abi.Counters), i32]),
             ("get_kernel_time", i32, [vp, i32, C.POINTER(fp), C.POINTER(u32), i32]),
             ("get_setting", i32, [vp, C.c_char_p, C.c_char_p, C.c_size_t]),
             ("get_settings", i32, [vp, C.POINTER(C.c_char_p), C.c_size_t]),
@@ -40,11 +39,6 @@ class RenderContext(CoreBinding):
             f.restype, f.argtypes = res, args
 
     # ---- measurement hooks -------------------------------------------------------------------------------------------
-    def get_counters(self, reset=False):
-        c = abi.Counters()
-        self._check(self._fn("get_counters")(self._ctx, C.byref(c), int(reset)))
-        return c.as_dict()
-
     KERNELS = ("generate", "extend", "shade", "connect", "finalize", "refit")
 
     def get_kernel_time(self, which, reset=False):

@@ -23,7 +23,8 @@ enum GenMode
 {
 	GEN_BUFFER = 0, // rays come from the wave buffers (depth >= 1)
 	GEN_PT = 1,		// generate pt primary rays   (CUDART generatePrimaryRay)
-	GEN_PARITY = 2	// generate parity primary rays (EmbreeRT GenerateRay8 draw order)
+	GEN_PARITY = 2, // generate parity primary rays (EmbreeRT GenerateRay8 draw order)
+	GEN_RANGED = 3	// rays from the wave buffers with per-ray (t_min, t_max) in the w components (rfwhip_trace_rays)
 };
 
 typedef void *stream_t; // hipStream_t
@@ -33,6 +34,7 @@ void set_device_cus(int cus);
 
 // zero the per-render wave counters (ext/shadow/probe) and set ext[0] = primary_count
 void launch_init_counters(rt::WaveCounters *c, uint32_t primary_count, stream_t s);
+void launch_set_ext_count(rt::WaveCounters *c, uint32_t depth, uint32_t count, stream_t s);
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
 					   uint32_t packets_per_sample, uint32_t spp, stream_t s);
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t s);

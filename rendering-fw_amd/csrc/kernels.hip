@@ -94,12 +94,15 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 {
 	f3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
 	const uint32_t b = p.depth & 1u;
-	if (GEN == GEN_BUFFER)
+	float t_min = 1e-5f, t_max = 1e34f; // every wave of the integrators uses the reference's interval (Kernels.cu:455,478)
+	if (GEN == GEN_BUFFER || GEN == GEN_RANGED)
 	{
 		if (active)
 		{
 			const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
 			O = xyz(o4), D = xyz(d4);
+			if (GEN == GEN_RANGED)
+				t_min = o4.w, t_max = d4.w;
 		}
 	}
 	else
@@ -156,7 +159,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	st.inner = 0, st.tris = 0;
 	if (active)
 	{
-		trace<false, COUNT>(p.sc, O, D, 1e-5f, 1e34f, h, ctx.stk, st);
+		trace<false, COUNT>(p.sc, O, D, t_min, t_max, h, ctx.stk, st);
 		f4 *hb = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
 		int *ib = p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
 		hb[i] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
@@ -479,7 +482,7 @@ template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
 	RT_STACK_DECL
-	const uint32_t count = GEN == GEN_BUFFER ? p.wv.counters->ext[p.depth] : fixed_count;
+	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext[p.depth] : fixed_count;
 	ChunkQueue w(p, count);
 	uint32_t c;
 	while (w.next(c))
@@ -559,6 +562,11 @@ __global__ void k_init_counters(WaveCounters *c, uint32_t primary_count)
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 		init_counters_item(c, primary_count);
 }
+__global__ void k_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+		c->ext[depth] = count;
+}
 
 struct RngBase
 {
@@ -631,6 +639,11 @@ void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t s)
 	hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, (hipStream_t)s, c, primary_count);
 }
 
+void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t s)
+{
+	hipLaunchKernelGGL(k_set_ext_count, dim3(1), dim3(64), 0, (hipStream_t)s, c, depth, count);
+}
+
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
 					   uint32_t packets_per_sample, uint32_t spp, stream_t s)
 {
@@ -653,6 +666,13 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 			RT_EXT(GEN_BUFFER, true);
 		else
 			RT_EXT(GEN_BUFFER, false);
+	}
+	else if (gen == GEN_RANGED)
+	{
+		if (count)
+			RT_EXT(GEN_RANGED, true);
+		else
+			RT_EXT(GEN_RANGED, false);
 	}
 	else if (gen == GEN_PT)
 	{
@@ -729,6 +749,7 @@ void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_
 
 void set_device_cus(int) {}
 void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count); }
+void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = count; }
 
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
 					   uint32_t packets_per_sample, uint32_t spp, stream_t)
@@ -740,11 +761,13 @@ void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uin
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
 	Ctx ctx;
-	const uint32_t n = gen == GEN_BUFFER ? p.wv.counters->ext[p.depth] : max_items;
+	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext[p.depth] : max_items;
 	for (uint32_t i = 0; i < n; i++)
 	{
 		if (gen == GEN_BUFFER)
 			count ? extend_item<GEN_BUFFER, true>(p, i, true, ctx) : extend_item<GEN_BUFFER, false>(p, i, true, ctx);
+		else if (gen == GEN_RANGED)
+			count ? extend_item<GEN_RANGED, true>(p, i, true, ctx) : extend_item<GEN_RANGED, false>(p, i, true, ctx);
 		else if (gen == GEN_PT)
 			count ? extend_item<GEN_PT, true>(p, i, true, ctx) : extend_item<GEN_PT, false>(p, i, true, ctx);
 		else

@@ -1489,6 +1489,58 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	return RFWHIP_OK;
 }
 
+extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, const float *dir, float t_min, float t_max,
+								 float *t, int32_t *prim, int32_t *inst, float *u, float *v)
+{
+	CTX_ENTER(c);
+	if (n && (!org || !dir))
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_trace_rays: null rays");
+	if (c->scene_dirty)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_trace_rays: scene changed since the last rfwhip_update()");
+	if (n == 0)
+		return RFWHIP_OK;
+	if (n >= (1ull << 31))
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_trace_rays: too many rays");
+	RF_TRY(ensure_wave_buffers(c, n));
+	std::vector<f4> o4(n), d4(n);
+	for (size_t i = 0; i < n; i++)
+	{
+		o4[i] = f4{org[3 * i], org[3 * i + 1], org[3 * i + 2], t_min};
+		d4[i] = f4{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], t_max};
+	}
+	void *s = c->stream;
+	// the generic-ray wave uses the odd buffers at depth 1: org/dir carry (origin, t_min) and (direction, t_max)
+	RF_TRY(dm::h2d(c->d_org[1].p, o4.data(), n * sizeof(f4), s));
+	RF_TRY(dm::h2d(c->d_dir2[1].p, d4.data(), n * sizeof(f4), s));
+	rtk::Params p;
+	fill_params(c, nullptr, p);
+	rtk::launch_init_counters(p.wv.counters, 0, s);
+	rtk::launch_set_ext_count(p.wv.counters, 1, (uint32_t)n, s);
+	p.depth = 1, p.queue = 0, p.group = 16;
+	rtk::launch_extend(p, rtk::GEN_RANGED, c->count_traversal != 0, (uint32_t)n, s);
+	RF_TRY(dm::last_launch_error());
+	std::vector<f4> h(n);
+	std::vector<int> hi(n);
+	RF_TRY(dm::d2h(h.data(), c->d_hit.p, n * sizeof(f4), s));
+	RF_TRY(dm::d2h(hi.data(), c->d_hit_inst.p, n * 4, s));
+	for (size_t i = 0; i < n; i++)
+	{
+		int pr;
+		memcpy(&pr, &h[i].w, 4);
+		if (t)
+			t[i] = h[i].x;
+		if (u)
+			u[i] = h[i].y;
+		if (v)
+			v[i] = h[i].z;
+		if (prim)
+			prim[i] = pr;
+		if (inst)
+			inst[i] = pr >= 0 ? hi[i] : -1;
+	}
+	return RFWHIP_OK;
+}
+
 extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,
 							  uint32_t *prim_indices, size_t prim_cap, size_t *node_count, size_t *prim_count)
 {

@@ -250,6 +250,14 @@ struct TravStack
 	uint32_t *lds; // this lane's column of the workgroup's LDS stack
 };
 
+// 1/d for the slab test.  A direction component of exactly 0 (it happens: jitter r0 == 1.0f puts a ray on the image's
+// centre line) would give inf, and inf * 0 = NaN in the fma form below makes the slab test ignore that axis — the ray
+// then visits every box along it.  Such components are replaced by +-1e-30, i.e. a finite 1e30.
+RT_FN float safe_rcp(float d)
+{
+	return 1.0f / (fabsf(d) > 1e-30f ? d : copysignf(1e-30f, d));
+}
+
 RT_FN float fast_rcp(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -316,7 +324,7 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 	uint32_t spill[SPILL_STACK];
 	uint32_t *const lds = stk.lds;
 	f3 o = O, d = D;
-	f3 id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+	f3 id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
 	f3 oid = o * id;
 	const Node *nodes = sc.tlas_nodes;
 	uint32_t tri_base = 0;
@@ -348,7 +356,7 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 				return e;
 			// leaving an instance: back to the world-space ray and the top-level nodes
 			o = O, d = D;
-			id = mk3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+			id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
 			oid = o * id;
 			nodes = sc.tlas_nodes;
 			cur_inst = -1;
@@ -391,7 +399,7 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 					in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]);
 			d = mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z, in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
 					in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z);
-			id = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+			id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
 			oid = o * id;
 			nodes = sc.nodes + in.node_base;
 			tri_base = in.tri_base;
