@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=708, help="terrain cells per side (708 -> 1 002 528 triangles)")
     ap.add_argument("--integrator", default="pt", choices=["pt", "parity"])
     ap.add_argument("--max-depth", type=int, default=2)
+    ap.add_argument("--refill", type=int, default=3, help="persistent-lane traversal on the bounce / shadow waves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -99,6 +100,7 @@ def main():
     ctx.set_setting("max_depth", args.max_depth)
     ctx.set_setting("stage_timing", 1)
     ctx.set_setting("count_traversal", 0)
+    ctx.set_setting("refill", args.refill)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()

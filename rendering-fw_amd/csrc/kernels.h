@@ -17,6 +17,7 @@ struct Params
 	uint32_t lds_pairs; // number of top-of-tree node pairs staged in LDS (0 = off)
 	uint32_t queue;		// which WaveCounters::work[] row this launch pulls its chunks from
 	uint32_t group;		// chunks per XCD group (one row of tiles for the primary wave)
+	uint32_t refill;	// incoherent waves: lanes that finish a ray pull the next one (persistent lanes)
 };
 
 enum GenMode

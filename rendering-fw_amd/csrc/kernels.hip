@@ -78,8 +78,8 @@ struct Ctx
 struct Ctx
 {
 	TravStack stk;
-	uint32_t lds[LDS_STACK];
-	Ctx() { stk.lds = lds; }
+	uint32_t lds[LDS_STACK], spill[SPILL_STACK];
+	Ctx() { stk.lds = lds, stk.spill = spill; }
 	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
 	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
 };
@@ -475,8 +475,10 @@ struct ChunkQueue
 static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of the workgroup]");
 #define RT_STACK_DECL                                        \
 	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];          \
+	uint32_t spill_[SPILL_STACK];                            \
 	Ctx ctx;                                                 \
-	ctx.stk.lds = s_stack + threadIdx.x;
+	ctx.stk.lds = s_stack + threadIdx.x;                     \
+	ctx.stk.spill = spill_;
 
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
@@ -490,6 +492,102 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Para
 		const uint32_t i = c * BLOCK + threadIdx.x;
 		if (c < w.nchunks)
 			extend_item<GEN, COUNT>(p, i, i < count, ctx);
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Persistent-lane traversal for the incoherent waves (extension rays of depth >= 1, shadow rays).
+// A wave keeps 64 traversals in flight; as soon as RT_REFILL_IDLE lanes have finished their ray, those lanes pull the
+// next rays from the launch's queue (one wave-aggregated atomicAdd) while the others continue — the wave's SIMD lanes
+// stay busy although rays of one wave need very different numbers of steps (measured lane utilisation of the
+// one-ray-per-lane form on the bounce waves: 18-30 %).
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef RT_REFILL_IDLE_EXT
+#define RT_REFILL_IDLE_EXT 40 // extension rays: refill once 40 of 64 lanes are idle (swept 1..56 on MI355X: eager
+							  // refills cost more than they save; 32..56 are equivalent, +6 % over no refill)
+#endif
+#ifndef RT_REFILL_IDLE_ANY
+#define RT_REFILL_IDLE_ANY 56 // shadow rays are short: only nearly-empty waves are worth refilling (+3 %)
+#endif
+
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
+{
+	RT_STACK_DECL
+	WaveCounters *const wc = p.wv.counters;
+	const uint32_t count = ANY ? wc->shadow[p.depth] : wc->ext[p.depth];
+	uint32_t *const head = &wc->work[p.queue][0];
+	const uint32_t b = p.depth & 1u;
+	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
+	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
+	Traverser<ANY, COUNT> T;
+	T.cur = ENTRY_DONE;
+	bool has_ray = false, exhausted = false;
+	uint32_t ray = 0, slot = 0, nrays = 0;
+	TStat st;
+	st.inner = 0, st.tris = 0;
+	const uint32_t lane = __lane_id();
+	for (;;)
+	{
+		const unsigned long long idle_mask = __ballot(!has_ray);
+		const uint32_t nidle = (uint32_t)__popcll(idle_mask);
+		if (!exhausted && nidle >= (ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE_EXT))
+		{
+			const uint32_t leader = (uint32_t)__ffsll((long long)idle_mask) - 1u;
+			uint32_t base = 0;
+			if (lane == leader)
+				base = atomicAdd(head, nidle);
+			base = __shfl(base, (int)leader);
+			if (!has_ray)
+			{
+				const uint32_t idx = base + wave_prefix(idle_mask);
+				if (idx < count)
+				{
+					const f4 o4 = ray_o[idx], d4 = ray_d[idx];
+					// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
+					T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
+					has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+				}
+			}
+			exhausted = base + nidle >= count;
+		}
+		if (__ballot(has_ray) == 0ull)
+			break;
+		T.descend(p.sc, ctx.stk, st);
+		if (has_ray)
+		{
+			T.visit(p.sc, ctx.stk, st);
+			if (T.done())
+			{
+				if (ANY)
+				{
+					if (T.hit.prim < 0)
+					{
+						const f4 e4 = p.wv.sh_rad[ray];
+						f4 r = p.wv.rad[slot];
+						r.x += e4.x, r.y += e4.y, r.z += e4.z;
+						p.wv.rad[slot] = r;
+					}
+				}
+				else
+				{
+					p.wv.hit[ray] = mk4(T.hit.t, T.hit.u, T.hit.v, ubits((uint32_t)T.hit.prim));
+					p.wv.hit_inst[ray] = T.hit.inst;
+				}
+				has_ray = false;
+			}
+		}
+	}
+	if (COUNT)
+	{
+		ctx.add64(ANY ? &wc->inner_shadow : &wc->inner_extend, st.inner);
+		ctx.add64(ANY ? &wc->tris_shadow : &wc->tris_extend, st.tris);
+		ctx.add64(ANY ? &wc->rays_shadow : &wc->rays_extend, nrays);
 	}
 }
 
@@ -510,7 +608,7 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(cons
 __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params p)
 {
 	Ctx ctx;
-	ctx.stk.lds = nullptr;
+	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
@@ -660,7 +758,14 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 	const dim3 g(persistent_grid(max_items)), b(BLOCK);
 	hipStream_t st = (hipStream_t)s;
 #define RT_EXT(G, C) hipLaunchKernelGGL((k_extend<G, C>), g, b, 0, st, p, max_items)
-	if (gen == GEN_BUFFER)
+	if (gen == GEN_BUFFER && (p.refill & 1u))
+	{
+		if (count)
+			hipLaunchKernelGGL((k_trace_stream<false, true>), g, b, 0, st, p);
+		else
+			hipLaunchKernelGGL((k_trace_stream<false, false>), g, b, 0, st, p);
+	}
+	else if (gen == GEN_BUFFER)
 	{
 		if (count)
 			RT_EXT(GEN_BUFFER, true);
@@ -708,7 +813,14 @@ void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
 {
 	const dim3 g(persistent_grid(max_items)), b(BLOCK);
-	if (count)
+	if (p.refill & 2u)
+	{
+		if (count)
+			hipLaunchKernelGGL((k_trace_stream<true, true>), g, b, 0, (hipStream_t)s, p);
+		else
+			hipLaunchKernelGGL((k_trace_stream<true, false>), g, b, 0, (hipStream_t)s, p);
+	}
+	else if (count)
 		hipLaunchKernelGGL((k_connect<true>), g, b, 0, (hipStream_t)s, p);
 	else
 		hipLaunchKernelGGL((k_connect<false>), g, b, 0, (hipStream_t)s, p);

@@ -307,6 +307,7 @@ struct rfwhip_context
 	int stage_timing = 0;
 	int count_traversal = 0;
 	int lds_nodes = 0;
+	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
 
 	// scene (host side)
 	std::vector<MeshRec> meshes;
@@ -1062,6 +1063,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	p.max_depth = (uint32_t)c->max_depth;
 	p.parity_no_jitter = c->jitter == 1;
 	p.lds_pairs = (uint32_t)c->lds_nodes;
+	p.refill = (uint32_t)c->refill;
 }
 
 extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int status)
@@ -1313,7 +1315,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -1359,6 +1361,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->count_traversal = atoi(value) != 0;
 	else if (k == "lds_nodes")
 		c->lds_nodes = std::max(0, atoi(value));
+	else if (k == "refill")
+		c->refill = atoi(value) & 3; // bit 0: extension waves, bit 1: shadow waves
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
@@ -1384,6 +1388,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->count_traversal);
 	else if (k == "lds_nodes")
 		snprintf(value, cap, "%d", c->lds_nodes);
+	else if (k == "refill")
+		snprintf(value, cap, "%d", c->refill);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;

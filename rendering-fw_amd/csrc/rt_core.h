@@ -247,7 +247,9 @@ constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 
 struct TravStack
 {
-	uint32_t *lds; // this lane's column of the workgroup's LDS stack
+	uint32_t *lds;	 // this lane's column of the workgroup's LDS stack
+	uint32_t *spill; // SPILL_STACK private entries behind it (a plain local array of the caller: keeping it out of
+					 // the traversal state lets that state live in registers)
 };
 
 // 1/d for the slab test.  A direction component of exactly 0 (it happens: jitter r0 == 1.0f puts a ray on the image's
@@ -314,32 +316,46 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 // Node::left_first holds the ready-made stack entry of the node on the device (see make_entry): inner node = index
 // of its left child (children are adjacent), leaf = first/count packed, ENTRY_TLAS marks top-level entries,
 // ENTRY_SENTINEL on the stack marks "leave the instance".
-// ANY = true: occlusion query, returns on the first accepted hit in (t_min, t_max).
+// ANY = true: occlusion query, finishes on the first accepted hit in (t_min, t_max).
+//
+// The traversal is a resumable per-lane state machine (begin / descend / visit) so that the persistent kernels can
+// hand a finished lane a new ray while its neighbours are still busy; trace() below runs it to completion.
 template <bool ANY, bool COUNT>
-RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit &hit, const TravStack stk, TStat &st)
+struct Traverser
 {
-	hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
-	if (sc.instance_count == 0)
-		return false;
-	uint32_t spill[SPILL_STACK];
-	uint32_t *const lds = stk.lds;
-	f3 o = O, d = D;
-	f3 id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-	f3 oid = o * id;
-	const Node *nodes = sc.tlas_nodes;
-	uint32_t tri_base = 0;
-	int cur_inst = -1;
-	int sp = 0;
-	uint32_t cur = sc.tlas_root_entry;
+	f3 O, D;		 // world-space ray
+	f3 o, d, id, oid; // ray in the current space (world, or the object space of cur_inst), 1/d, o/d
+	const Node *nodes;
+	uint32_t tri_base;
+	int cur_inst;
+	int sp;
+	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
+	float t_min;
+	Hit hit;
 
-	auto push = [&](uint32_t e) {
+	RT_FN void begin(const SceneView &sc, f3 O_, f3 D_, float t_min_, float t_max)
+	{
+		O = O_, D = D_, t_min = t_min_;
+		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
+		o = O, d = D;
+		id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
+		oid = o * id;
+		nodes = sc.tlas_nodes;
+		tri_base = 0, cur_inst = -1, sp = 0;
+		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	}
+	RT_FN bool done() const { return cur == ENTRY_DONE; }
+
+	RT_FN void push(const TravStack stk, uint32_t e)
+	{
 		if (sp < LDS_STACK)
-			lds[sp * STACK_STRIDE] = e;
+			stk.lds[sp * STACK_STRIDE] = e;
 		else if (sp < LDS_STACK + SPILL_STACK)
-			spill[sp - LDS_STACK] = e;
+			stk.spill[sp - LDS_STACK] = e;
 		sp++;
-	};
-	auto pop_next = [&]() -> uint32_t {
+	}
+	RT_FN uint32_t pop_next(const SceneView &sc, const TravStack stk)
+	{
 		for (;;)
 		{
 			if (sp == 0)
@@ -347,9 +363,9 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 			sp--;
 			uint32_t e;
 			if (sp < LDS_STACK)
-				e = lds[sp * STACK_STRIDE];
+				e = stk.lds[sp * STACK_STRIDE];
 			else if (sp < LDS_STACK + SPILL_STACK)
-				e = spill[sp - LDS_STACK];
+				e = stk.spill[sp - LDS_STACK];
 			else
 				e = ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
 			if (e != ENTRY_SENTINEL)
@@ -361,9 +377,10 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 			nodes = sc.tlas_nodes;
 			cur_inst = -1;
 		}
-	};
+	}
 
-	for (;;)
+	// phase 1: walk inner nodes until this lane holds a leaf entry (or ENTRY_DONE)
+	RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
 		while (!(cur & ENTRY_LEAF))
 		{
@@ -378,22 +395,27 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 			if (h0 && h1)
 			{
 				const bool first0 = n0 < n1;
-				push(first0 ? e1 : e0);
+				push(stk, first0 ? e1 : e0);
 				cur = first0 ? e0 : e1;
 			}
 			else if (h0 || h1)
 				cur = h0 ? e0 : e1;
 			else
-				cur = pop_next();
+				cur = pop_next(sc, stk);
 		}
+	}
+
+	// phase 2: the leaf in hand — enter an instance (top-level leaf) or test the triangles, then fetch the next entry
+	RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st)
+	{
 		if (cur == ENTRY_DONE)
-			break;
+			return;
 		if (cur & ENTRY_TLAS)
 		{
 			// top-level leaf: exactly one instance (the TLAS builder never merges)
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
 			const Instance &in = sc.instances[ii];
-			push(ENTRY_SENTINEL);
+			push(stk, ENTRY_SENTINEL);
 			o = mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
 					in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
 					in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]);
@@ -405,7 +427,7 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 			tri_base = in.tri_base;
 			cur_inst = (int)ii;
 			cur = in.root_entry;
-			continue;
+			return;
 		}
 		const uint32_t first = tri_base + (cur & ENTRY_FIRST_MASK);
 		const uint32_t count = ((cur >> 27) & 7u) + 1u;
@@ -420,11 +442,27 @@ RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit 
 				hit.prim = (int)fbits(v0.w);
 				hit.inst = cur_inst;
 				if (ANY)
-					return true;
+				{
+					cur = ENTRY_DONE;
+					return;
+				}
 			}
 		}
-		cur = pop_next();
+		cur = pop_next(sc, stk);
 	}
+};
+
+template <bool ANY, bool COUNT>
+RT_FN bool trace(const SceneView &sc, f3 O, f3 D, float t_min, float t_max, Hit &hit, const TravStack stk, TStat &st)
+{
+	Traverser<ANY, COUNT> T;
+	T.begin(sc, O, D, t_min, t_max);
+	while (!T.done())
+	{
+		T.descend(sc, stk, st);
+		T.visit(sc, stk, st);
+	}
+	hit = T.hit;
 	return hit.prim >= 0;
 }
 
