@@ -47,6 +47,7 @@ constexpr int BLOCK = 256;
 struct Ctx
 {
 	TravStack stk;
+	float *pot = nullptr; // this lane's column of the light-potential cache (shade kernel)
 
 	// wave-aggregated slot allocation: returns the compacted index for lanes with flag set
 	__device__ __forceinline__ uint32_t compact(bool flag, uint32_t *counter)
@@ -79,7 +80,9 @@ struct Ctx
 {
 	TravStack stk;
 	uint32_t lds[LDS_STACK], spill[SPILL_STACK];
-	Ctx() { stk.lds = lds, stk.spill = spill; }
+	float potbuf[POT_CACHE];
+	float *pot;
+	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf; }
 	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
 	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
 };
@@ -254,7 +257,7 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 				WaveCounters *c = p.wv.counters;
 				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
 			}
-			pt_shade(p.sc, p.cam, p.max_depth, in, h, out);
+			pt_shade(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
 			write_rad = true;
 		}
 	}
@@ -607,8 +610,11 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(cons
 
 __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params p)
 {
+	static_assert(BLOCK == POT_STRIDE, "potential cache layout is pot[light][thread]");
+	__shared__ float s_pot[POT_CACHE * BLOCK];
 	Ctx ctx;
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr;
+	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)

@@ -209,16 +209,20 @@ RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x
 	uint32_t seed = wang_hash(pixel * 16789u + sampleIdx * 1791u);
 	const float r0 = random_float(seed), r1 = random_float(seed);
 	float r2 = random_float(seed), r3 = random_float(seed);
-	const float blade = (float)(int)(r0 * 9);
-	r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
-	const float piOver4point5 = 3.14159265359f / 4.5f;
-	// __sincosf(a, &x1, &y1): x1 = sin, y1 = cos (Kernels.cu:407-408)
-	const float x1 = sinf(blade * piOver4point5), y1 = cosf(blade * piOver4point5);
-	const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
-	if ((r2 + r3) > 1.0f)
-		r2 = 1.0f - r2, r3 = 1.0f - r3;
-	const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
-	O = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
+	O = cam.pos;
+	if (cam.aperture != 0.0f) // with aperture 0 the lens offset is exactly zero: skip the four trig evaluations
+	{
+		const float blade = (float)(int)(r0 * 9);
+		r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
+		const float piOver4point5 = 3.14159265359f / 4.5f;
+		// __sincosf(a, &x1, &y1): x1 = sin, y1 = cos (Kernels.cu:407-408)
+		const float x1 = sinf(blade * piOver4point5), y1 = cosf(blade * piOver4point5);
+		const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
+		if ((r2 + r3) > 1.0f)
+			r2 = 1.0f - r2, r3 = 1.0f - r3;
+		const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
+		O = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
+	}
 	const float u = ((float)x + r0) * (1.0f / (float)W), v = ((float)y + r1) * (1.0f / (float)H);
 	D = normalize(((cam.p1 + cam.right * u) + cam.up * v) - O);
 }
@@ -821,12 +825,16 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 			const float FL = schlick_fresnel(NDotL), FV = schlick_fresnel(NDotV);
 			const float Fd90 = 0.5f + 2.0f * LDotH * LDotH * a;
 			const float Fd = lerp1(1.0f, Fd90, FL) * lerp1(1.0f, Fd90, FV);
-			const float Dr = gtr1(NDotH, lerp1(.1f, .001f, sd_clearcoatgloss(sd)));
-			const float Fc = lerp1(.04f, 1.0f, FH);
-			const float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
 			const f3 diff = ((Cdlin * (RT_INVPI * Fd)) * (1.0f - METALLIC)) * (1.0f - SUBSURFACE);
 			const f3 spec = (Fs * Gs) * Ds;
-			const float cc = sd_clearcoat(sd) * Gr * Fc * Dr;
+			float cc = 0.0f; // CLEARCOAT * Gr * Fc * Dr: all factors are finite, so a zero clearcoat contributes exactly 0
+			if (sd_clearcoat(sd) > 0.0f)
+			{
+				const float Dr = gtr1(NDotH, lerp1(.1f, .001f, sd_clearcoatgloss(sd)));
+				const float Fc = lerp1(.04f, 1.0f, FH);
+				const float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
+				cc = sd_clearcoat(sd) * Gr * Fc * Dr;
+			}
 			brdf = (diff + spec) + mk3(cc, cc, cc);
 		}
 	}
@@ -835,24 +843,37 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 		return fin * mk3(expf(-sd.absorption.x * t), expf(-sd.absorption.y * t), expf(-sd.absorption.z * t));
 	return fin;
 }
+// sin / cos of 2*pi*frac.  On the GPU v_sin_f32 / v_cos_f32 take their argument in turns — one instruction each instead
+// of a range-reduced polynomial; |error| ~1e-6, well inside the path tracer's tolerance.
+RT_FN void sincos_turns(float frac, float &s, float &c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	s = __builtin_amdgcn_sinf(frac), c = __builtin_amdgcn_cosf(frac);
+#else
+	s = sinf(frac * RT_TWOPI), c = cosf(frac * RT_TWOPI);
+#endif
+}
 RT_FN f3 reflect_dir(f3 I, f3 N) { return I - N * (dot(N, I) * 2.0f); }
 RT_FN f3 diffuse_reflection_uniform(float r0, float r1)
 {
-	const float term1 = RT_TWOPI * r0, term2 = sqrtf(1.0f - r1 * r1);
-	return mk3(cosf(term1) * term2, sinf(term1) * term2, r1);
+	const float term2 = sqrtf(1.0f - r1 * r1);
+	float sn, cs;
+	sincos_turns(r0, sn, cs);
+	return mk3(cs * term2, sn * term2, r1);
 }
 RT_FN f3 diffuse_reflection_cos_weighted(float r0, float r1)
 {
-	const float term1 = RT_TWOPI * r0;
 	const float term2 = (float)sqrt(1.0 - (double)r1); // tools.h:113 computes this term in double
-	return normalize(mk3(cosf(term1) * term2, sinf(term1) * term2, sqrtf(r1)));
+	float sn, cs;
+	sincos_turns(r0, sn, cs);
+	return normalize(mk3(cs * term2, sn * term2, sqrtf(r1)));
 }
 RT_FN f3 ggx_halfway(f3 T, f3 B, f3 N, f3 wo, float rough, float r1, float r2)
 {
 	const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(rough) - 1.0f) * r2));
 	const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
-	const float sinPhiHalf = sinf(r1 * RT_TWOPI);
-	const float cosPhiHalf = cosf(r1 * RT_TWOPI);
+	float sinPhiHalf, cosPhiHalf;
+	sincos_turns(r1, sinPhiHalf, cosPhiHalf);
 	f3 halfway = (T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf)) + N * cosThetaHalf;
 	if (dot(halfway, wo) <= 0.0f)
 		halfway = halfway * -1.0f;
@@ -1056,14 +1077,25 @@ RT_FN f3 random_barycentrics(float r0)
 }
 // lights.h:159-265 with importance sampling over the potential contribution of every light.  The potentials are
 // recomputed in the selection pass instead of being kept in a MAX_IS_LIGHTS array, so any light count is valid.
+constexpr uint32_t POT_CACHE = 16; // potentials of the first 16 lights are kept (in LDS on the GPU) between the passes
+#if defined(RT_DEVICE_BUILD)
+constexpr int POT_STRIDE = 256;
+#else
+constexpr int POT_STRIDE = 1;
+#endif
 RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3 N, float &pickProb, float &lightPdf,
-							   f3 &lightColor)
+							   f3 &lightColor, float *pot_cache)
 {
 	const uint32_t lights = total_lights(sc);
 	const f3 bary = random_barycentrics(r0);
 	float sum = 0;
 	for (uint32_t k = 0; k < lights; k++)
-		sum += pot_any(sc, k, I, N, bary);
+	{
+		const float pk = pot_any(sc, k, I, N, bary);
+		if (pot_cache && k < POT_CACHE)
+			pot_cache[k * POT_STRIDE] = pk;
+		sum += pk;
+	}
 	if (sum <= 0)
 	{
 		lightPdf = 0;
@@ -1074,7 +1106,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 	uint32_t li = 0;
 	for (uint32_t k = 0; k < lights; k++)
 	{
-		const float p = pot_any(sc, k, I, N, bary);
+		const float p = (pot_cache && k < POT_CACHE) ? pot_cache[k * POT_STRIDE] : pot_any(sc, k, I, N, bary);
 		if (k == 0)
 			first = p;
 		total += p;
@@ -1157,7 +1189,7 @@ struct ShadeOut
 };
 
 RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
-					ShadeOut &out)
+					ShadeOut &out, float *pot_cache)
 {
 	out.radiance = mk3(0, 0, 0);
 	out.emit_shadow = false, out.emit_ext = false;
@@ -1252,7 +1284,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 		f3 lightColor = mk3(0, 0, 0);
 		float pickProb = 0, lightPdf = 0;
 		const float q0 = random_float(seed), q1 = random_float(seed);
-		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor) - I;
+		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache) - I;
 		const float dist = length(L);
 		L = L * (1.0f / dist);
 		const float NdotL = dot(L, iN);
