@@ -48,7 +48,10 @@ void launch_present(const Params &p, rt::f4 *out, float scale, int full, stream_
 void launch_deinterleave(const rt::f4 *gathered, rt::f4 *out, uint32_t W, uint32_t H, uint32_t local_rows,
 						 uint32_t world, stream_t s);
 // bottom-up refit of one BLAS after its vertices changed: leaf_order[i] = original primitive of leaf slot i
-void launch_refit(rt::Node *nodes, const int *parents, uint32_t node_count, rt::f4 *tri_verts, const rt::f4 *verts,
-				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s);
+// nodes / tri_verts are the scene-wide arrays (device entries carry absolute indices); node_base / tri_base locate the
+// BLAS in them; parents are BLAS-relative
+void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint32_t node_count, rt::f4 *tri_verts,
+				  uint32_t tri_base, const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags,
+				  stream_t s);
 
 } // namespace rtk

@@ -691,12 +691,13 @@ __global__ void __launch_bounds__(BLOCK) k_refit_tris(f4 *tri_verts, const f4 *v
 
 // pass 2: one thread per node; leaves recompute their box and walk up; the second thread to arrive at a parent
 // (agent-scope counter + fences: the sibling's box was written by another CU) merges the two children.
-__global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *nodes, const int *parents, uint32_t node_count,
-													   const f4 *tri_verts, uint32_t *flags)
+__global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *all_nodes, uint32_t node_base, const int *parents,
+													   uint32_t node_count, const f4 *tri_verts, uint32_t *flags)
 {
 	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= node_count)
 		return;
+	Node *nodes = all_nodes + node_base; // BLAS-relative view; entries inside are absolute
 	const Node n = nodes[i];
 	if (n.count < 0 || (i == 1u)) // inner node, or the unused slot next to the root
 		return;
@@ -714,7 +715,7 @@ __global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *nodes, const int *p
 		if (atomicAdd(&flags[parent], 1u) == 0u)
 			break;		 // first arrival: the sibling will continue
 		__threadfence(); // acquire the sibling's box
-		const int l = (int)((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK);
+		const int l = (int)(((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK) - node_base);
 		for (int a = 0; a < 3; a++)
 		{
 			const float lo0 = __hip_atomic_load(&nodes[l].bmin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -850,14 +851,14 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 					   local_rows, world);
 }
 
-void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_verts, const f4 *verts,
-				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s)
+void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
+				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s)
 {
 	hipStream_t st = (hipStream_t)s;
-	hipMemsetAsync(flags, 0, sizeof(uint32_t) * node_count, st);
-	hipLaunchKernelGGL(k_refit_tris, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tri_verts, verts, indices,
-					   tri_count);
-	hipLaunchKernelGGL(k_refit_nodes, dim3((node_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, parents,
+	(void)hipMemsetAsync(flags, 0, sizeof(uint32_t) * node_count, st);
+	hipLaunchKernelGGL(k_refit_tris, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tri_verts + 3ull * tri_base,
+					   verts, indices, tri_count);
+	hipLaunchKernelGGL(k_refit_nodes, dim3((node_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, nodes, node_base, parents,
 					   node_count, tri_verts, flags);
 }
 
@@ -927,12 +928,13 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 	for (uint32_t i = 0; i < W * H; i++)
 		deinterleave_item(gathered, out, W, H, local_rows, world, i);
 }
-void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_verts, const f4 *verts,
-				  const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)
+void launch_refit(Node *all_nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
+				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)
 {
 	for (uint32_t i = 0; i < tri_count; i++)
-		refit_tris_item(tri_verts, verts, indices, i);
+		refit_tris_item(tri_verts + 3ull * tri_base, verts, indices, i);
 	memset(flags, 0, sizeof(uint32_t) * node_count);
+	Node *nodes = all_nodes + node_base;
 	for (uint32_t i = 0; i < node_count; i++)
 	{
 		const Node n = nodes[i];
@@ -950,7 +952,7 @@ void launch_refit(Node *nodes, const int *parents, uint32_t node_count, f4 *tri_
 				break;
 			if (flags[parent]++ == 0u)
 				break;
-			const int l = (int)((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK);
+			const int l = (int)(((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK) - node_base);
 			for (int a = 0; a < 3; a++)
 			{
 				nodes[parent].bmin[a] = fminf(nodes[l].bmin[a], nodes[l + 1].bmin[a]);

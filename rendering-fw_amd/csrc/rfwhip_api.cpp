@@ -316,7 +316,8 @@ struct rfwhip_context
 	bool scene_dirty = true;
 
 	// scene (device side)
-	DevBuf d_nodes, d_tri_verts, d_tri_shade, d_tlas_nodes, d_tlas_prims, d_instances;
+	DevBuf d_nodes, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
+	size_t blas_nodes = 0, node_capacity = 0; // d_nodes = [all BLAS nodes | TLAS nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
 	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
 	uint32_t tlas_root_entry = 0, instance_count = 0;
@@ -470,7 +471,7 @@ static void free_all(rfwhip_context *c)
 {
 	for (auto &m : c->meshes)
 		m.d_verts.free_(), m.d_indices.free_(), m.d_parents.free_(), m.d_flags.free_();
-	DevBuf *bufs[] = {&c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_nodes, &c->d_tlas_prims, &c->d_instances,
+	DevBuf *bufs[] = {&c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
 					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org, &c->d_sh_dir,
@@ -482,6 +483,7 @@ static void free_all(rfwhip_context *c)
 		dm::event_destroy(e);
 	c->event_pool.clear();
 	c->wave_capacity = 0;
+	c->blas_nodes = 0, c->node_capacity = 0;
 }
 
 extern "C" int rfwhip_cleanup(rfwhip_context *c)
@@ -701,8 +703,8 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 			dm::event_create(&ea), dm::event_create(&eb);
 			dm::event_record(ea, c->stream);
 		}
-		rtk::launch_refit(c->d_nodes.as<rt::Node>() + m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
-						  c->d_tri_verts.as<f4>() + 3ull * m.tri_base, m.d_verts.as<f4>(),
+		rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+						  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 						  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, m.d_flags.as<uint32_t>(),
 						  c->stream);
 		RF_TRY(dm::last_launch_error());
@@ -804,9 +806,16 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	RF_TRY(dm::sync(c->stream));
 	// ---- place meshes in the global arrays (only when some mesh was rebuilt) ----
 	bool relayout = false;
+	size_t live_instances = 0;
+	for (auto &in : c->instances)
+		if (in.used)
+			live_instances++;
+	const size_t tlas_reserve = 2 * live_instances + 2; // a BVH2 over n leaves of one primitive has at most 2n nodes
 	for (auto &m : c->meshes)
 		if (m.used && m.dirty)
 			relayout = true;
+	if (c->blas_nodes + tlas_reserve > c->node_capacity)
+		relayout = true; // the TLAS lives behind the BLAS nodes in the same array: grow it together
 	if (relayout)
 	{
 		size_t nodes = 0, tris = 0;
@@ -825,17 +834,24 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			if (!m.used)
 				continue;
 			memcpy(&all_nodes[m.node_base], m.bvh.nodes.data(), m.bvh.nodes.size() * sizeof(rt::Node));
-			// device form: left_first carries the ready-made stack entry (rt::make_entry), count is kept
+			// device form: left_first carries the ready-made stack entry (rt::make_entry) with ABSOLUTE indices —
+			// node index into the scene-wide node array / leaf-ordered triangle index into tri_verts; count is kept
 			for (size_t k = 0; k < m.bvh.nodes.size(); k++)
 			{
 				rt::Node &nd = all_nodes[m.node_base + k];
-				if (nd.count != 0)
-					nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, false);
+				if (nd.count > 0)
+					nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.tri_base, nd.count, false);
+				else if (nd.count < 0)
+					nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.node_base, nd.count, false);
 			}
 			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
 			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
 		}
-		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
+		if (tris > rt::ENTRY_FIRST_MASK)
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
+		c->blas_nodes = all_nodes.size();
+		c->node_capacity = all_nodes.size() + 2 * tlas_reserve + 64;
+		RF_TRY(c->d_nodes.ensure(c->node_capacity * sizeof(rt::Node)));
 		RF_TRY(c->d_tri_verts.ensure(all_verts.size() * sizeof(f4)));
 		RF_TRY(c->d_tri_shade.ensure(all_shade.size() * sizeof(rt::TriShade)));
 		RF_TRY(dm::h2d(c->d_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(rt::Node), c->stream));
@@ -849,8 +865,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				continue;
 			if (m.resident && !m.dirty)
 			{
-				rtk::launch_refit(c->d_nodes.as<rt::Node>() + m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
-								  c->d_tri_verts.as<f4>() + 3ull * m.tri_base, m.d_verts.as<f4>(),
+				rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+								  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 								  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount,
 								  m.d_flags.as<uint32_t>(), c->stream);
 				RF_TRY(dm::last_launch_error());
@@ -880,7 +896,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			for (int r = 0; r < 3; r++)
 				d.nrm[4 * col + r] = in.normal[3 * col + r];
 		d.node_base = m.node_base, d.tri_base = m.tri_base, d.shade_base = m.shade_base;
-		d.root_entry = rt::make_entry(m.bvh.nodes[0].left_first, m.bvh.nodes[0].count, false);
+		d.root_entry = rt::make_entry(m.bvh.nodes[0].left_first + (int)(m.bvh.nodes[0].count < 0 ? m.node_base : m.tri_base),
+									  m.bvh.nodes[0].count, false);
 		float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
 		for (int k = 0; k < 8; k++)
 		{
@@ -906,24 +923,30 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		tprims[k] = live[tl.order[k]];
 	if (tl.nodes.empty())
 		tl.nodes.resize(2);
+	if (c->blas_nodes + tl.nodes.size() > c->node_capacity)
+		return set_error(RFWHIP_ERR_STATE, "internal: TLAS does not fit behind the BLAS nodes");
+	const int tlas_base = (int)c->blas_nodes; // even: every BLAS has an even node count
 	const int tl_root_left = tl.nodes[0].left_first, tl_root_count = tl.nodes[0].count;
 	for (rt::Node &nd : tl.nodes)
-		if (nd.count != 0)
-			nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, true);
+	{
+		if (nd.count > 0)
+			nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, true); // index into tlas_prims
+		else if (nd.count < 0)
+			nd.left_first = (int)rt::make_entry(nd.left_first + tlas_base, nd.count, true);
+	}
 	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
-	RF_TRY(c->d_tlas_nodes.ensure(tl.nodes.size() * sizeof(rt::Node)));
 	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
 	RF_TRY(dm::h2d(c->d_instances.p, inst.data(), inst.size() * sizeof(rt::Instance), c->stream));
-	RF_TRY(dm::h2d(c->d_tlas_nodes.p, tl.nodes.data(), tl.nodes.size() * sizeof(rt::Node), c->stream));
+	RF_TRY(dm::h2d(c->d_nodes.as<rt::Node>() + tlas_base, tl.nodes.data(), tl.nodes.size() * sizeof(rt::Node), c->stream));
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
-	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl_root_left, tl_root_count, true);
+	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl_root_count < 0 ? tl_root_left + tlas_base : tl_root_left, tl_root_count, true);
 
 	rt::SceneView &sv = c->sv;
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
 	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
-	sv.tlas_nodes = c->d_tlas_nodes.as<rt::Node>(), sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();
+	sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();
 	sv.instances = c->d_instances.as<rt::Instance>();
 	sv.tlas_root_entry = c->tlas_root_entry, sv.instance_count = c->instance_count;
 	sv.materials = c->d_materials.as<rt::MaterialRec>(), sv.material_count = c->material_count;

@@ -240,7 +240,10 @@ struct TStat
 	uint32_t inner, tris;
 };
 
-constexpr int LDS_STACK = 24;	// entries per lane kept in LDS
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 24
+#endif
+constexpr int LDS_STACK = RT_LDS_STACK;	// entries per lane kept in LDS
 constexpr int SPILL_STACK = 40; // further entries in private memory (touched only by pathological rays)
 #if defined(RT_DEVICE_BUILD)
 constexpr int STACK_STRIDE = 256; // = workgroup size: stack[entry][thread], bank = thread % 32, conflict-free
@@ -329,8 +332,6 @@ struct Traverser
 {
 	f3 O, D;		 // world-space ray
 	f3 o, d, id, oid; // ray in the current space (world, or the object space of cur_inst), 1/d, o/d
-	const Node *nodes;
-	uint32_t tri_base;
 	int cur_inst;
 	int sp;
 	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
@@ -344,8 +345,7 @@ struct Traverser
 		o = O, d = D;
 		id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
 		oid = o * id;
-		nodes = sc.tlas_nodes;
-		tri_base = 0, cur_inst = -1, sp = 0;
+		cur_inst = -1, sp = 0;
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
 	}
 	RT_FN bool done() const { return cur == ENTRY_DONE; }
@@ -358,29 +358,17 @@ struct Traverser
 			stk.spill[sp - LDS_STACK] = e;
 		sp++;
 	}
-	RT_FN uint32_t pop_next(const SceneView &sc, const TravStack stk)
+	// next entry from the stack; ENTRY_SENTINEL comes back like a leaf and is resolved in visit()
+	RT_FN uint32_t pop(const TravStack stk)
 	{
-		for (;;)
-		{
-			if (sp == 0)
-				return ENTRY_DONE;
-			sp--;
-			uint32_t e;
-			if (sp < LDS_STACK)
-				e = stk.lds[sp * STACK_STRIDE];
-			else if (sp < LDS_STACK + SPILL_STACK)
-				e = stk.spill[sp - LDS_STACK];
-			else
-				e = ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
-			if (e != ENTRY_SENTINEL)
-				return e;
-			// leaving an instance: back to the world-space ray and the top-level nodes
-			o = O, d = D;
-			id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-			oid = o * id;
-			nodes = sc.tlas_nodes;
-			cur_inst = -1;
-		}
+		if (sp == 0)
+			return ENTRY_DONE;
+		sp--;
+		if (sp < LDS_STACK)
+			return stk.lds[sp * STACK_STRIDE];
+		if (sp < LDS_STACK + SPILL_STACK)
+			return stk.spill[sp - LDS_STACK];
+		return ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
 	}
 
 	// phase 1: walk inner nodes until this lane holds a leaf entry (or ENTRY_DONE)
@@ -388,7 +376,7 @@ struct Traverser
 	{
 		while (!(cur & ENTRY_LEAF))
 		{
-			const f4 *p = (const f4 *)(nodes + (cur & ENTRY_INDEX_MASK));
+			const f4 *p = (const f4 *)(sc.nodes + (cur & ENTRY_INDEX_MASK));
 			const f4 a0 = p[0], b0 = p[1], a1 = p[2], b1 = p[3];
 			if (COUNT)
 				st.inner++;
@@ -405,7 +393,7 @@ struct Traverser
 			else if (h0 || h1)
 				cur = h0 ? e0 : e1;
 			else
-				cur = pop_next(sc, stk);
+				cur = pop(stk);
 		}
 	}
 
@@ -414,6 +402,16 @@ struct Traverser
 	{
 		if (cur == ENTRY_DONE)
 			return;
+		if (cur == ENTRY_SENTINEL)
+		{
+			// leaving an instance: back to the world-space ray
+			o = O, d = D;
+			id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
+			oid = o * id;
+			cur_inst = -1;
+			cur = pop(stk);
+			return;
+		}
 		if (cur & ENTRY_TLAS)
 		{
 			// top-level leaf: exactly one instance (the TLAS builder never merges)
@@ -427,13 +425,11 @@ struct Traverser
 					in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z);
 			id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
 			oid = o * id;
-			nodes = sc.nodes + in.node_base;
-			tri_base = in.tri_base;
 			cur_inst = (int)ii;
 			cur = in.root_entry;
 			return;
 		}
-		const uint32_t first = tri_base + (cur & ENTRY_FIRST_MASK);
+		const uint32_t first = cur & ENTRY_FIRST_MASK;
 		const uint32_t count = ((cur >> 27) & 7u) + 1u;
 		for (uint32_t i = 0; i < count; i++)
 		{
@@ -452,7 +448,7 @@ struct Traverser
 				}
 			}
 		}
-		cur = pop_next(sc, stk);
+		cur = pop(stk);
 	}
 };
 

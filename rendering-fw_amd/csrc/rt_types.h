@@ -64,7 +64,7 @@ struct alignas(16) Instance
 {
 	float inv[12];		 // rows 0..2 of M^-1 (row-major 3x4)
 	float nrm[12];		 // normal matrix, 3 columns padded to float4 (column-major like glm::mat3)
-	uint32_t root_entry; // stack entry of the BLAS root
+	uint32_t root_entry; // stack entry of the BLAS root (absolute indices, like every entry on the device)
 	uint32_t node_base;	 // first node of the BLAS in SceneView::nodes
 	uint32_t tri_base;	 // first leaf-ordered triangle of the BLAS in SceneView::tri_verts
 	uint32_t shade_base; // first mesh-ordered shading record in SceneView::tri_shade
@@ -132,10 +132,12 @@ struct DirectionalLight
 
 struct SceneView
 {
-	const Node *nodes;		 // all BLAS nodes, concatenated
+	const Node *nodes;		 // ONE array: all BLAS nodes, then the TLAS nodes.  Node::left_first holds the node's
+							 // ready-made stack entry with ABSOLUTE indices (node index into this array, leaf-ordered
+							 // triangle index into tri_verts): a traversal step is base + 32-bit offset, no per-lane
+							 // base pointers
 	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
 	const TriShade *tri_shade;
-	const Node *tlas_nodes;
 	const uint32_t *tlas_prims; // instance index per TLAS leaf slot
 	const Instance *instances;
 	uint32_t tlas_root_entry;
