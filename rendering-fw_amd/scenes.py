@@ -512,10 +512,10 @@ def atrium(width=1920, height=1080, columns=10, tex_size=256):
                                    texture=texs[i % len(texs)] if i % 2 == 0 else -1,
                                    uvscale=(float(rng.integers(1, 6)), float(rng.integers(1, 6)))))
     # tessellated column (cylinder with entasis): rings x segments
-    seg, rings = 96, 60
+    seg, rings = 64, 44
     th = np.linspace(0, 2 * np.pi, seg, endpoint=False)
     yy = np.linspace(0, 1, rings + 1)
-    rad = 0.45 * (1 - 0.18 * yy ** 2) * (1 + 0.04 * np.cos(th[None, :] * 12))
+    rad = 0.45 * (1 - 0.18 * yy[:, None] ** 2) * (1 + 0.04 * np.cos(th[None, :] * 12))
     vx = rad * np.cos(th)[None, :]
     vz = rad * np.sin(th)[None, :]
     cv = np.stack([vx, np.repeat(yy[:, None] * 6.0, seg, 1), vz], -1).reshape(-1, 3).astype(np.float32)
@@ -568,7 +568,7 @@ def atrium(width=1920, height=1080, columns=10, tex_size=256):
     s.add_point_light((0.0, 5.0, -3.0), (40.0, 36.0, 30.0))
     s.set_gradient_sky(1024, 512)
     cam = Camera(aperture=0.0, FOV=55.0, focalDistance=5.0)
-    cam.look_at((-11.0, 3.2, -5.2), (6.0, 4.2, 4.0))
+    cam.look_at((-12.2, 3.4, -6.2), (6.0, 4.6, 3.0))
     cam.resize(width, height)
     s.camera = cam
     return s

@@ -106,3 +106,91 @@ def test_errors_are_loud(pkg, make_hip):
         ctx.set_setting("integrator", "bogus")
     ctx.cleanup()
     ctx.cleanup()  # idempotent
+
+
+def test_config2_cornell_1080p_64spp(pkg, make_hip, make_oracle):
+    """BASELINE.json config 2 at its full size: Cornell scene, 1920x1080, 64 spp, parity integrator, xor128 jitter
+    from the default seed — per-pixel L2 against the oracle (which has no accumulator: 64 single-sample frames).
+    Stated tolerance: RGB L2 <= 1e-3 on >= 99.9 % of pixels and RMSE <= 1e-3."""
+    scene = pkg.scenes.cornell(1920, 1080)
+    hip, ref = make_hip(), make_oracle()
+    for ctx, spp, calls in ((hip, 16, 4), (ref, 1, 64)):
+        ctx.init(1920, 1080)
+        scene.upload(ctx)
+        ctx.set_setting("integrator", "parity")
+        ctx.set_setting("spp", spp)
+        for k in range(calls):
+            ctx.render_frame(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+    a, b = hip.framebuffer(), ref.framebuffer()
+    frac, rmse, d = image_stats(a, b, 1e-3)
+    assert frac <= 1e-3 and rmse <= 1e-3, (frac, rmse, float(d.max()))
+
+
+def test_atrium_textured_instanced(pkg, make_hip, make_oracle):
+    """BASELINE config 4 stand-in (~264 k instanced triangles, 46 instances of 10 meshes, 25 materials, 12 mip-mapped
+    textures) at reduced resolution: both integrators against the oracle."""
+    scene = pkg.scenes.atrium(480, 270)
+    assert 200_000 < scene.triangle_count() < 400_000
+    # parity integrator: keep emitters out of the geometry (see test_terrain_parity_hits)
+    par = pkg.scenes.atrium(480, 270)
+    par.area_lights = par.area_lights[:0]
+    par.instances = par.instances[:-1]          # drop the emissive quads' instance
+    par.add_area_light_quad((0.0, -1.0, 0.0), (0.0, 12.0, 0.0), 3.0, 3.0, (25.0, 24.0, 20.0))
+    hip, ref = _pair(pkg, make_hip, make_oracle, par, 480, 270, {"integrator": "parity", "jitter": "center"})
+    a, b = hip.primary_hits(), ref.primary_hits()
+    assert (a["prim"] != b["prim"]).mean() <= 2e-3 and (a["inst"] != b["inst"]).mean() <= 2e-3
+    frac, rmse, _ = image_stats(hip.framebuffer(), ref.framebuffer(), 1e-3)
+    assert frac <= 5e-3, (frac, rmse)
+    hip, ref = _pair(pkg, make_hip, make_oracle, scene, 480, 270, {"integrator": "pt", "spp": 8})
+    frac, rmse, _ = image_stats(hip.framebuffer(), ref.framebuffer(), 3e-2)
+    assert frac <= 2e-2, (frac, rmse)
+    assert abs(hip.framebuffer()[..., :3].mean() - ref.framebuffer()[..., :3].mean()) <= 5e-3 * ref.framebuffer()[..., :3].mean()
+
+
+def test_skinned_tube_refit_on_device(pkg, make_hip, make_oracle):
+    """BASELINE config 5 logic on the GPU: host skinning -> set_mesh with unchanged counts -> device refit; every
+    frame's image equals a fresh build of that pose and the oracle's."""
+    w, h = 480, 270
+    base = pkg.scenes.skinned_tube(frame=0.0, rings=80, seg=48, width=w, height=h)
+    live = make_hip()
+    live.init(w, h)
+    base.upload(live)
+    live.set_setting("jitter", "center")
+    live.set_setting("stage_timing", 1)
+    for frame in (1.0, 2.5, 4.0):
+        pose = pkg.scenes.skinned_tube(frame=frame, rings=80, seg=48, width=w, height=h)
+        m = pose.meshes[0]
+        live.set_mesh(0, m["vertices"], m["triangles"], m["indices"])
+        live.update()
+        live.render_frame(pose.camera, pkg.RESET)
+        fresh, ref = _pair(pkg, make_hip, make_oracle, pose, w, h, {"integrator": "parity", "jitter": "center"})
+        assert image_stats(live.framebuffer(), fresh.framebuffer(), 1e-4)[0] <= 1e-3
+        assert image_stats(live.framebuffer(), ref.framebuffer(), 1e-3)[0] <= 2e-3
+    ms, launches = live.get_kernel_time("refit")
+    assert launches == 6 and ms > 0.0
+
+
+def test_two_ranks_on_one_device(pkg, make_hip):
+    """The multi-GPU data path on one GPU: two contexts own the interleaved strips of one frame; their local
+    framebuffers, concatenated the way the RCCL gather delivers them, de-interleave to the single-rank image."""
+    import torch
+    w, h = 640, 360
+    scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+    def render(rank, world):
+        c = make_hip(rank, world)
+        c.init(w, h)
+        scene.upload(c)
+        c.set_setting("integrator", "pt")
+        c.set_setting("spp", 4)
+        c.render_frame(scene.camera, pkg.RESET)
+        return c
+    single = render(0, 1)
+    ranks = [render(r, 3) for r in range(3)]
+    rows = ranks[0].local_rows()
+    gathered = torch.empty((3, rows, w, 4), dtype=torch.float32, device="cuda:0")
+    for r, c in enumerate(ranks):
+        c.read_local_framebuffer_device(gathered[r].data_ptr())
+    full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ranks[0].deinterleave_device(gathered.data_ptr(), full.data_ptr())
+    assert np.array_equal(full.cpu().numpy(), single.framebuffer())
