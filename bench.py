@@ -191,6 +191,9 @@ def main():
                         "rays_per_sample": cnt["rays_extend"] / max(1.0, primaries),
                         "shadow_rays_per_sample": cnt["rays_shadow"] / max(1.0, primaries)},
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
+            # the BVH (32 MB nodes + 48 MB vertices) is L2 / Infinity-Cache resident, so the algorithmic byte rate is
+            # not an HBM rate and can exceed the HBM peak; the PMC-measured HBM rate of the same launches:
+            "hbm_traffic_gbs": round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if (traffic and ms_per_launch > 0) else None,
         }
 
     # ---- CPU baseline: the oracle (a port, not the reference build) on this box's host cores ----------------------------
