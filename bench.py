@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--integrator", default="pt", choices=["pt", "parity"])
     ap.add_argument("--max-depth", type=int, default=2)
     ap.add_argument("--refill", type=int, default=3, help="persistent-lane traversal on the bounce / shadow waves")
+    ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -101,6 +102,7 @@ def main():
     ctx.set_setting("stage_timing", 1)
     ctx.set_setting("count_traversal", 0)
     ctx.set_setting("refill", args.refill)
+    ctx.set_setting("streams", args.streams)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()

@@ -111,6 +111,7 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)
  *   count_traversal = "0"|"1": instrumented traversal (popped inner nodes / triangle tests), for the roofline
  *   lds_nodes    = number of top-of-tree BVH node pairs staged in LDS per workgroup (0 disables)
+ *   streams      = sub-batches of one render call that run concurrently on their own HIP streams (1..8, default 4)
  *   refill       = "1"|"0": persistent lanes on the incoherent waves (a lane that finishes its ray pulls the next)
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);

@@ -160,6 +160,11 @@ static float event_ms(event_t a, event_t b)
 		return 0.0f;
 	return ms;
 }
+static int stream_wait_event(void *s, event_t e)
+{
+	DM_CHECK(hipStreamWaitEvent((hipStream_t)s, e, 0));
+	return 0;
+}
 #else
 // ---- host emulation (tests/emu): plain heap memory, "streams" are immediate ----
 static int init(int, int *cus)
@@ -211,6 +216,7 @@ static int event_record(event_t &e, void *)
 	return 0;
 }
 static float event_ms(event_t a, event_t b) { return std::chrono::duration<float, std::milli>(b - a).count(); }
+static int stream_wait_event(void *, event_t) { return 0; }
 #endif
 } // namespace dm
 
@@ -295,7 +301,13 @@ struct TimedSpan
 struct rfwhip_context
 {
 	int device = 0, rank = 0, world = 1, cus = 256;
-	void *stream = nullptr;
+	void *stream = nullptr; // stream 0: prologue, sub-batch 0, resolve, presents
+	static constexpr int MAX_SUB = 8;
+	void *sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	DevBuf d_counters_sub[MAX_SUB]; // [0] is d_counters' alias slot (unused), 1.. are the extra sub-batches' counters
+	dm::event_t ev_prologue, ev_resolve, ev_sub_done[MAX_SUB];
+	bool events_ready = false;
+	int subs_last = 1; // sub-batches of the most recent render call
 	bool cleaned = false;
 	uint32_t W = 0, H = 0;
 
@@ -308,6 +320,7 @@ struct rfwhip_context
 	int count_traversal = 0;
 	int lds_nodes = 0;
 	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
+	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 
 	// scene (host side)
 	std::vector<MeshRec> meshes;
@@ -436,6 +449,8 @@ static uint32_t local_rows_of(const rfwhip_context *c)
 	return ((strips + c->world - 1) / c->world) * rt::STRIP_ROWS;
 }
 
+static int sync_all(rfwhip_context *c);
+
 // =================================================================================================================
 // lifetime
 // =================================================================================================================
@@ -482,6 +497,20 @@ static void free_all(rfwhip_context *c)
 	for (auto &e : c->event_pool)
 		dm::event_destroy(e);
 	c->event_pool.clear();
+	for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
+		c->d_counters_sub[i].free_();
+	if (c->events_ready)
+	{
+		dm::event_destroy(c->ev_prologue), dm::event_destroy(c->ev_resolve);
+		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
+			dm::event_destroy(c->ev_sub_done[i]);
+		c->events_ready = false;
+	}
+	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
+	{
+		dm::stream_destroy(c->sub_stream[i]);
+		c->sub_stream[i] = nullptr;
+	}
 	c->wave_capacity = 0;
 	c->blas_nodes = 0, c->node_capacity = 0;
 }
@@ -522,7 +551,7 @@ extern "C" int rfwhip_init(rfwhip_context *c, uint32_t width, uint32_t height)
 	CTX_ENTER(c);
 	if (!width || !height || width > 65536 || height > 65536)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_init: bad target size %ux%u", width, height);
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	c->W = width, c->H = height;
 	const uint32_t lr = local_rows_of(c);
 	RF_TRY(c->d_acc.ensure((size_t)lr * width * sizeof(f4)));
@@ -546,7 +575,7 @@ extern "C" int rfwhip_set_sky(rfwhip_context *c, const float *rgb, size_t width,
 	std::vector<f4> px(width * height);
 	for (size_t i = 0; i < width * height; i++)
 		px[i] = f4{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 0.0f};
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	RF_TRY(c->d_sky.ensure(px.size() * sizeof(f4)));
 	RF_TRY(dm::h2d(c->d_sky.p, px.data(), px.size() * sizeof(f4), c->stream));
 	RF_TRY(dm::sync(c->stream));
@@ -585,7 +614,7 @@ extern "C" int rfwhip_set_textures(rfwhip_context *c, const rfwhip_texture *tex,
 		else
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_textures: texture %zu has unknown type %u", i, tex[i].type);
 	}
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	RF_TRY(c->d_textures.ensure(desc.size() * sizeof(rt::TexDesc)));
 	RF_TRY(c->d_tex_u32.ensure(u32.size() * 4));
 	RF_TRY(c->d_tex_f4.ensure(f4s.size() * sizeof(f4)));
@@ -605,7 +634,7 @@ extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *ma
 	CTX_ENTER(c);
 	if (count && !materials)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_materials: null array");
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	RF_TRY(c->d_materials.ensure(count * sizeof(rfwhip_material)));
 	RF_TRY(dm::h2d(c->d_materials.p, materials, count * sizeof(rfwhip_material), c->stream));
 	RF_TRY(dm::sync(c->stream));
@@ -661,7 +690,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	MeshRec &m = c->meshes[index];
 	const bool same_topology = m.used && m.resident && !m.dirty && m.vertexCount == mesh->vertexCount &&
 							   m.triCount == mesh->triangleCount && m.indexed == (mesh->indices != nullptr);
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	// vertices / indices always go to the device (the refit kernels read them there)
 	RF_TRY(m.d_verts.ensure(mesh->vertexCount * sizeof(f4)));
 	RF_TRY(dm::h2d(m.d_verts.p, mesh->vertices, mesh->vertexCount * sizeof(f4), c->stream));
@@ -785,7 +814,7 @@ extern "C" int rfwhip_set_lights(rfwhip_context *c, rfwhip_light_count n, const 
 	if ((n.areaLightCount && !area) || (n.pointLightCount && !point) || (n.spotLightCount && !spot) ||
 		(n.directionalLightCount && !directional))
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_lights: count > 0 with a null array");
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	RF_TRY(c->d_area.ensure(n.areaLightCount * sizeof(rfwhip_area_light)));
 	RF_TRY(c->d_point.ensure(n.pointLightCount * sizeof(rfwhip_point_light)));
 	RF_TRY(c->d_spot.ensure(n.spotLightCount * sizeof(rfwhip_spot_light)));
@@ -803,7 +832,7 @@ extern "C" int rfwhip_set_lights(rfwhip_context *c, rfwhip_light_count n, const 
 extern "C" int rfwhip_update(rfwhip_context *c)
 {
 	CTX_ENTER(c);
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	// ---- place meshes in the global arrays (only when some mesh was rebuilt) ----
 	bool relayout = false;
 	size_t live_instances = 0;
@@ -994,11 +1023,12 @@ extern "C" void rfwhip_camera_get_view(const rfwhip_camera *cam, rfwhip_camera_v
 // =================================================================================================================
 // render
 // =================================================================================================================
+static int sync_all(rfwhip_context *c);
 static int ensure_wave_buffers(rfwhip_context *c, size_t paths)
 {
 	if (paths <= c->wave_capacity)
 		return 0;
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	const size_t b16 = paths * sizeof(f4);
 	for (int k = 0; k < 2; k++)
 	{
@@ -1034,13 +1064,15 @@ struct StageTimer
 	rfwhip_context *c;
 	size_t ia = 0, ib = 0;
 	bool on;
-	StageTimer(rfwhip_context *ctx, int family, int depth) : c(ctx), on(ctx->stage_timing != 0)
+	void *stream;
+	StageTimer(rfwhip_context *ctx, int family, int depth, void *st = nullptr)
+		: c(ctx), on(ctx->stage_timing != 0), stream(st ? st : ctx->stream)
 	{
 		if (!on)
 			return;
 		next_event(c), ia = c->events_used - 1;
 		next_event(c), ib = c->events_used - 1;
-		dm::event_record(c->event_pool[ia], c->stream);
+		dm::event_record(c->event_pool[ia], stream);
 		fam = family, dep = depth;
 	}
 	int fam = 0, dep = 0;
@@ -1048,7 +1080,7 @@ struct StageTimer
 	{
 		if (!on)
 			return;
-		dm::event_record(c->event_pool[ib], c->stream);
+		dm::event_record(c->event_pool[ib], stream);
 		TimedSpan s;
 		s.a = c->event_pool[ia], s.b = c->event_pool[ib], s.family = fam, s.depth = dep;
 		c->spans.push_back(s);
@@ -1089,6 +1121,45 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	p.refill = (uint32_t)c->refill;
 }
 
+static int sync_all(rfwhip_context *c)
+{
+	RF_TRY(dm::sync(c->stream));
+	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
+		if (c->sub_stream[i])
+			RF_TRY(dm::sync(c->sub_stream[i]));
+	return 0;
+}
+
+static int ensure_sub_batches(rfwhip_context *c, int subs)
+{
+	if (!c->events_ready)
+	{
+		RF_TRY(dm::event_create(&c->ev_prologue));
+		RF_TRY(dm::event_create(&c->ev_resolve));
+		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
+			RF_TRY(dm::event_create(&c->ev_sub_done[i]));
+		c->events_ready = true;
+	}
+	c->sub_stream[0] = c->stream;
+	for (int i = 1; i < subs; i++)
+	{
+		if (!c->sub_stream[i])
+			RF_TRY(dm::stream_create(&c->sub_stream[i]));
+		if (!c->d_counters_sub[i].p)
+		{
+			RF_TRY(c->d_counters_sub[i].ensure(sizeof(rt::WaveCounters)));
+			RF_TRY(dm::zero(c->d_counters_sub[i].p, sizeof(rt::WaveCounters), c->stream));
+			RF_TRY(dm::sync(c->stream));
+		}
+	}
+	return 0;
+}
+
+// One render call = `spp` samples per pixel.  The samples are cut into up to `streams` sub-batches that run the whole
+// wavefront pipeline concurrently on their own HIP streams (own slices of the path buffers, own device counters):
+// every traversal kernel ends with a tail in which a few long rays keep a handful of waves busy — a chain of ~150
+// dependent node fetches at ~1 us each out of the Infinity Cache — and the other sub-batches' kernels fill the CUs
+// during that tail.  The accumulator is touched by one resolve kernel over all sub-batches at the end (stream 0).
 extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int status)
 {
 	CTX_ENTER(c);
@@ -1103,86 +1174,120 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
 	if (paths >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "spp batch too large: %zu path slots (limit 2^31)", paths);
+	if (paths > c->wave_capacity)
+		RF_TRY(sync_all(c));
 	RF_TRY(ensure_wave_buffers(c, paths));
+	const int subs = std::max(1, std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp));
+	RF_TRY(ensure_sub_batches(c, subs));
 	if (!c->render_pending)
 	{
 		c->render_t0 = std::chrono::steady_clock::now();
 		c->render_pending = true;
 	}
-	void *s = c->stream;
+	void *s0 = c->stream;
+	// ---- prologue on stream 0 ----
 	if (status == RFWHIP_RESET)
 	{
-		RF_TRY(dm::zero(c->d_acc.p, (size_t)c->fr.local_rows * c->W * sizeof(f4), s));
+		RF_TRY(dm::zero(c->d_acc.p, (size_t)c->fr.local_rows * c->W * sizeof(f4), s0));
 		c->samples_done = 0;
 	}
-	rtk::Params p;
-	fill_params(c, cam, p);
+	const uint32_t packets = (c->W / 4u) * (c->H / 2u);
+	if (c->integrator == 0 && c->jitter == 0)
+	{
+		// per-packet xor128 states for the whole batch (global packet order => image independent of world)
+		StageTimer tg(c, KF_GENERATE, -1);
+		if (!c->jump_table_uploaded)
+		{
+			RF_TRY(c->d_jump_table.ensure(c->jump_table.size() * 4));
+			RF_TRY(dm::h2d(c->d_jump_table.p, c->jump_table.data(), c->jump_table.size() * 4, s0));
+			c->jump_table_uploaded = true;
+		}
+		if ((size_t)std::max(1u, packets) * c->spp * 16 > c->d_packet_rng.cap)
+			RF_TRY(sync_all(c));
+		RF_TRY(c->d_packet_rng.ensure((size_t)std::max(1u, packets) * c->spp * 16));
+		if (packets)
+			rtk::launch_rng_states(c->d_packet_rng.as<uint32_t>(), c->rng_state, c->d_jump_table.as<uint32_t>(), packets,
+								   (uint32_t)c->spp, s0);
+		tg.stop();
+		xor128_jump(c->jump_table, c->rng_state, (unsigned long long)packets * 32ull * (unsigned long long)c->spp);
+	}
+	if (subs > 1)
+		RF_TRY(dm::event_record(c->ev_prologue, s0));
 	const bool count = c->count_traversal != 0;
-	const uint32_t n = (uint32_t)paths;
-	rtk::launch_init_counters(p.wv.counters, n, s);
-	uint32_t queue = 0;						   // every traversal launch pulls from its own chunk queue
 	const uint32_t row_group = std::max(1u, c->fr.tiles_x / 4u); // primary wave: one row of 8x8 tiles per XCD group
-	if (c->integrator == 0)
+	rtk::Params base;
+	fill_params(c, cam, base);
+	// ---- sub-batches ----
+	for (int i = 0; i < subs; i++)
 	{
-		if (c->jitter == 0)
+		void *s = c->sub_stream[i];
+		const uint32_t s_begin = (uint32_t)((long long)c->spp * i / subs), s_end = (uint32_t)((long long)c->spp * (i + 1) / subs);
+		const uint32_t spp_i = s_end - s_begin;
+		if (!spp_i)
+			continue;
+		if (i > 0)
+			RF_TRY(dm::stream_wait_event(s, c->ev_prologue)); // also orders it behind the previous call's resolve
+		rtk::Params p = base;
+		const size_t off = (size_t)c->fr.slots * s_begin; // this sub-batch's slice of every per-path buffer
+		for (int k = 0; k < 2; k++)
+			p.wv.org[k] += off, p.wv.dir[k] += off, p.wv.thr[k] += off;
+		p.wv.hit += off, p.wv.hit_inst += off, p.wv.hit0 += off, p.wv.hit0_inst += off;
+		p.wv.sh_org += off, p.wv.sh_dir += off, p.wv.sh_rad += off, p.wv.rad += off;
+		if (p.wv.packet_rng)
+			p.wv.packet_rng += (size_t)s_begin * packets * 4;
+		if (i > 0)
+			p.wv.counters = c->d_counters_sub[i].as<rt::WaveCounters>();
+		p.fr.spp = spp_i;
+		p.fr.sample_base = c->samples_done + s_begin;
+		const uint32_t n = c->fr.slots * spp_i;
+		rtk::launch_init_counters(p.wv.counters, n, s);
+		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
+		if (c->integrator == 0)
 		{
-			// per-packet xor128 states for the whole batch (global packet order => image independent of world)
-			const uint32_t packets = (c->W / 4u) * (c->H / 2u);
-			StageTimer tg(c, KF_GENERATE, -1);
-			if (!c->jump_table_uploaded)
-			{
-				RF_TRY(c->d_jump_table.ensure(c->jump_table.size() * 4));
-				RF_TRY(dm::h2d(c->d_jump_table.p, c->jump_table.data(), c->jump_table.size() * 4, s));
-				c->jump_table_uploaded = true;
-			}
-			RF_TRY(c->d_packet_rng.ensure((size_t)std::max(1u, packets) * c->spp * 16));
-			p.wv.packet_rng = c->d_packet_rng.as<uint32_t>();
-			if (packets)
-				rtk::launch_rng_states(c->d_packet_rng.as<uint32_t>(), c->rng_state, c->d_jump_table.as<uint32_t>(), packets,
-									   (uint32_t)c->spp, s);
-			tg.stop();
-			xor128_jump(c->jump_table, c->rng_state, (unsigned long long)packets * 32ull * (unsigned long long)c->spp);
-		}
-		p.depth = 0;
-		p.group = row_group;
-		p.queue = queue++;
-		StageTimer te(c, KF_EXTEND, 0);
-		rtk::launch_extend(p, rtk::GEN_PARITY, count, n, s);
-		te.stop();
-		p.queue = queue++;
-		StageTimer ts(c, KF_SHADE, -1);
-		rtk::launch_shade_parity(p, count, n, s);
-		ts.stop();
-	}
-	else
-	{
-		for (int d = 0; d <= c->max_depth; d++)
-		{
-			p.depth = (uint32_t)d;
-			p.group = d == 0 ? row_group : 16u;
-			p.queue = queue++;
-			StageTimer te(c, KF_EXTEND, d);
-			rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+			p.depth = 0, p.group = row_group, p.queue = queue++;
+			StageTimer te(c, KF_EXTEND, 0, s);
+			rtk::launch_extend(p, rtk::GEN_PARITY, count, n, s);
 			te.stop();
-			StageTimer ts(c, KF_SHADE, -1);
-			rtk::launch_shade_pt(p, n, s);
+			p.queue = queue++;
+			StageTimer ts(c, KF_SHADE, -1, s);
+			rtk::launch_shade_parity(p, count, n, s);
 			ts.stop();
-			if (total_light_count(c))
+		}
+		else
+		{
+			for (int d = 0; d <= c->max_depth; d++)
 			{
-				p.group = 16u;
+				p.depth = (uint32_t)d;
+				p.group = d == 0 ? row_group : 16u;
 				p.queue = queue++;
-				StageTimer tc(c, KF_CONNECT, -1);
-				rtk::launch_connect(p, count, n, s);
-				tc.stop();
+				StageTimer te(c, KF_EXTEND, d, s);
+				rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+				te.stop();
+				StageTimer ts(c, KF_SHADE, -1, s);
+				rtk::launch_shade_pt(p, n, s);
+				ts.stop();
+				if (total_light_count(c))
+				{
+					p.group = 16u, p.queue = queue++;
+					StageTimer tc(c, KF_CONNECT, -1, s);
+					rtk::launch_connect(p, count, n, s);
+					tc.stop();
+				}
 			}
 		}
+		if (i > 0)
+			RF_TRY(dm::event_record(c->ev_sub_done[i], s));
 	}
+	// ---- epilogue on stream 0: one resolve over every sample of the call ----
+	for (int i = 1; i < subs; i++)
+		RF_TRY(dm::stream_wait_event(s0, c->ev_sub_done[i]));
 	{
 		StageTimer tf(c, KF_FINALIZE, -1);
-		rtk::launch_resolve(p, s);
+		rtk::launch_resolve(base, s0);
 		tf.stop();
 	}
 	RF_TRY(dm::last_launch_error());
+	c->subs_last = subs;
 	c->samples_done += (uint32_t)c->spp;
 	c->totals.samples += (uint64_t)c->W * c->H * (uint64_t)c->spp / (uint64_t)c->world;
 	return RFWHIP_OK;
@@ -1191,10 +1296,17 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 extern "C" int rfwhip_wait(rfwhip_context *c)
 {
 	CTX_ENTER(c);
-	RF_TRY(dm::sync(c->stream));
-	// wave counters of the last frame
+	RF_TRY(sync_all(c));
+	// wave counters of the last frame, summed over its sub-batches
 	rt::WaveCounters wc;
 	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	for (int i = 1; i < c->subs_last; i++)
+	{
+		rt::WaveCounters w2;
+		RF_TRY(dm::d2h(&w2, c->d_counters_sub[i].p, sizeof(w2), c->stream));
+		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+			wc.ext[d] += w2.ext[d], wc.shadow[d] += w2.shadow[d];
+	}
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
 	rfwhip_render_stats &st = c->stats;
@@ -1338,7 +1450,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -1386,6 +1498,13 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->lds_nodes = std::max(0, atoi(value));
 	else if (k == "refill")
 		c->refill = atoi(value) & 3; // bit 0: extension waves, bit 1: shadow waves
+	else if (k == "streams")
+	{
+		const int n = atoi(value);
+		if (n < 1 || n > rfwhip_context::MAX_SUB)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "streams must be in [1, %d]", (int)rfwhip_context::MAX_SUB);
+		c->streams = n;
+	}
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
@@ -1413,6 +1532,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->lds_nodes);
 	else if (k == "refill")
 		snprintf(value, cap, "%d", c->refill);
+	else if (k == "streams")
+		snprintf(value, cap, "%d", c->streams);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
@@ -1432,20 +1553,29 @@ extern "C" int rfwhip_get_counters(rfwhip_context *c, rfwhip_counters *out, int 
 	CTX_ENTER(c);
 	if (!out)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null counters");
-	RF_TRY(dm::sync(c->stream));
-	rt::WaveCounters wc;
-	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
-	out->rays_extend = wc.rays_extend, out->rays_shadow = wc.rays_shadow;
-	out->inner_extend = wc.inner_extend, out->tris_extend = wc.tris_extend;
-	out->inner_shadow = wc.inner_shadow, out->tris_shadow = wc.tris_shadow;
-	out->shaded = wc.shaded, out->samples = c->totals.samples;
-	if (reset)
+	RF_TRY(sync_all(c));
+	memset(out, 0, sizeof(*out));
+	for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
 	{
-		wc.rays_extend = wc.rays_shadow = wc.inner_extend = wc.tris_extend = wc.inner_shadow = wc.tris_shadow = wc.shaded = 0;
-		RF_TRY(dm::h2d(c->d_counters.p, &wc, sizeof(wc), c->stream));
-		RF_TRY(dm::sync(c->stream));
-		c->totals.samples = 0;
+		void *buf = i == 0 ? c->d_counters.p : c->d_counters_sub[i].p;
+		if (!buf)
+			continue;
+		rt::WaveCounters wc;
+		RF_TRY(dm::d2h(&wc, buf, sizeof(wc), c->stream));
+		out->rays_extend += wc.rays_extend, out->rays_shadow += wc.rays_shadow;
+		out->inner_extend += wc.inner_extend, out->tris_extend += wc.tris_extend;
+		out->inner_shadow += wc.inner_shadow, out->tris_shadow += wc.tris_shadow;
+		out->shaded += wc.shaded;
+		if (reset)
+		{
+			wc.rays_extend = wc.rays_shadow = wc.inner_extend = wc.tris_extend = wc.inner_shadow = wc.tris_shadow = wc.shaded = 0;
+			RF_TRY(dm::h2d(buf, &wc, sizeof(wc), c->stream));
+			RF_TRY(dm::sync(c->stream));
+		}
 	}
+	out->samples = c->totals.samples;
+	if (reset)
+		c->totals.samples = 0;
 	return RFWHIP_OK;
 }
 
@@ -1468,7 +1598,7 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	CTX_ENTER(c);
 	if (!c->W || c->wave_capacity == 0)
 		return set_error(RFWHIP_ERR_STATE, "no frame rendered yet");
-	RF_TRY(dm::sync(c->stream));
+	RF_TRY(sync_all(c));
 	const size_t slots = c->fr.slots;
 	std::vector<f4> h(slots);
 	std::vector<int> hi(slots);
@@ -1530,6 +1660,7 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 		return RFWHIP_OK;
 	if (n >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_trace_rays: too many rays");
+	RF_TRY(sync_all(c)); // the wave buffers are shared with the sub-batch streams of a render in flight
 	RF_TRY(ensure_wave_buffers(c, n));
 	std::vector<f4> o4(n), d4(n);
 	for (size_t i = 0; i < n; i++)
@@ -1586,7 +1717,7 @@ extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_n
 		const size_t n = std::min(node_cap, m.bvh.nodes.size());
 		if (m.resident)
 		{
-			RF_TRY(dm::sync(c->stream));
+			RF_TRY(sync_all(c));
 			RF_TRY(dm::d2h(nodes, c->d_nodes.as<rt::Node>() + m.node_base, n * sizeof(rt::Node), c->stream));
 			for (size_t k = 0; k < n; k++) // device nodes carry packed entries: hand out the reference layout
 				nodes[k].left_first = m.bvh.nodes[k].left_first;

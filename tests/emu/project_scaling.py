@@ -1,0 +1,46 @@
+"""Development probe (1-GPU box): what would one rank of an N-GPU strip split cost per step?
+
+Runs rank r of world N alone on cuda:0 (same scene, same camera, its interleaved strips only), including everything
+bench.py does per step on a rank except the RCCL gather itself (wait, local present into a torch tensor, and on
+"rank 0" the de-interleave of a full-size gathered buffer).  Prints the slowest rank's ms/step and the projected
+efficiency  t1 / (N * tN)  — a projection, NOT a measurement of the 8-GPU run (the driver does that)."""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from __graft_entry__ import load_package
+pkg = load_package()
+W, H = 1920, 1080
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+scene = pkg.scenes.terrain(n=708, width=W, height_px=H)
+
+def run(rank, world, steps=10, warm=3):
+    ctx = pkg.RenderContext(0, rank, world); ctx.init(W, H); scene.upload(ctx)
+    ctx.set_setting("integrator", "pt"); ctx.set_setting("spp", spp)
+    rows = ctx.local_rows()
+    local = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0")
+    flat = torch.empty((world, rows, W, 4), dtype=torch.float32, device="cuda:0")
+    full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    def step(first):
+        ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
+        if world > 1:
+            ctx.wait()
+            ctx.read_local_framebuffer_device(local.data_ptr())
+            flat[rank].copy_(local)                      # stands in for the gather's landing copy
+            if rank == 0:
+                torch.cuda.synchronize()
+                ctx.deinterleave_device(flat.data_ptr(), full.data_ptr())
+    for k in range(warm): step(k == 0)
+    ctx.wait(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for k in range(steps): step(k == 0)
+    ctx.wait(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps * 1e3
+    ctx.destroy()
+    return dt
+
+t1 = run(0, 1)
+print("spp", spp, "world 1: %.3f ms/step" % t1, flush=True)
+for world in (2, 4, 8):
+    ts = [run(r, world) for r in range(world)]
+    tn = max(ts)
+    print("world %d: slowest rank %.3f ms/step (min %.3f)  projected efficiency %.3f" % (world, tn, min(ts), t1 / (world * tn)), flush=True)
