@@ -267,4 +267,74 @@ void build(const float *bmin, const float *bmax, size_t n, int max_leaf, int dep
 	}
 }
 
+namespace
+{
+float node_area(const rt::Node &n)
+{
+	const float e0 = n.bmax[0] - n.bmin[0], e1 = n.bmax[1] - n.bmin[1], e2 = n.bmax[2] - n.bmin[2];
+	return e0 * e1 + e0 * e2 + e1 * e2;
+}
+uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4> &out)
+{
+	const uint32_t idx = (uint32_t)out.size();
+	out.emplace_back();
+	int kids[4] = {b.nodes[n2].left_first, b.nodes[n2].left_first + 1, -1, -1};
+	int nk = 2;
+	while (nk < 4)
+	{
+		int best = -1;
+		float best_area = -1.0f;
+		for (int k = 0; k < nk; k++)
+			if (b.nodes[kids[k]].count < 0 && node_area(b.nodes[kids[k]]) > best_area)
+				best = k, best_area = node_area(b.nodes[kids[k]]);
+		if (best < 0)
+			break;
+		const int l = b.nodes[kids[best]].left_first;
+		kids[best] = l;
+		kids[nk++] = l + 1;
+	}
+	rt::Node4 nd;
+	for (int k = 0; k < 4; k++)
+	{
+		if (k < nk)
+		{
+			const rt::Node &c = b.nodes[kids[k]];
+			for (int a = 0; a < 3; a++)
+				nd.lo[a][k] = c.bmin[a], nd.hi[a][k] = c.bmax[a];
+			nd.src[k] = (uint32_t)kids[k];
+			nd.entry[k] = 0; // filled below (inner children are created after this node: depth-first order)
+		}
+		else
+		{
+			for (int a = 0; a < 3; a++)
+				nd.lo[a][k] = 1e34f, nd.hi[a][k] = 1e34f; // a far-away point: tmax > tmin never holds for it
+			nd.src[k] = 0xFFFFFFFFu;
+			nd.entry[k] = rt::ENTRY_EMPTY;
+		}
+	}
+	out[idx] = nd;
+	for (int k = 0; k < nk; k++)
+	{
+		const rt::Node &c = b.nodes[kids[k]];
+		uint32_t e;
+		if (c.count >= 0)
+			e = rt::make_entry(c.left_first, c.count, tlas);
+		else
+			e = rt::make_entry((int)collapse_node(b, kids[k], tlas, out), -1, tlas);
+		out[idx].entry[k] = e;
+	}
+	return idx;
+}
+} // namespace
+
+bool collapse4(const Result &bvh2, bool tlas, std::vector<rt::Node4> &out)
+{
+	out.clear();
+	if (bvh2.nodes.empty() || bvh2.nodes[0].count >= 0)
+		return false;
+	out.reserve(bvh2.nodes.size() / 3 + 2);
+	collapse_node(bvh2, 0, tlas, out);
+	return true;
+}
+
 } // namespace bvh

@@ -22,4 +22,9 @@ struct Result
 // the reference delegates construction to an external crate (RFW/system/bvh/src/bvh_tree.cpp:74-95).
 void build(const float *bmin, const float *bmax, size_t n, int max_leaf, int depth_limit, Result &out);
 
+// Collapse the binary tree into 4-wide nodes (greedy: open the inner child with the largest surface area until four
+// children).  Entries are relative: inner = index into `out`, leaf = make_entry(first, count) of the BVH2 leaf; `tlas`
+// sets ENTRY_TLAS on every entry.  Returns false when the root itself is a leaf (no 4-wide node needed).
+bool collapse4(const Result &bvh2, bool tlas, std::vector<rt::Node4> &out);
+
 } // namespace bvh

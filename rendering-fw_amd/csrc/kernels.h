@@ -54,4 +54,7 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 				  uint32_t tri_base, const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags,
 				  stream_t s);
 
+// after a refit of the BVH2 boxes: copy them into the 4-wide traversal nodes of the same BLAS (Node4::src)
+void launch_refresh4(rt::Node4 *nodes4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
+
 } // namespace rtk

@@ -408,6 +408,19 @@ RT_FN void rng_states_item(uint32_t *states, const uint32_t base[4], const uint3
 	}
 }
 
+RT_FN void refresh4_item(Node4 *nodes4, const Node *nodes2, uint32_t i)
+{
+	Node4 &n = nodes4[i];
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t src = n.src[k];
+		if (src == 0xFFFFFFFFu)
+			continue;
+		for (int a = 0; a < 3; a++)
+			n.lo[a][k] = nodes2[src].bmin[a], n.hi[a][k] = nodes2[src].bmax[a];
+	}
+}
+
 // refit, pass 1: rewrite the leaf-ordered triangle vertices from the new mesh vertices
 RT_FN void refit_tris_item(f4 *tri_verts, const f4 *verts, const uint32_t *indices, uint32_t slot)
 {
@@ -729,6 +742,13 @@ __global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *all_nodes, uint32_t
 	}
 }
 
+__global__ void __launch_bounds__(BLOCK) k_refresh4(Node4 *nodes4, uint32_t count4, const Node *nodes2)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < count4)
+		refresh4_item(nodes4, nodes2, i);
+}
+
 static inline uint32_t persistent_grid(uint32_t items)
 {
 	uint32_t blocks = (items + BLOCK - 1) / BLOCK;
@@ -851,6 +871,12 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 					   local_rows, world);
 }
 
+void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t s)
+{
+	if (count4)
+		hipLaunchKernelGGL(k_refresh4, dim3((count4 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, nodes4, count4, blas_nodes2);
+}
+
 void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
 				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t s)
 {
@@ -927,6 +953,11 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 {
 	for (uint32_t i = 0; i < W * H; i++)
 		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t)
+{
+	for (uint32_t i = 0; i < count4; i++)
+		refresh4_item(nodes4, blas_nodes2, i);
 }
 void launch_refit(Node *all_nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
 				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)

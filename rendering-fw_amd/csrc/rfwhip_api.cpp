@@ -261,6 +261,8 @@ struct MeshRec
 	size_t vertexCount = 0, triCount = 0;
 	bool indexed = false;
 	bvh::Result bvh;				   // host copy of the topology as built
+	std::vector<rt::Node4> n4;		   // 4-wide traversal nodes collapsed from it (relative entries)
+	uint32_t n4_base = 0;
 	std::vector<f4> leaf_verts;		   // 3 per leaf slot (host staging for (re)upload)
 	std::vector<rt::TriShade> shade;   // mesh order
 	float bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};
@@ -329,8 +331,8 @@ struct rfwhip_context
 	bool scene_dirty = true;
 
 	// scene (device side)
-	DevBuf d_nodes, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
-	size_t blas_nodes = 0, node_capacity = 0; // d_nodes = [all BLAS nodes | TLAS nodes | spare]
+	DevBuf d_nodes, d_nodes4, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
+	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
 	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
 	uint32_t tlas_root_entry = 0, instance_count = 0;
@@ -486,7 +488,7 @@ static void free_all(rfwhip_context *c)
 {
 	for (auto &m : c->meshes)
 		m.d_verts.free_(), m.d_indices.free_(), m.d_parents.free_(), m.d_flags.free_();
-	DevBuf *bufs[] = {&c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
+	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
 					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org, &c->d_sh_dir,
@@ -512,7 +514,7 @@ static void free_all(rfwhip_context *c)
 		c->sub_stream[i] = nullptr;
 	}
 	c->wave_capacity = 0;
-	c->blas_nodes = 0, c->node_capacity = 0;
+	c->blas_nodes4 = 0, c->node4_capacity = 0;
 }
 
 extern "C" int rfwhip_cleanup(rfwhip_context *c)
@@ -736,6 +738,8 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 						  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 						  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, m.d_flags.as<uint32_t>(),
 						  c->stream);
+		rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(),
+							 c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 		RF_TRY(dm::last_launch_error());
 		if (timed)
 			dm::event_record(eb, c->stream);
@@ -743,7 +747,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		if (timed)
 		{
 			c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
-			c->kernel_launches[KF_REFIT] += 2;
+			c->kernel_launches[KF_REFIT] += 3;
 			c->stats.animationTime = dm::event_ms(ea, eb);
 			dm::event_destroy(ea), dm::event_destroy(eb);
 		}
@@ -768,6 +772,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: BVH depth %d exceeds the traversal stack", m.bvh.max_depth);
 	for (int a = 0; a < 3; a++)
 		m.bounds_min[a] = m.bvh.nodes[0].bmin[a], m.bounds_max[a] = m.bvh.nodes[0].bmax[a];
+	bvh::collapse4(m.bvh, false, m.n4);
 	m.leaf_verts.resize(3 * n);
 	for (size_t s = 0; s < n; s++)
 	{
@@ -839,21 +844,23 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	for (auto &in : c->instances)
 		if (in.used)
 			live_instances++;
-	const size_t tlas_reserve = 2 * live_instances + 2; // a BVH2 over n leaves of one primitive has at most 2n nodes
+	const size_t tlas_reserve = live_instances + 2; // a 4-wide tree over n single-instance leaves has < n inner nodes
 	for (auto &m : c->meshes)
 		if (m.used && m.dirty)
 			relayout = true;
-	if (c->blas_nodes + tlas_reserve > c->node_capacity)
+	if (c->blas_nodes4 + tlas_reserve > c->node4_capacity)
 		relayout = true; // the TLAS lives behind the BLAS nodes in the same array: grow it together
 	if (relayout)
 	{
-		size_t nodes = 0, tris = 0;
+		size_t nodes = 0, tris = 0, nodes4 = 0;
 		for (auto &m : c->meshes)
 			if (m.used)
 			{
 				m.node_base = (uint32_t)nodes, m.tri_base = (uint32_t)tris, m.shade_base = (uint32_t)tris;
-				nodes += m.bvh.nodes.size(), tris += m.triCount;
+				m.n4_base = (uint32_t)nodes4;
+				nodes += m.bvh.nodes.size(), tris += m.triCount, nodes4 += m.n4.size();
 			}
+		std::vector<rt::Node4> all_nodes4(nodes4);
 		// resident meshes were refit on the device: save their current device data before the arrays move
 		std::vector<rt::Node> all_nodes(nodes);
 		std::vector<f4> all_verts(3 * tris);
@@ -873,14 +880,32 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				else if (nd.count < 0)
 					nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.node_base, nd.count, false);
 			}
+			// 4-wide traversal nodes: entries become absolute (node index into nodes4 / triangle index into tri_verts)
+			for (size_t k = 0; k < m.n4.size(); k++)
+			{
+				rt::Node4 nd = m.n4[k];
+				for (int j = 0; j < 4; j++)
+				{
+					const uint32_t e = nd.entry[j];
+					if (e == rt::ENTRY_EMPTY)
+						continue;
+					if (e & rt::ENTRY_LEAF)
+						nd.entry[j] = (e & ~rt::ENTRY_FIRST_MASK) | (((e & rt::ENTRY_FIRST_MASK) + m.tri_base) & rt::ENTRY_FIRST_MASK);
+					else
+						nd.entry[j] = e + m.n4_base;
+				}
+				all_nodes4[m.n4_base + k] = nd;
+			}
 			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
 			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
 		}
 		if (tris > rt::ENTRY_FIRST_MASK)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
-		c->blas_nodes = all_nodes.size();
-		c->node_capacity = all_nodes.size() + 2 * tlas_reserve + 64;
-		RF_TRY(c->d_nodes.ensure(c->node_capacity * sizeof(rt::Node)));
+		c->blas_nodes4 = all_nodes4.size();
+		c->node4_capacity = all_nodes4.size() + 2 * tlas_reserve + 64;
+		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
+		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4)));
+		RF_TRY(dm::h2d(c->d_nodes4.p, all_nodes4.data(), all_nodes4.size() * sizeof(rt::Node4), c->stream));
 		RF_TRY(c->d_tri_verts.ensure(all_verts.size() * sizeof(f4)));
 		RF_TRY(c->d_tri_shade.ensure(all_shade.size() * sizeof(rt::TriShade)));
 		RF_TRY(dm::h2d(c->d_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(rt::Node), c->stream));
@@ -898,6 +923,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 								  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 								  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount,
 								  m.d_flags.as<uint32_t>(), c->stream);
+				rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(),
+									 c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 				RF_TRY(dm::last_launch_error());
 			}
 			m.resident = true, m.dirty = false;
@@ -925,8 +952,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			for (int r = 0; r < 3; r++)
 				d.nrm[4 * col + r] = in.normal[3 * col + r];
 		d.node_base = m.node_base, d.tri_base = m.tri_base, d.shade_base = m.shade_base;
-		d.root_entry = rt::make_entry(m.bvh.nodes[0].left_first + (int)(m.bvh.nodes[0].count < 0 ? m.node_base : m.tri_base),
-									  m.bvh.nodes[0].count, false);
+		d.root_entry = m.bvh.nodes[0].count < 0 ? rt::make_entry((int)m.n4_base, -1, false)
+												: rt::make_entry(m.bvh.nodes[0].left_first + (int)m.tri_base, m.bvh.nodes[0].count, false);
 		float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
 		for (int k = 0; k < 8; k++)
 		{
@@ -950,29 +977,28 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	std::vector<uint32_t> tprims(std::max<size_t>(1, live.size()), 0u);
 	for (size_t k = 0; k < live.size(); k++)
 		tprims[k] = live[tl.order[k]];
-	if (tl.nodes.empty())
-		tl.nodes.resize(2);
-	if (c->blas_nodes + tl.nodes.size() > c->node_capacity)
+	std::vector<rt::Node4> tl4;
+	const bool tl_inner = bvh::collapse4(tl, true, tl4);
+	if (c->blas_nodes4 + tl4.size() > c->node4_capacity)
 		return set_error(RFWHIP_ERR_STATE, "internal: TLAS does not fit behind the BLAS nodes");
-	const int tlas_base = (int)c->blas_nodes; // even: every BLAS has an even node count
-	const int tl_root_left = tl.nodes[0].left_first, tl_root_count = tl.nodes[0].count;
-	for (rt::Node &nd : tl.nodes)
-	{
-		if (nd.count > 0)
-			nd.left_first = (int)rt::make_entry(nd.left_first, nd.count, true); // index into tlas_prims
-		else if (nd.count < 0)
-			nd.left_first = (int)rt::make_entry(nd.left_first + tlas_base, nd.count, true);
-	}
+	const uint32_t tlas_base = (uint32_t)c->blas_nodes4;
+	for (rt::Node4 &nd : tl4)
+		for (int j = 0; j < 4; j++)
+			if (nd.entry[j] != rt::ENTRY_EMPTY && !(nd.entry[j] & rt::ENTRY_LEAF))
+				nd.entry[j] += tlas_base; // inner: absolute node index; leaves index tlas_prims
 	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
 	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
 	RF_TRY(dm::h2d(c->d_instances.p, inst.data(), inst.size() * sizeof(rt::Instance), c->stream));
-	RF_TRY(dm::h2d(c->d_nodes.as<rt::Node>() + tlas_base, tl.nodes.data(), tl.nodes.size() * sizeof(rt::Node), c->stream));
+	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4>() + tlas_base, tl4.data(), tl4.size() * sizeof(rt::Node4), c->stream));
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
-	c->tlas_root_entry = live.empty() ? 0u : rt::make_entry(tl_root_count < 0 ? tl_root_left + tlas_base : tl_root_left, tl_root_count, true);
+	c->tlas_root_entry = live.empty() ? 0u
+						 : tl_inner	   ? rt::make_entry((int)tlas_base, -1, true)
+									   : rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true);
 
 	rt::SceneView &sv = c->sv;
+	sv.nodes4 = c->d_nodes4.as<rt::Node4>();
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
 	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
 	sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();

@@ -371,29 +371,95 @@ struct Traverser
 		return ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
 	}
 
-	// phase 1: walk inner nodes until this lane holds a leaf entry (or ENTRY_DONE)
+	// phase 1: walk 4-wide inner nodes until this lane holds a leaf entry (or ENTRY_DONE / ENTRY_SENTINEL)
 	RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
 		while (!(cur & ENTRY_LEAF))
 		{
-			const f4 *p = (const f4 *)(sc.nodes + (cur & ENTRY_INDEX_MASK));
-			const f4 a0 = p[0], b0 = p[1], a1 = p[2], b1 = p[3];
+			const f4 *p = (const f4 *)(sc.nodes4 + (cur & ENTRY_INDEX_MASK));
+			const f4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5], en = p[6];
 			if (COUNT)
 				st.inner++;
-			float n0, n1;
-			const bool h0 = slab(a0, b0, id, oid, hit.t, n0);
-			const bool h1 = slab(a1, b1, id, oid, hit.t, n1);
-			const uint32_t e0 = fbits(b0.z), e1 = fbits(b1.z);
-			if (h0 && h1)
+			// slab test of the four children (aabb.cpp:39-77 in fma form); a miss (and an empty slot: a point box at
+			// 1e34) gets distance +inf
+			const float INF = 3.0e38f;
+			float t0, t1, t2, t3;
+#define RT_SLAB4(K, OUT)                                                                                              \
+	{                                                                                                                 \
+		const float x1 = fmaf(lx.K, id.x, -oid.x), x2 = fmaf(hx.K, id.x, -oid.x);                                     \
+		const float y1 = fmaf(ly.K, id.y, -oid.y), y2 = fmaf(hy.K, id.y, -oid.y);                                     \
+		const float z1 = fmaf(lz.K, id.z, -oid.z), z2 = fmaf(hz.K, id.z, -oid.z);                                     \
+		const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));                                 \
+		const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));                                 \
+		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                             \
+	}
+			RT_SLAB4(x, t0)
+			RT_SLAB4(y, t1)
+			RT_SLAB4(z, t2)
+			RT_SLAB4(w, t3)
+#undef RT_SLAB4
+			uint32_t e0 = fbits(en.x), e1 = fbits(en.y), e2 = fbits(en.z), e3 = fbits(en.w);
+			if (!ANY)
 			{
-				const bool first0 = n0 < n1;
-				push(stk, first0 ? e1 : e0);
-				cur = first0 ? e0 : e1;
+				// order the four children by entry distance (5-comparator network), nearest first
+#define RT_CSWAP(TA, EA, TB, EB)              \
+	{                                         \
+		const bool sw = TB < TA;              \
+		const float tt = sw ? TB : TA;        \
+		const uint32_t ee = sw ? EB : EA;     \
+		TB = sw ? TA : TB, EB = sw ? EA : EB; \
+		TA = tt, EA = ee;                     \
+	}
+				RT_CSWAP(t0, e0, t1, e1)
+				RT_CSWAP(t2, e2, t3, e3)
+				RT_CSWAP(t0, e0, t2, e2)
+				RT_CSWAP(t1, e1, t3, e3)
+				RT_CSWAP(t1, e1, t2, e2)
+#undef RT_CSWAP
+				if (t0 < INF)
+				{
+					// far children first, so the nearest of them is popped first
+					if (t3 < INF)
+						push(stk, e3);
+					if (t2 < INF)
+						push(stk, e2);
+					if (t1 < INF)
+						push(stk, e1);
+					cur = e0;
+				}
+				else
+					cur = pop(stk);
 			}
-			else if (h0 || h1)
-				cur = h0 ? e0 : e1;
 			else
-				cur = pop(stk);
+			{
+				// occlusion query: any order will do
+				uint32_t next = ENTRY_DONE;
+				bool have = false;
+				if (t0 < INF)
+					next = e0, have = true;
+				if (t1 < INF)
+				{
+					if (have)
+						push(stk, e1);
+					else
+						next = e1, have = true;
+				}
+				if (t2 < INF)
+				{
+					if (have)
+						push(stk, e2);
+					else
+						next = e2, have = true;
+				}
+				if (t3 < INF)
+				{
+					if (have)
+						push(stk, e3);
+					else
+						next = e3, have = true;
+				}
+				cur = have ? next : pop(stk);
+			}
 		}
 	}
 

@@ -59,6 +59,21 @@ struct alignas(16) Node
 	int count;
 };
 
+// Traversal node: a 4-wide node collapsed from the BVH2 (128 bytes = eight 16-byte loads).  The bounce waves are bound
+// by the chain of dependent node fetches (~1 us each out of the Infinity Cache): a 4-wide node halves the
+// chain.  Child boxes are stored SoA (one float4 per plane, lane k = child k); an unused slot has a degenerate far-away box
+// (lo = hi = 1e34: the slab test's tmax > tmin never holds) and entry ENTRY_EMPTY.  src[k] is the BVH2 node (BLAS-relative) the child box was copied from — refit refreshes the boxes
+// from the refitted BVH2.
+constexpr uint32_t ENTRY_EMPTY = 0xFFFFFFFCu;
+struct alignas(16) Node4
+{
+	float lo[3][4];
+	float hi[3][4];
+	uint32_t entry[4]; // ready-made stack entries (absolute indices on the device)
+	uint32_t src[4];
+};
+static_assert(sizeof(Node4) == 128, "4-wide node");
+
 // Per-instance record (set_instance): inverse transform for rays, normal matrix for shading, BLAS location.
 struct alignas(16) Instance
 {
@@ -136,6 +151,7 @@ struct SceneView
 							 // ready-made stack entry with ABSOLUTE indices (node index into this array, leaf-ordered
 							 // triangle index into tri_verts): a traversal step is base + 32-bit offset, no per-lane
 							 // base pointers
+	const Node4 *nodes4;	 // traversal form: all BLAS 4-wide nodes, then the TLAS 4-wide nodes (absolute entries)
 	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
 	const TriShade *tri_shade;
 	const uint32_t *tlas_prims; // instance index per TLAS leaf slot

@@ -167,7 +167,7 @@ def test_skinned_tube_refit_on_device(pkg, make_hip, make_oracle):
         assert image_stats(live.framebuffer(), fresh.framebuffer(), 1e-4)[0] <= 1e-3
         assert image_stats(live.framebuffer(), ref.framebuffer(), 1e-3)[0] <= 2e-3
     ms, launches = live.get_kernel_time("refit")
-    assert launches == 6 and ms > 0.0
+    assert launches == 9 and ms > 0.0  # per refit: triangles, BVH2 boxes bottom-up, 4-wide node refresh
 
 
 def test_two_ranks_on_one_device(pkg, make_hip):
