@@ -12,7 +12,7 @@ Inputs (scene, BVH, path buffers) are resident in HBM before the timed region st
 
 The JSON line carries, besides the driver contract fields:
   roofline      dominant kernel (extend = closest-hit traversal): algorithmic bytes per SURVEY §8(d)
-                (ray 32 B in [+32 B out for generated primaries], 64 B per popped inner node, 52 B per triangle test,
+                (ray 32 B in [+32 B out for generated primaries], 112 B per popped 4-wide node, 52 B per triangle test,
                 16 B hit record out) from an instrumented replay of the same frames, divided by the kernel's mean
                 duration measured with hipEvents on the render stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle's restatement of the same integrator ("port") on the host cores, bounded sample.
@@ -44,9 +44,9 @@ def usable_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step (one wavefront batch)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one wavefront batch; config 3: >= 64 spp)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=708, help="terrain cells per side (708 -> 1 002 528 triangles)")
@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=2)
     ap.add_argument("--refill", type=int, default=3, help="persistent-lane traversal on the bounce / shadow waves")
     ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
+    ap.add_argument("--lds-nodes", type=int, default=-1,
+                    help="top-of-tree 4-wide nodes kept in LDS by the traversal kernels (-1: kernel capacity, 0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -103,12 +105,14 @@ def main():
     ctx.set_setting("count_traversal", 0)
     ctx.set_setting("refill", args.refill)
     ctx.set_setting("streams", args.streams)
+    ctx.set_setting("lds_nodes", args.lds_nodes)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()
     local_fb = torch.empty((local_rows, W, 4), dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(local_fb) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # the gather lands directly in the [world][local_rows][W] staging image the de-interleave kernel reads
     gathered_flat = torch.empty((world, local_rows, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    gathered = list(gathered_flat.unbind(0)) if gathered_flat is not None else None
     full_fb = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
     gather_ms = []
 
@@ -121,7 +125,6 @@ def main():
             ctx.read_local_framebuffer_device(local_fb.data_ptr())
             dist.gather(local_fb, gathered, dst=0)
             if rank == 0:
-                torch.stack(gathered, out=gathered_flat)
                 torch.cuda.synchronize()
                 ctx.deinterleave_device(gathered_flat.data_ptr(), full_fb.data_ptr())
             gather_ms.append((time.perf_counter() - t) * 1e3)
@@ -169,17 +172,23 @@ def main():
         ctx.wait()
         cnt = ctx.get_counters(reset=True)
         ctx.set_setting("count_traversal", 0)
-        launches_replay = replay * (args.max_depth + 1 if args.integrator == "pt" else 1)
         primaries = float(W) * H * args.spp * replay / world
-        algo_bytes = (cnt["rays_extend"] * (32 + 16) + primaries * 32 + 64.0 * cnt["inner_extend"] + 52.0 * cnt["tris_extend"])
-        bytes_per_launch = algo_bytes / launches_replay
+        algo_bytes = (cnt["rays_extend"] * (32 + 16) + primaries * 32 + 112.0 * cnt["inner_extend"] + 52.0 * cnt["tris_extend"])
+        # one render call launches the extend kernel (max_depth + 1) x sub-batches times; the sub-batches run on their
+        # own HIP streams, so launches of different sub-batches overlap and each launch's duration is stretched by the
+        # share of the chip it gets.  Reported: bytes and duration of the average launch as it ran (what rocprofv3
+        # shows), and the mean number of kernels in flight (sum of all kernel durations / wall time) beside it.
+        launches_per_step = ext_launches / max(1, args.steps)
+        bytes_per_launch = algo_bytes / replay / max(1.0, launches_per_step)
         ms_per_launch = ext_ms / max(1, ext_launches)
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
+        concurrency = busy_ms / (elapsed * 1e3) if elapsed > 0 else 1.0
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("spp") == args.spp and tj.get("workload") == scene.name:
+                if tj.get("spp") == args.spp and tj.get("workload") == scene.name and tj.get("streams") == args.streams:
                     traffic = tj.get("hbm_bytes_per_extend_launch")
             except Exception:
                 traffic = None
@@ -187,7 +196,9 @@ def main():
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": ms_per_launch,
-            "launches_timed": ext_launches,
+            "launches_timed": ext_launches, "launches_per_step": launches_per_step,
+            "kernels_in_flight": round(concurrency, 3),
+            "achieved_x_kernels_in_flight": round(achieved * max(1.0, concurrency), 2),
             "per_ray": {"inner_nodes": cnt["inner_extend"] / max(1, cnt["rays_extend"]),
                         "triangle_tests": cnt["tris_extend"] / max(1, cnt["rays_extend"]),
                         "rays_per_sample": cnt["rays_extend"] / max(1.0, primaries),

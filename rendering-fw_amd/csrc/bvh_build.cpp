@@ -269,16 +269,16 @@ void build(const float *bmin, const float *bmax, size_t n, int max_leaf, int dep
 
 namespace
 {
+constexpr size_t BFS_TOP_NODES = 1024;
 float node_area(const rt::Node &n)
 {
 	const float e0 = n.bmax[0] - n.bmin[0], e1 = n.bmax[1] - n.bmin[1], e2 = n.bmax[2] - n.bmin[2];
 	return e0 * e1 + e0 * e2 + e1 * e2;
 }
-uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4> &out)
+// children of the 4-wide node made from BVH2 node n2: open the inner child with the largest area until four
+int pick_children(const Result &b, int n2, int kids[4])
 {
-	const uint32_t idx = (uint32_t)out.size();
-	out.emplace_back();
-	int kids[4] = {b.nodes[n2].left_first, b.nodes[n2].left_first + 1, -1, -1};
+	kids[0] = b.nodes[n2].left_first, kids[1] = b.nodes[n2].left_first + 1, kids[2] = kids[3] = -1;
 	int nk = 2;
 	while (nk < 4)
 	{
@@ -293,7 +293,10 @@ uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4
 		kids[best] = l;
 		kids[nk++] = l + 1;
 	}
-	rt::Node4 nd;
+	return nk;
+}
+void fill_boxes(const Result &b, const int kids[4], int nk, rt::Node4 &nd)
+{
 	for (int k = 0; k < 4; k++)
 	{
 		if (k < nk)
@@ -302,7 +305,7 @@ uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4
 			for (int a = 0; a < 3; a++)
 				nd.lo[a][k] = c.bmin[a], nd.hi[a][k] = c.bmax[a];
 			nd.src[k] = (uint32_t)kids[k];
-			nd.entry[k] = 0; // filled below (inner children are created after this node: depth-first order)
+			nd.entry[k] = 0;
 		}
 		else
 		{
@@ -312,6 +315,16 @@ uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4
 			nd.entry[k] = rt::ENTRY_EMPTY;
 		}
 	}
+}
+// depth-first: a subtree's nodes are contiguous (what the caches like below the top of the tree)
+uint32_t collapse_node(const Result &b, int n2, bool tlas, std::vector<rt::Node4> &out)
+{
+	const uint32_t idx = (uint32_t)out.size();
+	out.emplace_back();
+	int kids[4];
+	const int nk = pick_children(b, n2, kids);
+	rt::Node4 nd;
+	fill_boxes(b, kids, nk, nd);
 	out[idx] = nd;
 	for (int k = 0; k < nk; k++)
 	{
@@ -333,7 +346,42 @@ bool collapse4(const Result &bvh2, bool tlas, std::vector<rt::Node4> &out)
 	if (bvh2.nodes.empty() || bvh2.nodes[0].count >= 0)
 		return false;
 	out.reserve(bvh2.nodes.size() / 3 + 2);
-	collapse_node(bvh2, 0, tlas, out);
+	// The top of the tree is laid out breadth-first, so that a prefix of the array is "the top levels" (the traversal
+	// kernels keep such a prefix in LDS); below it every subtree is depth-first.
+	struct Item
+	{
+		int n2;
+		uint32_t idx;
+	};
+	std::vector<Item> queue;
+	out.emplace_back();
+	queue.push_back({0, 0u});
+	for (size_t head = 0; head < queue.size(); head++)
+	{
+		const Item it = queue[head];
+		int kids[4];
+		const int nk = pick_children(bvh2, it.n2, kids);
+		rt::Node4 nd;
+		fill_boxes(bvh2, kids, nk, nd);
+		out[it.idx] = nd;
+		for (int k = 0; k < nk; k++)
+		{
+			const rt::Node &c = bvh2.nodes[kids[k]];
+			uint32_t e;
+			if (c.count >= 0)
+				e = rt::make_entry(c.left_first, c.count, tlas);
+			else if (out.size() < BFS_TOP_NODES)
+			{
+				const uint32_t cidx = (uint32_t)out.size();
+				out.emplace_back();
+				queue.push_back({kids[k], cidx});
+				e = rt::make_entry((int)cidx, -1, tlas);
+			}
+			else
+				e = rt::make_entry((int)collapse_node(bvh2, kids[k], tlas, out), -1, tlas);
+			out[it.idx].entry[k] = e;
+		}
+	}
 	return true;
 }
 

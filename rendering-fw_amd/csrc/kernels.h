@@ -14,7 +14,8 @@ struct Params
 	uint32_t depth;		// pathLength of this wave
 	uint32_t max_depth; // MAX_PATH_LENGTH
 	uint32_t parity_no_jitter;
-	uint32_t lds_pairs; // number of top-of-tree node pairs staged in LDS (0 = off)
+	uint32_t lds_first; // Node4 range every traversal workgroup keeps in LDS: the top of the largest BLAS
+	uint32_t lds_count; // (0 = off, <= max_lds_nodes())
 	uint32_t queue;		// which WaveCounters::work[] row this launch pulls its chunks from
 	uint32_t group;		// chunks per XCD group (one row of tiles for the primary wave)
 	uint32_t refill;	// incoherent waves: lanes that finish a ray pull the next one (persistent lanes)
@@ -29,6 +30,9 @@ enum GenMode
 };
 
 typedef void *stream_t; // hipStream_t
+
+// capacity of the LDS top-of-tree cache the kernels were built with
+uint32_t max_lds_nodes();
 
 // device properties used for grid sizing
 void set_device_cus(int cus);

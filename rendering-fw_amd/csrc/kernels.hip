@@ -82,7 +82,12 @@ struct Ctx
 	uint32_t lds[LDS_STACK], spill[SPILL_STACK];
 	float potbuf[POT_CACHE];
 	float *pot;
-	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf; }
+	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0; }
+	explicit Ctx(const Params &p) : Ctx()
+	{
+		// emulation: the "LDS" rows alias the node table (TOP_ROWS = 8), the range check is the device's
+		stk.top = (const f4 *)(p.sc.nodes4 + p.lds_first), stk.top_first = p.lds_first, stk.top_count = p.lds_count;
+	}
 	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
 	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
 };
@@ -455,6 +460,7 @@ RT_FN void leaf_bounds(const Node &n, const f4 *tri_verts, float mn[3], float mx
 
 static int g_cus = 256;
 void set_device_cus(int cus) { g_cus = cus > 0 ? cus : 256; }
+uint32_t max_lds_nodes() { return MAX_LDS_NODES; }
 
 // XCD-aware dynamic chunk queue of a persistent grid.  Chunk = 256 consecutive items.  Chunks are dealt to the 8
 // XCDs in groups of `group` consecutive chunks (for the primary wave: one row of 8x8 tiles), so each XCD owns every
@@ -489,12 +495,28 @@ struct ChunkQueue
 };
 
 static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of the workgroup]");
-#define RT_STACK_DECL                                        \
-	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];          \
-	uint32_t spill_[SPILL_STACK];                            \
-	Ctx ctx;                                                 \
-	ctx.stk.lds = s_stack + threadIdx.x;                     \
-	ctx.stk.spill = spill_;
+#define RT_STACK_DECL                                                                       \
+	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];                                         \
+	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
+	uint32_t spill_[SPILL_STACK];                                                           \
+	Ctx ctx;                                                                                \
+	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
+	ctx.stk.spill = spill_;                                                                 \
+	stage_top(p, s_top);                                                                    \
+	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;
+
+// every workgroup copies the top-of-tree rows into its LDS once (the grids are persistent)
+__device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
+{
+	const f4 *src = (const f4 *)(p.sc.nodes4 + p.lds_first);
+	const uint32_t rows = p.lds_count * TOP_ROWS;
+	for (uint32_t i = threadIdx.x; i < rows; i += BLOCK)
+	{
+		const uint32_t n = i / TOP_ROWS, r = i - n * TOP_ROWS;
+		s_top[i] = src[n * 8u + r];
+	}
+	__syncthreads();
+}
 
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
@@ -626,7 +648,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 	static_assert(BLOCK == POT_STRIDE, "potential cache layout is pot[light][thread]");
 	__shared__ float s_pot[POT_CACHE * BLOCK];
 	Ctx ctx;
-	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr;
+	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
 	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
@@ -893,6 +915,7 @@ void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t 
 // ================================================================================================================
 
 void set_device_cus(int) {}
+uint32_t max_lds_nodes() { return MAX_LDS_NODES; }
 void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count); }
 void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = count; }
 
@@ -905,7 +928,7 @@ void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uin
 }
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
-	Ctx ctx;
+	Ctx ctx(p);
 	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext[p.depth] : max_items;
 	for (uint32_t i = 0; i < n; i++)
 	{
@@ -921,7 +944,7 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 }
 void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t)
 {
-	Ctx ctx;
+	Ctx ctx(p);
 	for (uint32_t i = 0; i < max_items; i++)
 		count ? shade_parity_item<true>(p, i, true, ctx) : shade_parity_item<false>(p, i, true, ctx);
 }
@@ -934,7 +957,7 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 }
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)
 {
-	Ctx ctx;
+	Ctx ctx(p);
 	const uint32_t n = p.wv.counters->shadow[p.depth];
 	for (uint32_t i = 0; i < n; i++)
 		count ? connect_item<true>(p, i, true, ctx) : connect_item<false>(p, i, true, ctx);

@@ -320,7 +320,7 @@ struct rfwhip_context
 	int jitter = 0; // 0 xor128, 1 center
 	int stage_timing = 0;
 	int count_traversal = 0;
-	int lds_nodes = 0;
+	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
 	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 
@@ -903,6 +903,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
 		c->blas_nodes4 = all_nodes4.size();
 		c->node4_capacity = all_nodes4.size() + 2 * tlas_reserve + 64;
+		if (c->node4_capacity >= (size_t(1) << 25))
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^25 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
 		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
 		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4)));
 		RF_TRY(dm::h2d(c->d_nodes4.p, all_nodes4.data(), all_nodes4.size() * sizeof(rt::Node4), c->stream));
@@ -1143,7 +1145,18 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	p.fr.probe_pixel = c->probe_y * c->W + c->probe_x;
 	p.max_depth = (uint32_t)c->max_depth;
 	p.parity_no_jitter = c->jitter == 1;
-	p.lds_pairs = (uint32_t)c->lds_nodes;
+	// LDS top-of-tree cache: the first nodes (breadth-first top, bvh::collapse4) of the BLAS with the most nodes
+	p.lds_first = 0, p.lds_count = 0;
+	{
+		const MeshRec *big = nullptr;
+		for (const auto &m : c->meshes)
+			if (m.used && !m.n4.empty() && (!big || m.n4.size() > big->n4.size()))
+				big = &m;
+		const uint32_t cap = rtk::max_lds_nodes();
+		const uint32_t want = c->lds_nodes < 0 ? cap : std::min<uint32_t>((uint32_t)c->lds_nodes, cap);
+		if (big && want)
+			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, (uint32_t)big->n4.size());
+	}
 	p.refill = (uint32_t)c->refill;
 }
 
@@ -1521,7 +1534,7 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	else if (k == "count_traversal")
 		c->count_traversal = atoi(value) != 0;
 	else if (k == "lds_nodes")
-		c->lds_nodes = std::max(0, atoi(value));
+		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
 		c->refill = atoi(value) & 3; // bit 0: extension waves, bit 1: shadow waves
 	else if (k == "streams")

@@ -241,7 +241,7 @@ struct TStat
 };
 
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 24
+#define RT_LDS_STACK 16
 #endif
 constexpr int LDS_STACK = RT_LDS_STACK;	// entries per lane kept in LDS
 constexpr int SPILL_STACK = 40; // further entries in private memory (touched only by pathological rays)
@@ -252,11 +252,27 @@ constexpr int STACK_STRIDE = 1;
 #endif
 constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 
+// The top of the largest BLAS, kept in LDS by every traversal workgroup: rows [lo.x lo.y lo.z hi.x hi.y hi.z entry] of
+// Node4 top_first .. top_first + top_count - 1.  A divergent 16-byte load costs the CU's vector L1 one cycle per lane
+// (profiles/micro/gather_micro.hip: 9.6 TB/s chip-wide whatever the table size) and that rate bounds the traversal
+// kernels; the same rows from LDS cost 4 cycles per 64 lanes, and every ray walks through these nodes.
+#ifndef RT_LDS_NODES
+#define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth)
+#endif
+constexpr uint32_t MAX_LDS_NODES = RT_LDS_NODES;
+#if defined(RT_DEVICE_BUILD)
+constexpr uint32_t TOP_ROWS = 7; // the src row stays behind
+#else
+constexpr uint32_t TOP_ROWS = 8; // emulation: `top` aliases the node table itself
+#endif
+
 struct TravStack
 {
 	uint32_t *lds;	 // this lane's column of the workgroup's LDS stack
 	uint32_t *spill; // SPILL_STACK private entries behind it (a plain local array of the caller: keeping it out of
 					 // the traversal state lets that state live in registers)
+	const f4 *top;	 // staged top-of-tree rows (TOP_ROWS per node)
+	uint32_t top_first, top_count;
 };
 
 // 1/d for the slab test.  A direction component of exactly 0 (it happens: jitter r0 == 1.0f puts a ray on the image's
@@ -288,6 +304,96 @@ RT_FN bool slab(const f4 &a, const f4 &b, f3 id, f3 oid, float t, float &tnear)
 	const float tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
 	tnear = tmin;
 	return tmax > tmin && tmin < t && tmax >= 0.0f;
+}
+
+// The seven 16-byte rows of a Node4 a ray needs (entries, and per axis the entry-plane row and the exit-plane row of
+// its four children), turned into plane distances p * id - oid.
+//  * device: the seven loads are pinned by one empty asm that names every row, so they are issued back to back (one
+//    round trip; none is sunk into the branch that uses it, none is waited for while others are still to be issued),
+//    and the 24 fmas are 12 v_pk_fma_f32 on the natural register pairs of the loaded rows.
+//  * emulation: the same fma arithmetic, scalar.
+#ifndef RT_NODE_VARIANT
+#define RT_NODE_VARIANT 4
+#endif
+struct Node4Planes
+{
+	f4 ax, ay, az; // distances to the entry planes of children 0..3
+	f4 bx, by, bz; // distances to the exit planes
+	f4 en;		   // the four entries (bit patterns)
+};
+template <bool PIN>
+RT_FN Node4Planes load_node4(const char *base, uint32_t nb, uint32_t near_x, uint32_t near_y, uint32_t near_z, f3 id, f3 oid)
+{
+	Node4Planes r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	const v2f ix = {id.x, id.x}, iy = {id.y, id.y}, iz = {id.z, id.z};
+	const v2f ox = {-oid.x, -oid.x}, oy = {-oid.y, -oid.y}, oz = {-oid.z, -oid.z};
+#define RT_ROW(OUT, ROW, I, O)                                            \
+	{                                                                     \
+		const v2f lo_ = __builtin_elementwise_fma(ROW.xy, I, O);          \
+		const v2f hi_ = __builtin_elementwise_fma(ROW.zw, I, O);          \
+		OUT = mk4(lo_.x, lo_.y, hi_.x, hi_.y);                            \
+	}
+#if RT_NODE_VARIANT <= 1
+	const v4f *p = (const v4f *)(base + nb);
+	v4f nx = p[0], ny = p[1], nz = p[2], fx = p[3], fy = p[4], fz = p[5], en = p[6];
+	f4 x1, x2, y1, y2, z1, z2;
+#if RT_NODE_VARIANT == 1
+	RT_ROW(x1, nx, ix, ox)
+	RT_ROW(y1, ny, iy, oy)
+	RT_ROW(z1, nz, iz, oz)
+	RT_ROW(x2, fx, ix, ox)
+	RT_ROW(y2, fy, iy, oy)
+	RT_ROW(z2, fz, iz, oz)
+#else
+#define RT_ROWS(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
+	x1 = RT_ROWS(nx, id.x, oid.x), y1 = RT_ROWS(ny, id.y, oid.y), z1 = RT_ROWS(nz, id.z, oid.z);
+	x2 = RT_ROWS(fx, id.x, oid.x), y2 = RT_ROWS(fy, id.y, oid.y), z2 = RT_ROWS(fz, id.z, oid.z);
+#undef RT_ROWS
+#endif
+#define RT_MM(A, B, F) mk4(F(A.x, B.x), F(A.y, B.y), F(A.z, B.z), F(A.w, B.w))
+	r.ax = RT_MM(x1, x2, fminf), r.ay = RT_MM(y1, y2, fminf), r.az = RT_MM(z1, z2, fminf);
+	r.bx = RT_MM(x1, x2, fmaxf), r.by = RT_MM(y1, y2, fmaxf), r.bz = RT_MM(z1, z2, fmaxf);
+#undef RT_MM
+#else
+	v4f en = *(const v4f *)(base + (nb + 96u));
+	v4f nx = *(const v4f *)(base + (nb + near_x)), fx = *(const v4f *)(base + (nb + (near_x ^ 48u)));
+	v4f ny = *(const v4f *)(base + (nb + near_y)), fy = *(const v4f *)(base + (nb + (near_y ^ 80u)));
+	v4f nz = *(const v4f *)(base + (nb + near_z)), fz = *(const v4f *)(base + (nb + (near_z ^ 112u)));
+#if RT_NODE_VARIANT == 2 || RT_NODE_VARIANT == 4
+	if (PIN)
+		asm volatile("" : "+v"(en), "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz));
+#endif
+#if RT_NODE_VARIANT >= 4
+#define RT_ROWS(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
+	r.ax = RT_ROWS(nx, id.x, oid.x), r.ay = RT_ROWS(ny, id.y, oid.y), r.az = RT_ROWS(nz, id.z, oid.z);
+	r.bx = RT_ROWS(fx, id.x, oid.x), r.by = RT_ROWS(fy, id.y, oid.y), r.bz = RT_ROWS(fz, id.z, oid.z);
+#undef RT_ROWS
+#else
+	RT_ROW(r.ax, nx, ix, ox)
+	RT_ROW(r.ay, ny, iy, oy)
+	RT_ROW(r.az, nz, iz, oz)
+	RT_ROW(r.bx, fx, ix, ox)
+	RT_ROW(r.by, fy, iy, oy)
+	RT_ROW(r.bz, fz, iz, oz)
+#endif
+#endif
+#undef RT_ROW
+	r.en = mk4(en.x, en.y, en.z, en.w);
+#else
+	const f4 en = *(const f4 *)(base + (nb + 96u));
+	const f4 nx = *(const f4 *)(base + (nb + near_x)), fx = *(const f4 *)(base + (nb + (near_x ^ 48u)));
+	const f4 ny = *(const f4 *)(base + (nb + near_y)), fy = *(const f4 *)(base + (nb + (near_y ^ 80u)));
+	const f4 nz = *(const f4 *)(base + (nb + near_z)), fz = *(const f4 *)(base + (nb + (near_z ^ 112u)));
+#define RT_ROW(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
+	r.ax = RT_ROW(nx, id.x, oid.x), r.ay = RT_ROW(ny, id.y, oid.y), r.az = RT_ROW(nz, id.z, oid.z);
+	r.bx = RT_ROW(fx, id.x, oid.x), r.by = RT_ROW(fy, id.y, oid.y), r.bz = RT_ROW(fz, id.z, oid.z);
+#undef RT_ROW
+	r.en = en;
+#endif
+	return r;
 }
 
 // Möller–Trumbore with the reference's rejections: |a| < 1e-6, u outside [0,1], v < 0, u+v > 1, t <= t_min, t >= t.
@@ -332,19 +438,31 @@ struct Traverser
 {
 	f3 O, D;		 // world-space ray
 	f3 o, d, id, oid; // ray in the current space (world, or the object space of cur_inst), 1/d, o/d
+	uint32_t near_x, near_y, near_z; // byte offsets inside a Node4 of the planes this ray enters through, per axis
 	int cur_inst;
 	int sp;
 	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
 	float t_min;
 	Hit hit;
 
+	// the ray in the space about to be traversed.  Which of a child's two planes per axis is the entry plane depends
+	// only on the direction's sign, so it is resolved once here into load offsets (lo row or hi row of the Node4)
+	// instead of a min/max pair per plane in the loop.
+	RT_FN void enter_space(f3 o_, f3 d_)
+	{
+		o = o_, d = d_;
+		id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+		oid = o * id;
+		near_x = id.x < 0.0f ? 48u : 0u;
+		near_y = id.y < 0.0f ? 64u : 16u;
+		near_z = id.z < 0.0f ? 80u : 32u;
+	}
+
 	RT_FN void begin(const SceneView &sc, f3 O_, f3 D_, float t_min_, float t_max)
 	{
 		O = O_, D = D_, t_min = t_min_;
 		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
-		o = O, d = D;
-		id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-		oid = o * id;
+		enter_space(O, D);
 		cur_inst = -1, sp = 0;
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
 	}
@@ -376,29 +494,31 @@ struct Traverser
 	{
 		while (!(cur & ENTRY_LEAF))
 		{
-			const f4 *p = (const f4 *)(sc.nodes4 + (cur & ENTRY_INDEX_MASK));
-			const f4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5], en = p[6];
+			const uint32_t idx = cur & ENTRY_INDEX_MASK;
+			const uint32_t rel = idx - stk.top_first;
+			Node4Planes n;
+			if (rel < stk.top_count)
+				n = load_node4<false>((const char *)stk.top, rel * (TOP_ROWS * 16u), near_x, near_y, near_z, id, oid);
+			else // byte offset of the Node4 in the table (tables stay below 4 GiB)
+				n = load_node4<true>((const char *)sc.nodes4, idx << 7, near_x, near_y, near_z, id, oid);
 			if (COUNT)
 				st.inner++;
-			// slab test of the four children (aabb.cpp:39-77 in fma form); a miss (and an empty slot: a point box at
-			// 1e34) gets distance +inf
+			// slab test of the four children (aabb.cpp:39-77 in fma form, entry/exit planes picked by the direction
+			// sign); a miss (and an empty slot: a point box at 1e34) gets distance +inf
 			const float INF = 3.0e38f;
 			float t0, t1, t2, t3;
-#define RT_SLAB4(K, OUT)                                                                                              \
-	{                                                                                                                 \
-		const float x1 = fmaf(lx.K, id.x, -oid.x), x2 = fmaf(hx.K, id.x, -oid.x);                                     \
-		const float y1 = fmaf(ly.K, id.y, -oid.y), y2 = fmaf(hy.K, id.y, -oid.y);                                     \
-		const float z1 = fmaf(lz.K, id.z, -oid.z), z2 = fmaf(hz.K, id.z, -oid.z);                                     \
-		const float tmin = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));                                 \
-		const float tmax = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));                                 \
-		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                             \
+#define RT_SLAB4(K, OUT)                                                  \
+	{                                                                     \
+		const float tmin = fmaxf(fmaxf(n.ax.K, n.ay.K), n.az.K);          \
+		const float tmax = fminf(fminf(n.bx.K, n.by.K), n.bz.K);          \
+		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF; \
 	}
 			RT_SLAB4(x, t0)
 			RT_SLAB4(y, t1)
 			RT_SLAB4(z, t2)
 			RT_SLAB4(w, t3)
 #undef RT_SLAB4
-			uint32_t e0 = fbits(en.x), e1 = fbits(en.y), e2 = fbits(en.z), e3 = fbits(en.w);
+			uint32_t e0 = fbits(n.en.x), e1 = fbits(n.en.y), e2 = fbits(n.en.z), e3 = fbits(n.en.w);
 			if (!ANY)
 			{
 				// order the four children by entry distance (5-comparator network), nearest first
@@ -471,9 +591,7 @@ struct Traverser
 		if (cur == ENTRY_SENTINEL)
 		{
 			// leaving an instance: back to the world-space ray
-			o = O, d = D;
-			id = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-			oid = o * id;
+			enter_space(O, D);
 			cur_inst = -1;
 			cur = pop(stk);
 			return;
@@ -484,13 +602,12 @@ struct Traverser
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
 			const Instance &in = sc.instances[ii];
 			push(stk, ENTRY_SENTINEL);
-			o = mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
-					in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
-					in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]);
-			d = mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z, in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
-					in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z);
-			id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-			oid = o * id;
+			enter_space(mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
+							in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
+							in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]),
+						mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z,
+							in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
+							in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z));
 			cur_inst = (int)ii;
 			cur = in.root_entry;
 			return;
