@@ -110,7 +110,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   jitter       = "xor128" (EmbreeRT: rfw::utils::xor128 stream) | "center" (r0=r1=0.5) — parity integrator only
  *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)
  *   count_traversal = "0"|"1": instrumented traversal (popped inner nodes / triangle tests), for the roofline
- *   lds_nodes    = number of top-of-tree BVH node pairs staged in LDS per workgroup (0 disables)
+ *   lds_nodes    = top-of-tree 4-wide nodes of the largest mesh BVH that every traversal workgroup keeps in LDS
+ *                  (-1 = as many as the kernels were built for, the default; 0 disables)
  *   streams      = sub-batches of one render call that run concurrently on their own HIP streams (1..8, default 4)
  *   refill       = "1"|"0": persistent lanes on the incoherent waves (a lane that finishes its ray pulls the next)
  * Returns the number of keys; fills up to cap pointers with static strings. */
@@ -123,7 +124,7 @@ typedef struct rfwhip_counters
 {
 	uint64_t rays_extend;	 /* closest-hit rays traced since the last reset (primary + extension) */
 	uint64_t rays_shadow;	 /* any-hit rays traced */
-	uint64_t inner_extend;	 /* popped inner nodes (each loads both 32 B children), closest-hit rays */
+	uint64_t inner_extend;	 /* popped 4-wide inner nodes (7 rows of 16 B each), closest-hit rays */
 	uint64_t tris_extend;	 /* triangle tests, closest-hit rays */
 	uint64_t inner_shadow;
 	uint64_t tris_shadow;

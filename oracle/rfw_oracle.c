@@ -721,10 +721,18 @@ int rfwo_set_textures(rfwo_context *c, const rfwhip_texture *t, size_t count)
 }
 int rfwo_set_materials(rfwo_context *c, const rfwhip_material *m, const rfwhip_material_tex_ids *ids, size_t count)
 {
-	(void)ids;
 	free(c->materials);
 	c->materials = (rfwhip_material *)malloc(sizeof(rfwhip_material) * (count ? count : 1));
 	memcpy(c->materials, m, sizeof(rfwhip_material) * count);
+	if (ids)
+	{
+		/* per-slot texture ids as a backend resolves them (CUDART/src/Context.cpp:171-190) */
+		static const int slot_of_id[11] = {0, 1, 2, 3, 4, 5, 6, 7, -1, 8, 9};
+		for (size_t i = 0; i < count; i++)
+			for (int k = 0; k < 11; k++)
+				if (slot_of_id[k] >= 0 && ids[i].texture[k] != -1)
+					c->materials[i].map[slot_of_id[k]].addr = (uint32_t)ids[i].texture[k];
+	}
 	c->materialCount = count;
 	return 0;
 }
@@ -1451,6 +1459,21 @@ static void fetch_trilinear(const otexture *tex, float lambda, float tu, float t
 		out[q] = (1.0f - f) * p0[q] + f * p1[q];
 }
 
+static void layer_trilinear(const rfwo_context *c, const rfwhip_map_desc *md, float lambda, float tu, float tv,
+							float out[4])
+{
+	fetch_trilinear(&c->textures[md->addr], lambda, half_to_float(md->uscale) * (half_to_float(md->uoffs) + tu),
+					half_to_float(md->vscale) * (half_to_float(md->voffs) + tv), md->width, md->height, out);
+}
+static v3 layer_normal(const rfwo_context *c, const rfwhip_map_desc *md, float tu, float tv)
+{
+	float p[4];
+	fetch_texel(&c->textures[md->addr], half_to_float(md->uscale) * (half_to_float(md->uoffs) + tu),
+				half_to_float(md->vscale) * (half_to_float(md->voffs) + tv), 0, md->width > 0 ? md->width : 1,
+				md->height > 0 ? md->height : 1, p);
+	return vscale(vsub(V3(p[0], p[1], p[2]), V3(0.5f, 0.5f, 0.5f)), 2.0f);
+}
+
 typedef struct
 {
 	v3 sum;
@@ -1526,24 +1549,60 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 		iN = vnorm(m3_mul(in->normal, iN));
 		v3 Tg, Bt;
 		create_tangent_space(iN, &Tg, &Bt);
+		int alpha_skip = 0;
 		if (mat_flag(mat, RFWHIP_MAT_HAS_DIFFUSE_MAP) && mat->map[0].addr < c->textureCount)
 		{
 			const float tu = bw0 * tri->u0 + bw1 * tri->u1 + bw2 * tri->u2;
 			const float tv = bw0 * tri->v0 + bw1 * tri->v1 + bw2 * tri->v2;
 			const float coneWidth = view->spreadAngle * t;
 			const float lambda = tri->LOD + log2f(coneWidth * (1.0f / fabsf(vdot(vscale(D, -1.0f), N))));
-			const rfwhip_map_desc *md = &mat->map[0];
 			float texel[4];
-			fetch_trilinear(&c->textures[md->addr], lambda,
-							half_to_float(md->uscale) * (half_to_float(md->uoffs) + tu),
-							half_to_float(md->vscale) * (half_to_float(md->voffs) + tv), md->width, md->height, texel);
-			/* getShadingData.h:150 and :206 both multiply the colour by the texel */
-			sd.color = vmul(sd.color, V3(texel[0], texel[1], texel[2]));
-			sd.color = vmul(sd.color, V3(texel[0], texel[1], texel[2]));
+			layer_trilinear(c, &mat->map[0], lambda, tu, tv, texel);
+			if (mat_flag(mat, RFWHIP_MAT_HAS_ALPHA) && texel[3] < 0.5f)
+				alpha_skip = 1; /* getShadingData.h:145-149 */
+			else
+			{
+				sd.color = vmul(sd.color, V3(texel[0], texel[1], texel[2]));
+				/* additive second and third layers (getShadingData.h:153-166) */
+				if (mat_flag(mat, RFWHIP_MAT_HAS_2ND_DIFFUSE_MAP) && mat->map[1].addr < c->textureCount)
+				{
+					float l1[4];
+					layer_trilinear(c, &mat->map[1], lambda, tu, tv, l1);
+					sd.color = vadd(sd.color, V3(l1[0], l1[1], l1[2]));
+				}
+				if (mat_flag(mat, RFWHIP_MAT_HAS_3RD_DIFFUSE_MAP) && mat->map[2].addr < c->textureCount)
+				{
+					float l2[4];
+					layer_trilinear(c, &mat->map[2], lambda, tu, tv, l2);
+					sd.color = vadd(sd.color, V3(l2[0], l2[1], l2[2]));
+				}
+				/* normal maps at level 0 (getShadingData.h:169-200); layer 3 reads layer 2's descriptor (:189-196) */
+				if (mat_flag(mat, RFWHIP_MAT_HAS_NORMAL_MAP) && mat->map[3].addr < c->textureCount)
+				{
+					v3 sn = layer_normal(c, &mat->map[3], tu, tv);
+					if (mat_flag(mat, RFWHIP_MAT_HAS_2ND_NORMAL_MAP) && mat->map[4].addr < c->textureCount)
+						sn = vadd(sn, layer_normal(c, &mat->map[4], tu, tv));
+					if (mat_flag(mat, RFWHIP_MAT_HAS_3RD_NORMAL_MAP) && mat->map[4].addr < c->textureCount)
+						sn = vadd(sn, layer_normal(c, &mat->map[4], tu, tv));
+					sn = vnorm(sn);
+					/* tangentToWorld (tools.h:214) with the frame of the unperturbed normal */
+					iN = vnorm(vadd(vadd(vscale(Tg, sn.x), vscale(Bt, sn.y)), vscale(iN, sn.z)));
+				}
+				/* getShadingData.h:150 and :206 both multiply the colour by the texel */
+				sd.color = vmul(sd.color, V3(texel[0], texel[1], texel[2]));
+			}
 		}
 		if (pathLength == 0 && pixel == c->probe_y * W + c->probe_x)
 			res->probe_hit = 1, res->probe_inst = inst, res->probe_prim = prim, res->probe_t = t;
 
+		/* ---- alpha pass-through: Kernels.cu:633-647 (the path continues behind the surface, state untouched) ---- */
+		if (alpha_skip)
+		{
+			if (pathLength >= (uint32_t)c->max_depth || v3_any_nan(T))
+				return;
+			O = vadd(I, vscale(D, GEO_EPS));
+			continue;
+		}
 		/* ---- emissive: Kernels.cu:650-692 ---- */
 		if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f)
 		{

@@ -632,13 +632,26 @@ extern "C" int rfwhip_set_textures(rfwhip_context *c, const rfwhip_texture *tex,
 extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *materials,
 									const rfwhip_material_tex_ids *tex_ids, size_t count)
 {
-	(void)tex_ids; // the CPU-style texaddr (index into the texture array) is what the kernels resolve
 	CTX_ENTER(c);
 	if (count && !materials)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_materials: null array");
+	// Every map descriptor's address becomes the index of its texture in the set_textures array.  rfw::system leaves
+	// only texaddr0 filled — with the id of the LAST map it packed (material_list.cpp:385-455 write texaddr0 for every
+	// slot) — and hands the per-slot texture ids over in MaterialTexIds; a backend resolves them per slot
+	// (CUDART/src/Context.cpp:171-190: texture[0..2] diffuse layers, [3..5] normal maps, [6] specularity,
+	// [7] roughness, [9] colour mask, [10] alpha mask).  Without ids the descriptors are taken as they are.
+	std::vector<rfwhip_material> mats(materials, materials + count);
+	if (tex_ids)
+	{
+		static const int slot_of_id[11] = {0, 1, 2, 3, 4, 5, 6, 7, -1, 8, 9};
+		for (size_t i = 0; i < count; i++)
+			for (int k = 0; k < 11; k++)
+				if (slot_of_id[k] >= 0 && tex_ids[i].texture[k] != -1)
+					mats[i].map[slot_of_id[k]].addr = (uint32_t)tex_ids[i].texture[k];
+	}
 	RF_TRY(sync_all(c));
 	RF_TRY(c->d_materials.ensure(count * sizeof(rfwhip_material)));
-	RF_TRY(dm::h2d(c->d_materials.p, materials, count * sizeof(rfwhip_material), c->stream));
+	RF_TRY(dm::h2d(c->d_materials.p, mats.data(), count * sizeof(rfwhip_material), c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->material_count = (uint32_t)count;
 	c->scene_dirty = true;
@@ -1352,7 +1365,14 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	const float anim = st.animationTime;
 	memset(&st, 0, sizeof(st));
 	st.animationTime = anim;
-	st.primaryCount = wc.ext[0];
+	{
+		// ext[0] counts path slots (8x8 tiles, padded at the image border); primary RAYS exist for real pixels only
+		uint32_t owned_rows = 0;
+		for (uint32_t y = 0; y < c->H; y++)
+			owned_rows += ((y / 8u) % (uint32_t)c->world) == (uint32_t)c->rank;
+		const uint32_t samples = c->fr.slots ? wc.ext[0] / c->fr.slots : 0u;
+		st.primaryCount = owned_rows * c->W * samples;
+	}
 	st.secondaryCount = wc.ext[1];
 	for (int d = 2; d < rt::MAX_DEPTH_SLOTS; d++)
 		st.deepCount += wc.ext[d];

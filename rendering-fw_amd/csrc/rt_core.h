@@ -660,7 +660,13 @@ RT_FN bool mat_flag(uint32_t flags, int bit) { return ((flags >> bit) & 1u) != 0
 enum
 {
 	MF_DIFFUSE_MAP = 2,
-	MF_SMOOTH_NORMALS = 11
+	MF_NORMAL_MAP = 3,
+	MF_2ND_NORMAL_MAP = 7,
+	MF_3RD_NORMAL_MAP = 8,
+	MF_2ND_DIFFUSE_MAP = 9,
+	MF_3RD_DIFFUSE_MAP = 10,
+	MF_SMOOTH_NORMALS = 11,
+	MF_ALPHA = 12
 };
 
 RT_FN f3 mul_normal(const Instance &in, f3 n)
@@ -1402,20 +1408,67 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	iN = normalize(mul_normal(inst, iN));
 	f3 Tg, Bt;
 	create_tangent_space(iN, Tg, Bt);
+	bool alpha_skip = false;
 	if (mat_flag(mflags, MF_DIFFUSE_MAP) && mat.map[0].addr < sc.texture_count)
 	{
 		const float tu = bw0 * tu4.x + bw1 * tu4.y + bw2 * tu4.z;
 		const float tv = bw0 * tv4.x + bw1 * tv4.y + bw2 * tv4.z;
 		const float coneWidth = cam.spread_angle * h.t;
 		const float lambda = ex.y + log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, N))));
-		const TexDesc td = sc.textures[mat.map[0].addr];
-		const f4 texel = fetch_trilinear(sc, td, lambda,
-										 half_to_float(mat.map[0].uscale) * (half_to_float(mat.map[0].uoffs) + tu),
-										 half_to_float(mat.map[0].vscale) * (half_to_float(mat.map[0].voffs) + tv),
-										 mat.map[0].width, mat.map[0].height);
-		// getShadingData.h:150 and :206 both multiply by the texel
-		sd.color = sd.color * xyz(texel);
-		sd.color = sd.color * xyz(texel);
+		// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
+#define RT_LAYER(K) \
+	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \
+					half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),         \
+					half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), mat.map[K].width, \
+					mat.map[K].height)
+#define RT_NORMAL_LAYER(K) \
+	((xyz(fetch_texel(sc, sc.textures[mat.map[K].addr],                                                \
+					  half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),       \
+					  half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), 0u,   \
+					  mat.map[K].width > 0 ? mat.map[K].width : 1, mat.map[K].height > 0 ? mat.map[K].height : 1)) - \
+	  mk3(0.5f, 0.5f, 0.5f)) *                                                                         \
+	 2.0f)
+		const f4 texel = RT_LAYER(0);
+		if (mat_flag(mflags, MF_ALPHA) && texel.w < 0.5f)
+			alpha_skip = true; // getShadingData.h:145-149: nothing else of the surface is evaluated
+		else
+		{
+			sd.color = sd.color * xyz(texel);
+			// second and third layers are additive (getShadingData.h:153-166)
+			if (mat_flag(mflags, MF_2ND_DIFFUSE_MAP) && mat.map[1].addr < sc.texture_count)
+				sd.color = sd.color + xyz(RT_LAYER(1));
+			if (mat_flag(mflags, MF_3RD_DIFFUSE_MAP) && mat.map[2].addr < sc.texture_count)
+				sd.color = sd.color + xyz(RT_LAYER(2));
+			// normal mapping, level 0 only (getShadingData.h:169-200); the third layer reads the descriptor of the
+			// second one there (:189-196) — kept.  The tangent frame stays the one of the unperturbed normal.
+			if (mat_flag(mflags, MF_NORMAL_MAP) && mat.map[3].addr < sc.texture_count)
+			{
+				f3 sn = RT_NORMAL_LAYER(3);
+				if (mat_flag(mflags, MF_2ND_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
+					sn = sn + RT_NORMAL_LAYER(4);
+				if (mat_flag(mflags, MF_3RD_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
+					sn = sn + RT_NORMAL_LAYER(4);
+				sn = normalize(sn);
+				iN = normalize((Tg * sn.x + Bt * sn.y) + iN * sn.z); // tangentToWorld, tools.h:214
+			}
+			// getShadingData.h:150 and :206 both multiply by the texel
+			sd.color = sd.color * xyz(texel);
+		}
+#undef RT_LAYER
+#undef RT_NORMAL_LAYER
+	}
+	// alpha pass-through (Kernels.cu:633-647): the path continues behind the surface, state untouched
+	if (alpha_skip)
+	{
+		if (in.depth < max_depth && !any_nan(T))
+		{
+			const f3 eo = I + D * 1e-5f;
+			out.emit_ext = true;
+			out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (in.flags & 1u)));
+			out.ed = mk4(D.x, D.y, D.z, ubits(in.packedN));
+			out.et = mk4(T.x, T.y, T.z, in.bsdfPdf);
+		}
+		return;
 	}
 	// emissive surface: Kernels.cu:650-692
 	if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f)

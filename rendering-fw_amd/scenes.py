@@ -33,16 +33,26 @@ def _touint4(a, b, c, d):
 def host_material(color=(1.0, 1.0, 1.0), roughness=0.5, metallic=0.0, subsurface=0.0, specular=0.5, specularTint=0.0,
                   anisotropic=0.0, sheen=0.0, sheenTint=0.0, clearcoat=0.0, clearcoatGloss=1.0, transmission=0.0,
                   eta=1.0, absorption=(0.0, 0.0, 0.0), smooth=True, texture=-1, uvscale=(1.0, 1.0),
-                  uvoffset=(0.0, 0.0)):
-    """HostMaterial with the reference's defaults (material_list.h:48-66)."""
+                  uvoffset=(0.0, 0.0), texture1=-1, texture2=-1, normalmap=-1, normalmap1=-1, normalmap2=-1,
+                  alpha=False):
+    """HostMaterial with the reference's defaults (material_list.h:48-66).  texture/texture1/texture2 are the diffuse
+    layers (map[TEXTURE0..2]), normalmap/normalmap1/normalmap2 the normal-map layers (map[NORMALMAP0..2]); all layers
+    share uvscale / uvoffset here.  alpha = the HASALPHA host flag."""
     return dict(color=color, roughness=roughness, metallic=metallic, subsurface=subsurface, specular=specular,
                 specularTint=specularTint, anisotropic=anisotropic, sheen=sheen, sheenTint=sheenTint,
                 clearcoat=clearcoat, clearcoatGloss=clearcoatGloss, transmission=transmission, eta=eta,
-                absorption=absorption, smooth=smooth, texture=texture, uvscale=uvscale, uvoffset=uvoffset)
+                absorption=absorption, smooth=smooth, texture=texture, uvscale=uvscale, uvoffset=uvoffset,
+                texture1=texture1, texture2=texture2, normalmap=normalmap, normalmap1=normalmap1,
+                normalmap2=normalmap2, alpha=alpha)
 
 
-def pack_materials(host_materials, textures):
-    """HostMaterial::convertToDeviceMaterial for a list of host materials (diffuse map 0 only)."""
+def pack_materials(host_materials, textures, faithful=False):
+    """HostMaterial::convertToDeviceMaterial (material_list.cpp:320-481) for a list of host materials: the 192-byte
+    device material and the per-slot texture ids (MaterialTexIds) a backend resolves the map addresses from.
+
+    faithful=True reproduces two quirks of the reference's packer: a second diffuse layer sets the Has2ndNormalMap
+    bit instead of Has2ndDiffuseMap (:372), and every present map writes its texture id into texaddr0 (:385-455), so
+    only MaterialTexIds says which texture belongs to which slot.  The default packs what was meant."""
     out = np.zeros(len(host_materials), dtype=abi.MATERIAL_DTYPE)
     ids = np.full((len(host_materials), 11), -1, dtype=np.int32)
     for i, m in enumerate(host_materials):
@@ -53,22 +63,36 @@ def pack_materials(host_materials, textures):
         o["parameters"][1] = _touint4(m["specularTint"], m["anisotropic"], m["sheen"], m["sheenTint"])
         o["parameters"][2] = _touint4(m["clearcoat"], m["clearcoatGloss"], m["transmission"], m["eta"] * 0.5)
         o["parameters"][3] = 0
-        t0 = m["texture"]
         flags = 0
         if m["eta"] > 0:
             flags |= 1 << abi.MAT_IS_DIELECTRIC
         if m["smooth"]:
             flags |= 1 << abi.MAT_HAS_SMOOTH_NORMALS
-        if t0 >= 0:
-            tex = textures[t0]
-            flags |= 1 << abi.MAT_HAS_DIFFUSE_MAP
-            if tex["type"] == abi.TEX_FLOAT4:
+        if m.get("alpha", False):
+            flags |= 1 << abi.MAT_HAS_ALPHA
+        # (host field, map slot = MaterialTexIds index, flag)
+        layers = [("texture", 0, abi.MAT_HAS_DIFFUSE_MAP),
+                  ("texture1", 1, abi.MAT_HAS_2ND_NORMAL_MAP if faithful else abi.MAT_HAS_2ND_DIFFUSE_MAP),
+                  ("texture2", 2, abi.MAT_HAS_3RD_DIFFUSE_MAP),
+                  ("normalmap", 3, abi.MAT_HAS_NORMAL_MAP), ("normalmap1", 4, abi.MAT_HAS_2ND_NORMAL_MAP),
+                  ("normalmap2", 5, abi.MAT_HAS_3RD_NORMAL_MAP)]
+        for field, slot, flag in layers:
+            t = m.get(field, -1)
+            if t < 0:
+                continue
+            tex = textures[t]
+            flags |= 1 << flag
+            if slot == 0 and tex["type"] == abi.TEX_FLOAT4:
                 flags |= 1 << abi.MAT_DIFFUSE_MAP_IS_HDR
-            d = o["map"][0]
-            d["width"], d["height"], d["addr"] = tex["width"], tex["height"], t0
+            d = o["map"][slot]
+            d["width"], d["height"] = tex["width"], tex["height"]
             d["uscale"], d["vscale"] = np.float16(m["uvscale"][0]), np.float16(m["uvscale"][1])
             d["uoffs"], d["voffs"] = np.float16(m["uvoffset"][0]), np.float16(m["uvoffset"][1])
-            ids[i, 0] = t0
+            if faithful:
+                o["map"][0]["addr"] = t
+            else:
+                d["addr"] = t
+            ids[i, slot] = t
         o["flags"] = flags
     return out, ids.view(abi.MATERIAL_TEX_IDS_DTYPE).reshape(-1)
 
@@ -322,7 +346,7 @@ class Scene:
         pix, w, h = self.sky
         ctx.set_sky(pix, w, h)
         ctx.set_textures(self.textures)
-        mats, ids = pack_materials(self.host_materials, self.textures)
+        mats, ids = pack_materials(self.host_materials, self.textures, faithful=getattr(self, "pack_faithful", False))
         ctx.set_materials(mats, ids)
         for i, m in enumerate(self.meshes):
             ctx.set_mesh(i, m["vertices"], m["triangles"], m["indices"])
@@ -407,6 +431,74 @@ def cornell(width=512, height=512, geometric_emitter=False, point_light=True):
     cam.look_at((0.37, L + 0.21, -3.6 * L), (0.0, L, 0.0))  # off-axis: no rays exactly along shared edges
     cam.resize(width, height)
     s.camera = cam
+    return s
+
+
+def cards(width=480, height=270, faithful=False):
+    """PT-integrator feature scene: the Cornell room with
+      * a "leaf card" in front of the tall box whose RGBA8 texture has alpha holes (HasAlpha: paths pass through),
+      * a floor with a tangent-space normal map (two layers) and a detail colour layer added on top of the base map,
+      * a third card with three diffuse layers.
+    faithful=True packs the materials with the reference packer's quirks (pack_materials)."""
+    s = cornell(width, height, geometric_emitter=True, point_light=True)
+    s.name = "cards"
+    s.pack_faithful = faithful
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    # leaf card: green with round holes (alpha 0) on a 4x4 lattice
+    cx, cy = (xx % 16) - 7.5, (yy % 16) - 7.5
+    hole = (cx * cx + cy * cy) < 30.0
+    leaf = np.zeros((n, n, 4), np.uint8)
+    leaf[..., 0] = 40 + (xx * 3) % 50
+    leaf[..., 1] = 150 + (yy * 2) % 90
+    leaf[..., 2] = 40
+    leaf[..., 3] = np.where(hole, 0, 255)
+    t_leaf = s.add_texture(make_texture_rgba8(leaf))
+    # base colour: checker; detail layers: faint stripes
+    base = np.zeros((n, n, 4), np.uint8)
+    chk = ((xx // 8) + (yy // 8)) % 2
+    base[..., 0] = np.where(chk, 230, 120)
+    base[..., 1] = np.where(chk, 220, 110)
+    base[..., 2] = np.where(chk, 200, 100)
+    base[..., 3] = 255
+    t_base = s.add_texture(make_texture_rgba8(base))
+    det = np.zeros((n, n, 4), np.uint8)
+    det[..., 0] = np.where((xx // 2) % 2, 30, 0)
+    det[..., 2] = np.where((yy // 2) % 2, 40, 0)
+    det[..., 3] = 255
+    t_det = s.add_texture(make_texture_rgba8(det))
+    det2 = np.zeros((n, n, 4), np.uint8)
+    det2[..., 1] = ((xx + yy) % 8) * 6
+    det2[..., 3] = 255
+    t_det2 = s.add_texture(make_texture_rgba8(det2))
+    # normal maps: sinusoidal bumps, encoded n * 0.5 + 0.5
+    def nmap(fx, fy, amp):
+        dx = amp * np.cos(2 * np.pi * fx * xx / n)
+        dy = amp * np.cos(2 * np.pi * fy * yy / n)
+        nn = np.stack([-dx, -dy, np.ones_like(dx)], -1)
+        nn /= np.linalg.norm(nn, axis=-1, keepdims=True)
+        img = np.zeros((n, n, 4), np.uint8)
+        img[..., :3] = np.clip(np.rint((nn * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+        img[..., 3] = 255
+        return img
+    t_n0 = s.add_texture(make_texture_rgba8(nmap(4, 4, 0.8), mips=False))
+    t_n1 = s.add_texture(make_texture_rgba8(nmap(16, 1, 0.3), mips=False))
+    m_leaf = s.add_material(color=(1.0, 1.0, 1.0), roughness=0.9, texture=t_leaf, alpha=True, uvscale=(2.0, 2.0))
+    m_floor = s.add_material(color=(0.9, 0.9, 0.9), roughness=0.7, texture=t_base, texture1=t_det, normalmap=t_n0,
+                             normalmap1=t_n1, uvscale=(3.0, 3.0))
+    m_three = s.add_material(color=(0.8, 0.8, 0.8), roughness=0.8, texture=t_base, texture1=t_det, texture2=t_det2,
+                             normalmap=t_n1, normalmap1=t_n0, normalmap2=t_n0)
+    L = 5.0
+    def card(p0, ex, ey, mat):
+        p0, ex, ey = np.asarray(p0, np.float32), np.asarray(ex, np.float32), np.asarray(ey, np.float32)
+        v = np.array([p0, p0 + ex, p0 + ex + ey, p0 + ey], np.float32)
+        idx = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        m = s.add_mesh(v, idx, uvs=uv, material=mat)
+        s.add_instance(m)
+    card((-4.5, 0.5, -2.5), (3.5, 0.0, 0.4), (0.0, 4.5, 0.0), m_leaf)    # in front of the tall box, slightly turned
+    card((-L + 0.02, 0.02, -L + 0.02), (0.0, 0.0, 2 * L - 0.04), (2 * L - 0.04, 0.0, 0.0), m_floor)  # just above the floor
+    card((1.2, 3.2, 0.5), (2.6, 0.0, -0.8), (0.0, 2.6, 0.0), m_three)
     return s
 
 

@@ -163,3 +163,32 @@ def test_settings_and_errors(pkg, make_emu):
     e.cleanup()                                            # idempotent
     with pytest.raises(RuntimeError):
         e.update()
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_alpha_cards_layers_and_normal_maps(pkg, make_emu, make_oracle, faithful):
+    """alpha pass-through (Kernels.cu:633-647), additive 2nd/3rd diffuse layers and 1-3 normal-map
+    layers (getShadingData.h:141-206) in the path tracer, with the map addresses resolved per slot from
+    MaterialTexIds (CUDART/src/Context.cpp:171-190).  faithful=True hands the materials over the way the reference's
+    packer does (texaddr0 only, 2nd diffuse layer flagged as 2nd normal map)."""
+    scene = pkg.scenes.cards(96, 64, faithful=faithful)
+    e, o = make_emu(), make_oracle()
+    a, b = _run(pkg, [e, o], scene, 96, 64, {"integrator": "pt", "spp": 8, "max_depth": 3, "count_traversal": 1})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 2e-2 and rmse <= 3e-2, (frac, rmse)
+    st, oc = e.get_stats(), o.get_counters()
+    total_ext = st.primaryCount + st.secondaryCount + st.deepCount
+    assert abs(total_ext - oc["rays_extend"]) <= 0.002 * oc["rays_extend"]
+
+
+def test_alpha_holes_let_paths_through(pkg, make_emu):
+    """The holes of the leaf card are really open: with the HasAlpha flag the image differs from the opaque card's
+    and primary hits behind the card appear where the texture's alpha is 0."""
+    scene = pkg.scenes.cards(96, 64)
+    a = _run(pkg, [make_emu()], scene, 96, 64, {"integrator": "pt", "spp": 4, "max_depth": 2})[0]
+    opaque = pkg.scenes.cards(96, 64)
+    for m in opaque.host_materials:
+        m["alpha"] = False
+    b = _run(pkg, [make_emu()], opaque, 96, 64, {"integrator": "pt", "spp": 4, "max_depth": 2})[0]
+    diff = np.abs(a[..., :3] - b[..., :3]).max(axis=-1)
+    assert (diff > 0.05).mean() > 0.01

@@ -147,6 +147,21 @@ def test_atrium_textured_instanced(pkg, make_hip, make_oracle):
     assert abs(hip.framebuffer()[..., :3].mean() - ref.framebuffer()[..., :3].mean()) <= 5e-3 * ref.framebuffer()[..., :3].mean()
 
 
+@pytest.mark.parametrize("faithful", [False, True])
+def test_alpha_cards_layers_and_normal_maps(pkg, make_hip, make_oracle, faithful):
+    """SURVEY §8 f1 on the GPU: alpha pass-through, additive diffuse layers, normal-map layers, per-slot texture ids."""
+    scene = pkg.scenes.cards(480, 270, faithful=faithful)
+    hip, ref = _pair(pkg, make_hip, make_oracle, scene, 480, 270, {"integrator": "pt", "spp": 8, "max_depth": 3})
+    frac, rmse, _ = image_stats(hip.framebuffer(), ref.framebuffer(), 3e-2)
+    assert frac <= 2e-2, (frac, rmse)
+    m = ref.framebuffer()[..., :3].mean()
+    assert abs(hip.framebuffer()[..., :3].mean() - m) <= 5e-3 * m
+    st = hip.get_stats()
+    oc = ref.get_counters()
+    total = st.primaryCount + st.secondaryCount + st.deepCount
+    assert abs(total - oc["rays_extend"]) <= 0.002 * oc["rays_extend"]
+
+
 def test_skinned_tube_refit_on_device(pkg, make_hip, make_oracle):
     """BASELINE config 5 logic on the GPU: host skinning -> set_mesh with unchanged counts -> device refit; every
     frame's image equals a fresh build of that pose and the oracle's."""
