@@ -72,6 +72,11 @@ RFWHIP_API int rfwhip_set_instance(rfwhip_context *ctx, size_t index, size_t mes
 RFWHIP_API int rfwhip_set_lights(rfwhip_context *ctx, rfwhip_light_count count, const rfwhip_area_light *area,
 								 const rfwhip_point_light *point, const rfwhip_spot_light *spot,
 								 const rfwhip_directional_light *directional);
+/* The 5 x 65536-word table of the reference's blue-noise sampler (createBlueNoiseBuffer(), blue_noise.h:8204, uploaded
+ * by CUDART/src/Context.cpp:43-46).  The table is data of the reference tree and is NOT part of this library: the
+ * plugin shim hands it over when it is built there.  With a table and sampler=bluenoise the pt integrator draws the
+ * primary-ray jitter / lens sample from blueNoiseSampler (Kernels.cu:391-394) instead of the hash RNG. */
+RFWHIP_API int rfwhip_set_blue_noise(rfwhip_context *ctx, const uint32_t *table, size_t words);
 /* update(): once after a batch of set_* — builds the TLAS, uploads descriptors              context.h:108 */
 RFWHIP_API int rfwhip_update(rfwhip_context *ctx);
 
@@ -108,6 +113,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   spp          = samples per pixel enqueued by one rfwhip_render call (default 1)
  *   max_depth    = MAX_PATH_LENGTH of the pt integrator (settings.h:5, default 2)
  *   jitter       = "xor128" (EmbreeRT: rfw::utils::xor128 stream) | "center" (r0=r1=0.5) — parity integrator only
+ *   sampler      = "hash" (WangHash + xorshift32, tools.h:218-235; default) | "bluenoise" (needs rfwhip_set_blue_noise)
+ *                  — pt integrator, primary rays
  *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)
  *   count_traversal = "0"|"1": instrumented traversal (popped inner nodes / triangle tests), for the roofline
  *   lds_nodes    = top-of-tree 4-wide nodes of the largest mesh BVH that every traversal workgroup keeps in LDS

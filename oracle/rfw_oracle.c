@@ -104,6 +104,8 @@ struct rfwo_context
 	int spp;
 	int max_depth;
 	int jitter; /* 0 xor128, 1 center */
+	int sampler;			 /* 0 hash RNG, 1 blue noise */
+	uint32_t *blue_noise; /* 5 x 65536 words or NULL */
 	int use_bvh;
 	int threads;
 
@@ -678,7 +680,7 @@ void rfwo_destroy(rfwo_context *c)
 		free(c->textures[i].data);
 	free(c->meshes), free(c->instances), free(c->materials), free(c->textures), free(c->sky), free(c->area);
 	free(c->point), free(c->spot), free(c->dir), free(c->acc), free(c->hit_t), free(c->hit_u), free(c->hit_v);
-	free(c->hit_prim), free(c->hit_inst);
+	free(c->hit_prim), free(c->hit_inst), free(c->blue_noise);
 	free(c);
 }
 int rfwo_init(rfwo_context *c, uint32_t w, uint32_t h)
@@ -839,6 +841,15 @@ int rfwo_set_setting(rfwo_context *c, const char *key, const char *val)
 		else
 			return fail("jitter must be xor128|center");
 	}
+	else if (!strcmp(key, "sampler"))
+	{
+		if (!strcmp(val, "hash"))
+			c->sampler = 0;
+		else if (!strcmp(val, "bluenoise"))
+			c->sampler = 1;
+		else
+			return fail("sampler must be hash|bluenoise");
+	}
 	else if (!strcmp(key, "bvh"))
 		c->use_bvh = atoi(val) != 0;
 	else if (!strcmp(key, "threads"))
@@ -848,6 +859,28 @@ int rfwo_set_setting(rfwo_context *c, const char *key, const char *val)
 	else
 		return fail("unknown setting");
 	return 0;
+}
+#define BLUE_NOISE_WORDS (5u * 65536u)
+int rfwo_set_blue_noise(rfwo_context *c, const uint32_t *table, size_t words)
+{
+	if (!table || words < BLUE_NOISE_WORDS)
+		return fail("rfwo_set_blue_noise: the table has 5 x 65536 words");
+	free(c->blue_noise);
+	c->blue_noise = (uint32_t *)malloc(BLUE_NOISE_WORDS * 4);
+	memcpy(c->blue_noise, table, BLUE_NOISE_WORDS * 4);
+	return 0;
+}
+/* blueNoiseSampler, bsdf/tools.h:163-181 / CUDART/src/Kernels.cu:205-223; table layout blue_noise.h:8204 */
+float rfwo_blue_noise_sample(const uint32_t *table, int x, int y, int sampleIdx, int dim)
+{
+	x &= 127, y &= 127, sampleIdx &= 255, dim &= 255;
+	uint32_t ri = (uint32_t)dim + (uint32_t)(x + y * 128) * 8u + 65536u * 3u;
+	if (ri >= BLUE_NOISE_WORDS)
+		ri = BLUE_NOISE_WORDS - 1u;
+	const int ranked = (sampleIdx ^ (int)table[ri]) & 255;
+	int value = (int)table[dim + ranked * 256];
+	value ^= (int)table[(dim & 7) + (x + y * 128) * 8 + 65536];
+	return (0.5f + (float)value) * (1.0f / 256.0f);
 }
 int rfwo_set_probe_index(rfwo_context *c, uint32_t x, uint32_t y)
 {
@@ -1492,8 +1525,19 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 	/* ---- generatePrimaryRay, Kernels.cu:383-426, RNG branch (BLUENOISE off) ---- */
 	uint32_t seed = wang_hash(pixel * 16789u + sampleIdx * 1791u);
 	const int sx = (int)(pixel % W), sy = (int)(pixel / W);
-	const float r0 = random_float(&seed), r1 = random_float(&seed);
-	float r2 = random_float(&seed), r3 = random_float(&seed);
+	float r0, r1, r2, r3;
+	if (c->sampler == 1 && c->blue_noise) /* Kernels.cu:391-394 */
+	{
+		r0 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 0);
+		r1 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 1);
+		r2 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 2);
+		r3 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 3);
+	}
+	else
+	{
+		r0 = random_float(&seed), r1 = random_float(&seed);
+		r2 = random_float(&seed), r3 = random_float(&seed);
+	}
 	const float blade = (float)(int)(r0 * 9);
 	r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
 	const float piOver4point5 = 3.14159265359f / 4.5f;

@@ -42,6 +42,7 @@ int rfwo_set_instance(rfwo_context *ctx, size_t index, size_t mesh_index, const 
 int rfwo_set_lights(rfwo_context *ctx, rfwhip_light_count count, const rfwhip_area_light *area,
 					const rfwhip_point_light *point, const rfwhip_spot_light *spot,
 					const rfwhip_directional_light *directional);
+int rfwo_set_blue_noise(rfwo_context *ctx, const uint32_t *table, size_t words);
 int rfwo_update(rfwo_context *ctx);
 void rfwo_camera_get_view(const rfwhip_camera *camera, rfwhip_camera_view *view);
 int rfwo_render(rfwo_context *ctx, const rfwhip_camera *camera, int status);
@@ -52,7 +53,8 @@ int rfwo_read_local_framebuffer(rfwo_context *ctx, float *rgba);
 int rfwo_set_probe_index(rfwo_context *ctx, uint32_t x, uint32_t y);
 int rfwo_get_probe_results(rfwo_context *ctx, uint32_t *inst, uint32_t *prim, float *dist);
 int rfwo_get_stats(rfwo_context *ctx, rfwhip_render_stats *stats);
-/* extra keys: bvh = "1" | "0" (0 = brute force over all triangles), threads = N */
+/* keys as rfwhip_set_setting (integrator, spp, max_depth, jitter, sampler; the launch-shape keys are accepted and
+ * ignored); extra keys: bvh = "1" | "0" (0 = brute force over all triangles), threads = N */
 int rfwo_set_setting(rfwo_context *ctx, const char *key, const char *value);
 int rfwo_read_primary_hits(rfwo_context *ctx, float *t, int32_t *prim, int32_t *inst, float *u, float *v);
 int rfwo_get_bvh(rfwo_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap, uint32_t *prims,
@@ -66,6 +68,8 @@ int rfwo_get_counters(rfwo_context *ctx, uint64_t out[8], int reset);
 uint32_t rfwo_xor128_next(uint32_t state[4]);				  /* utils/xor128.h:20-27 */
 float rfwo_rng_rand(uint32_t state[4]);						  /* utils/rng.h:14 */
 void rfwo_xor128_jump(uint32_t state[4], uint64_t draws);	  /* = calling rfwo_xor128_next `draws` times */
+/* bsdf/tools.h:163-181 on a 5 x 65536-word table */
+float rfwo_blue_noise_sample(const uint32_t *table, int x, int y, int sample_idx, int dim);
 uint32_t rfwo_wang_hash(uint32_t s);						  /* bsdf/tools.h:218-225 */
 uint32_t rfwo_random_int(uint32_t *s);						  /* bsdf/tools.h:227-233 */
 float rfwo_random_float(uint32_t *s);						  /* bsdf/tools.h:235 */

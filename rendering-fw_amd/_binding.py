@@ -42,6 +42,7 @@ class CoreBinding:
             "destroy": (None, [vp]),
             "init": (i32, [vp, u32, u32]),
             "set_sky": (i32, [vp, vp, sz, sz]),
+            "set_blue_noise": (i32, [vp, vp, sz]),
             "set_textures": (i32, [vp, vp, sz]),
             "set_materials": (i32, [vp, vp, vp, sz]),
             "set_mesh": (i32, [vp, sz, C.POINTER(abi.Mesh)]),
@@ -152,6 +153,11 @@ class CoreBinding:
         p = _f32(pixels).reshape(-1, 3)
         assert len(p) == width * height
         self._check(self._fn("set_sky")(self._ctx, p.ctypes.data, int(width), int(height)))
+
+    def set_blue_noise(self, table):
+        """The reference's 5 x 65536-word blue-noise table (createBlueNoiseBuffer()); see scenes.synthetic_blue_noise."""
+        t = np.ascontiguousarray(table, dtype=np.uint32).reshape(-1)
+        self._check(self._fn("set_blue_noise")(self._ctx, t.ctypes.data, int(t.size)))
 
     def set_lights(self, area=None, point=None, spot=None, directional=None):
         def prep(a, dt):

@@ -11,6 +11,10 @@
 #ifdef RFWHIP_USE_RFW_HEADERS
 #include <rfw/context/context.h>
 #include <rfw/context/export.h>
+#if __has_include(<rfw/context/blue_noise.h>)
+#include <rfw/context/blue_noise.h> // createBlueNoiseBuffer(): the sampler table lives in the reference tree
+#define RFWHIP_HAVE_BLUE_NOISE_TABLE 1
+#endif
 #else
 #include "rfw/restated_context.h"
 #endif
@@ -50,6 +54,14 @@ class Context final : public rfw::RenderContext
 			HIPRT_CHECK(rfwhip_set_setting(m_Core, "integrator", integ));
 		else
 			HIPRT_CHECK(rfwhip_set_setting(m_Core, "integrator", "pt"));
+#ifdef RFWHIP_HAVE_BLUE_NOISE_TABLE
+		{
+			// what CUDART does at init (CUDART/src/Context.cpp:43-46): primary rays then use blueNoiseSampler
+			const std::vector<unsigned int> table = createBlueNoiseBuffer();
+			HIPRT_CHECK(rfwhip_set_blue_noise(m_Core, table.data(), table.size()));
+			HIPRT_CHECK(rfwhip_set_setting(m_Core, "sampler", "bluenoise"));
+		}
+#endif
 	}
 	~Context() override
 	{

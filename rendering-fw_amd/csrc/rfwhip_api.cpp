@@ -320,6 +320,9 @@ struct rfwhip_context
 	int jitter = 0; // 0 xor128, 1 center
 	int stage_timing = 0;
 	int count_traversal = 0;
+	int sampler = 0;	// 0 hash RNG, 1 blue noise
+	DevBuf d_blue_noise;
+	bool have_blue_noise = false;
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
 	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
@@ -583,6 +586,19 @@ extern "C" int rfwhip_set_sky(rfwhip_context *c, const float *rgb, size_t width,
 	RF_TRY(dm::sync(c->stream));
 	c->sky_w = (uint32_t)width, c->sky_h = (uint32_t)height;
 	c->scene_dirty = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_set_blue_noise(rfwhip_context *c, const uint32_t *table, size_t words)
+{
+	CTX_ENTER(c);
+	if (!table || words < rt::BLUE_NOISE_WORDS)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_blue_noise: the table has 5 x 65536 words");
+	RF_TRY(sync_all(c));
+	RF_TRY(c->d_blue_noise.ensure(rt::BLUE_NOISE_WORDS * sizeof(uint32_t)));
+	RF_TRY(dm::h2d(c->d_blue_noise.p, table, rt::BLUE_NOISE_WORDS * sizeof(uint32_t), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	c->have_blue_noise = true;
 	return RFWHIP_OK;
 }
 
@@ -1142,6 +1158,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	wv.rad = c->d_rad.as<f4>(), wv.acc = c->d_acc.as<f4>();
 	wv.packet_rng = c->d_packet_rng.as<uint32_t>();
 	wv.counters = c->d_counters.as<rt::WaveCounters>();
+	p.cam.blue_noise = nullptr;
 	if (cam)
 	{
 		rfwhip_camera_view v;
@@ -1151,6 +1168,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 		p.cam.right = rt::f3{v.p2[0] - v.p1[0], v.p2[1] - v.p1[1], v.p2[2] - v.p1[2]};
 		p.cam.up = rt::f3{v.p3[0] - v.p1[0], v.p3[1] - v.p1[1], v.p3[2] - v.p1[2]};
 		p.cam.aperture = v.aperture, p.cam.spread_angle = v.spreadAngle, p.cam.clamp_value = cam->clampValue;
+		p.cam.blue_noise = (c->sampler == 1 && c->have_blue_noise) ? c->d_blue_noise.as<uint32_t>() : nullptr;
 	}
 	p.fr = c->fr;
 	p.fr.spp = (uint32_t)c->spp;
@@ -1221,6 +1239,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		return set_error(RFWHIP_ERR_STATE, "rfwhip_render before rfwhip_init");
 	if (c->scene_dirty)
 		return set_error(RFWHIP_ERR_STATE, "rfwhip_render: scene changed since the last rfwhip_update()");
+	if (c->sampler == 1 && !c->have_blue_noise)
+		return set_error(RFWHIP_ERR_STATE, "sampler=bluenoise needs rfwhip_set_blue_noise() first");
 	if (c->max_depth + 2 > rt::MAX_DEPTH_SLOTS)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "max_depth %d too large", c->max_depth);
 	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
@@ -1509,7 +1529,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -1549,6 +1569,15 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		else
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "jitter must be \"xor128\" or \"center\"");
 	}
+	else if (k == "sampler")
+	{
+		if (!strcmp(value, "hash"))
+			c->sampler = 0;
+		else if (!strcmp(value, "bluenoise"))
+			c->sampler = 1;
+		else
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "sampler must be \"hash\" or \"bluenoise\"");
+	}
 	else if (k == "stage_timing")
 		c->stage_timing = atoi(value) != 0;
 	else if (k == "count_traversal")
@@ -1583,6 +1612,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->max_depth);
 	else if (k == "jitter")
 		snprintf(value, cap, "%s", c->jitter ? "center" : "xor128");
+	else if (k == "sampler")
+		snprintf(value, cap, "%s", c->sampler ? "bluenoise" : "hash");
 	else if (k == "stage_timing")
 		snprintf(value, cap, "%d", c->stage_timing);
 	else if (k == "count_traversal")

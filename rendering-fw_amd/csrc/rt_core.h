@@ -201,14 +201,41 @@ RT_FN void parity_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32
 	D = d * inv;
 }
 
-// CUDART generatePrimaryRay with its hash-RNG branch: seed = WangHash(pixel*16789 + sample*1791), four RandomFloat.
+// blueNoiseSampler (bsdf/tools.h:163-181, CUDART/src/Kernels.cu:205-223): Sobol' sequence value of (sample, dimension),
+// ranked and scrambled per pixel of a 128 x 128 tile.  table = [sobol 256 x 256 | scrambling tile | ranking tile]
+// (blue_noise.h:8204: sobol at 0, scrambling at 65536, ranking at 3 * 65536).
+RT_FN float blue_noise_sample(const uint32_t *table, int x, int y, int sampleIdx, int dim)
+{
+	x &= 127, y &= 127, sampleIdx &= 255, dim &= 255;
+	uint32_t ri = (uint32_t)dim + (uint32_t)(x + y * 128) * 8u + 65536u * 3u;
+	if (ri >= BLUE_NOISE_WORDS) // dimensions >= 8 of the last pixels index past the table in the reference
+		ri = BLUE_NOISE_WORDS - 1u;
+	const int ranked = (sampleIdx ^ (int)table[ri]) & 255;
+	int value = (int)table[dim + ranked * 256];
+	value ^= (int)table[(dim & 7) + (x + y * 128) * 8 + 65536];
+	return (0.5f + (float)value) * (1.0f / 256.0f);
+}
+
+// CUDART generatePrimaryRay (Kernels.cu:383-426): r0..r3 from the blue-noise sampler when a table was handed over
+// (what the reference runs), else its hash-RNG branch: seed = WangHash(pixel*16789 + sample*1791), four RandomFloat.
 RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sampleIdx,
 						  f3 &O, f3 &D)
 {
 	const uint32_t pixel = y * W + x;
-	uint32_t seed = wang_hash(pixel * 16789u + sampleIdx * 1791u);
-	const float r0 = random_float(seed), r1 = random_float(seed);
-	float r2 = random_float(seed), r3 = random_float(seed);
+	float r0, r1, r2, r3;
+	if (cam.blue_noise)
+	{
+		r0 = blue_noise_sample(cam.blue_noise, (int)x, (int)y, (int)sampleIdx, 0);
+		r1 = blue_noise_sample(cam.blue_noise, (int)x, (int)y, (int)sampleIdx, 1);
+		r2 = blue_noise_sample(cam.blue_noise, (int)x, (int)y, (int)sampleIdx, 2);
+		r3 = blue_noise_sample(cam.blue_noise, (int)x, (int)y, (int)sampleIdx, 3);
+	}
+	else
+	{
+		uint32_t seed = wang_hash(pixel * 16789u + sampleIdx * 1791u);
+		r0 = random_float(seed), r1 = random_float(seed);
+		r2 = random_float(seed), r3 = random_float(seed);
+	}
 	O = cam.pos;
 	if (cam.aperture != 0.0f) // with aperture 0 the lens offset is exactly zero: skip the four trig evaluations
 	{

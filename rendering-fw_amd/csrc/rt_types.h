@@ -178,7 +178,9 @@ struct CamView
 {
 	f3 pos, p1, right, up;
 	float aperture, spread_angle, clamp_value;
+	const uint32_t *blue_noise; // 5 x 65536 table of the blue-noise sampler (tools.h:163-181) or null: hash RNG
 };
+constexpr uint32_t BLUE_NOISE_WORDS = 5u * 65536u;
 
 // Which image rows this rank owns, and how path slots map to pixels.
 struct FrameView

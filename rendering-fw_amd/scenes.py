@@ -114,6 +114,21 @@ def make_texture_rgba8(rgba_u8, mips=True):
     return {"type": abi.TEX_UINT, "width": w, "height": h, "data": data.astype(np.uint32)}
 
 
+def synthetic_blue_noise(seed=7):
+    """A table with the LAYOUT of the reference's createBlueNoiseBuffer() (blue_noise.h:8204: 256 x 256 sequence values,
+    then a 128 x 128 x 8 scrambling tile at word 65536 and a 128 x 128 x 8 ranking tile at word 3 * 65536, every word
+    in 0..255) filled with our own numbers: per dimension a stratified permutation of 0..255 as the "sequence", random
+    bytes as the tiles.  It exercises blueNoiseSampler's indexing exactly; it is NOT the published blue-noise data
+    (that table belongs to the reference tree and reaches the core through rfwhip_set_blue_noise)."""
+    rng = np.random.default_rng(seed)
+    t = np.zeros(5 * 65536, np.uint32)
+    seq = np.stack([rng.permutation(256) for _ in range(256)], axis=1)  # [sample][dimension]
+    t[:65536] = seq.reshape(-1)
+    t[65536:65536 + 131072] = rng.integers(0, 256, 131072)
+    t[3 * 65536:3 * 65536 + 131072] = rng.integers(0, 256, 131072)
+    return t
+
+
 def make_texture_float4(rgba_f32):
     img = np.ascontiguousarray(rgba_f32, dtype=np.float32)
     h, w, _ = img.shape

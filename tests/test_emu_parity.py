@@ -192,3 +192,40 @@ def test_alpha_holes_let_paths_through(pkg, make_emu):
     b = _run(pkg, [make_emu()], opaque, 96, 64, {"integrator": "pt", "spp": 4, "max_depth": 2})[0]
     diff = np.abs(a[..., :3] - b[..., :3]).max(axis=-1)
     assert (diff > 0.05).mean() > 0.01
+
+
+def test_blue_noise_primary_sampler(pkg, make_emu, make_oracle, orc):
+    """the pt integrator's primary rays draw r0..r3 from blueNoiseSampler (Kernels.cu:391-394,
+    tools.h:163-181) once a table is set.  The sampler itself is pinned against a numpy restatement on a synthetic
+    table of the reference's layout; then product (emulation) == oracle on images and the sampler changes the image."""
+    table = pkg.scenes.synthetic_blue_noise()
+    import ctypes as C
+    f = orc.load().rfwo_blue_noise_sample
+    f.restype, f.argtypes = C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        x, y, s, d = (int(v) for v in rng.integers(0, 1000, 4))
+        xx, yy, ss, dd = x & 127, y & 127, s & 255, d & 255
+        ri = min(dd + (xx + yy * 128) * 8 + 3 * 65536, 5 * 65536 - 1)
+        ranked = (ss ^ int(table[ri])) & 255
+        value = int(table[dd + ranked * 256]) ^ int(table[(dd & 7) + (xx + yy * 128) * 8 + 65536])
+        assert f(table.ctypes.data, x, y, s, d) == np.float32((0.5 + value) * (1.0 / 256.0))
+    scene = pkg.scenes.cornell(96, 64, geometric_emitter=True)
+    scene.camera.aperture = 0.05  # the lens sample uses r2, r3
+    imgs = {}
+    for sampler in ("hash", "bluenoise"):
+        ctxs = [make_emu(), make_oracle()]
+        for c in ctxs:
+            c.set_blue_noise(table)
+        a, b = _run(pkg, ctxs, scene, 96, 64, {"integrator": "pt", "spp": 8, "sampler": sampler})
+        frac, rmse, _ = image_stats(a, b, 2e-2)
+        assert frac <= 1e-2 and rmse <= 3e-2, (sampler, frac, rmse)
+        imgs[sampler] = a
+    assert np.abs(imgs["hash"][..., :3] - imgs["bluenoise"][..., :3]).mean() > 1e-3
+    e = make_emu()
+    e.init(32, 16)
+    scene.upload(e)
+    e.set_setting("integrator", "pt")
+    e.set_setting("sampler", "bluenoise")
+    with pytest.raises(RuntimeError):
+        e.render_frame(scene.camera, pkg.RESET)  # no table: the core refuses instead of silently using the hash RNG

@@ -162,6 +162,27 @@ def test_alpha_cards_layers_and_normal_maps(pkg, make_hip, make_oracle, faithful
     assert abs(total - oc["rays_extend"]) <= 0.002 * oc["rays_extend"]
 
 
+def test_blue_noise_primary_sampler(pkg, make_hip, make_oracle):
+    """The blue-noise primary sampler on the GPU (synthetic table of the reference's layout) against the oracle."""
+    table = pkg.scenes.synthetic_blue_noise()
+    scene = pkg.scenes.cornell(480, 270, geometric_emitter=True)
+    scene.camera.aperture = 0.05
+    out = []
+    for ctx in (make_hip(), make_oracle()):
+        ctx.init(480, 270)
+        scene.upload(ctx)
+        ctx.set_blue_noise(table)
+        for k, v in {"integrator": "pt", "spp": 8, "sampler": "bluenoise"}.items():
+            ctx.set_setting(k, v)
+        ctx.render_frame(scene.camera, pkg.RESET)
+        out.append(ctx)
+    hip, ref = out
+    frac, rmse, _ = image_stats(hip.framebuffer(), ref.framebuffer(), 3e-2)
+    assert frac <= 2e-2, (frac, rmse)
+    m = ref.framebuffer()[..., :3].mean()
+    assert abs(hip.framebuffer()[..., :3].mean() - m) <= 5e-3 * m
+
+
 def test_skinned_tube_refit_on_device(pkg, make_hip, make_oracle):
     """BASELINE config 5 logic on the GPU: host skinning -> set_mesh with unchanged counts -> device refit; every
     frame's image equals a fresh build of that pose and the oracle's."""
