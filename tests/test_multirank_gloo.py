@@ -36,10 +36,11 @@ def _worker(rank, world, port, integrator, w, h, out_path):
     rows = ctx.local_rows()
     local = torch.zeros((rows, w, 4), dtype=torch.float32)
     ctx.read_local_framebuffer_device(local.data_ptr())
-    gathered = [torch.zeros_like(local) for _ in range(world)] if rank == 0 else None
+    # as bench.py: the gather lands directly in the [world][rows][w] staging image the de-interleave reads
+    flat = torch.zeros((world, rows, w, 4), dtype=torch.float32) if rank == 0 else None
+    gathered = list(flat.unbind(0)) if rank == 0 else None
     dist.gather(local, gathered, dst=0)
     if rank == 0:
-        flat = torch.stack(gathered).contiguous()
         full = torch.zeros((h, w, 4), dtype=torch.float32)
         ctx.deinterleave_device(flat.data_ptr(), full.data_ptr())
         np.save(out_path, full.numpy())
