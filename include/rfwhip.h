@@ -77,6 +77,16 @@ RFWHIP_API int rfwhip_set_lights(rfwhip_context *ctx, rfwhip_light_count count, 
  * plugin shim hands it over when it is built there.  With a table and sampler=bluenoise the pt integrator draws the
  * primary-ray jitter / lens sample from blueNoiseSampler (Kernels.cu:391-394) instead of the hash RNG. */
 RFWHIP_API int rfwhip_set_blue_noise(rfwhip_context *ctx, const uint32_t *table, size_t words);
+/* ---- device skinning (extension: rfw::system skins on the host, geometry/gltf/mesh.cpp:18-125, and re-sends the mesh
+ * through set_mesh; these two calls keep the bind pose on the device and take the CPU out of the animation loop) ----
+ * set_mesh_skin: per vertex of mesh `index` (as last set with rfwhip_set_mesh = bind pose) four joint indices, four
+ * weights and the bind-pose vertex normal (xyz, w ignored).
+ * pose_mesh: joint_count column-major 4x4 joint matrices -> vertex = sum_k w_k M[j_k] * base, normal =
+ * normalize(base_normal * inverse(that matrix)) (mesh.cpp:35-44), triangles' vertex/face normals (update_triangles,
+ * mesh.cpp:428-485), then the same device refit as a same-count rfwhip_set_mesh.  rfwhip_update() afterwards. */
+RFWHIP_API int rfwhip_set_mesh_skin(rfwhip_context *ctx, size_t mesh_index, const uint32_t *joints4, const float *weights4,
+									const float *base_normals4, size_t vertex_count);
+RFWHIP_API int rfwhip_pose_mesh(rfwhip_context *ctx, size_t mesh_index, const float *joint_matrices16, size_t joint_count);
 /* update(): once after a batch of set_* — builds the TLAS, uploads descriptors              context.h:108 */
 RFWHIP_API int rfwhip_update(rfwhip_context *ctx);
 

@@ -860,6 +860,64 @@ int rfwo_set_setting(rfwo_context *c, const char *key, const char *val)
 		return fail("unknown setting");
 	return 0;
 }
+/* ---- host skinning: geometry/gltf/mesh.cpp:31-45 (4x4 blend, general 4x4 inverse, row vector times inverse) ---- */
+static int invert4(const float m[16], float inv[16])
+{
+	/* cofactor expansion of a column-major 4x4 */
+	float t[16];
+	t[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+	t[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+	t[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+	t[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+	t[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+	t[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+	t[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+	t[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+	t[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+	t[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+	t[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+	t[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+	t[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+	t[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+	t[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+	t[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+	const float det = m[0] * t[0] + m[1] * t[4] + m[2] * t[8] + m[3] * t[12];
+	if (det == 0.0f)
+		return 0;
+	for (int i = 0; i < 16; i++)
+		inv[i] = t[i] / det;
+	return 1;
+}
+void rfwo_skin_vertices(const float *base_v4, const float *base_n4, const uint32_t *joints4, const float *weights4,
+						const float *mats16, uint32_t joint_count, size_t n, float *out_v4, float *out_n4)
+{
+	for (size_t i = 0; i < n; i++)
+	{
+		float m[16] = {0};
+		for (int k = 0; k < 4; k++)
+		{
+			uint32_t j = joints4[4 * i + k];
+			if (j >= joint_count)
+				j = 0;
+			for (int e = 0; e < 16; e++)
+				m[e] += mats16[16 * j + e] * weights4[4 * i + k];
+		}
+		const float *b = base_v4 + 4 * i;
+		for (int r = 0; r < 4; r++)
+			out_v4[4 * i + r] = m[r] * b[0] + m[4 + r] * b[1] + m[8 + r] * b[2] + m[12 + r] * b[3];
+		float inv[16];
+		if (!invert4(m, inv))
+			memset(inv, 0, sizeof(inv));
+		/* row vector times matrix: result[c] = sum_r n[r] * inv(r, c), element (r, c) = inv[c * 4 + r] */
+		const float *nb = base_n4 + 4 * i;
+		float r3[3];
+		for (int c = 0; c < 3; c++)
+			r3[c] = nb[0] * inv[c * 4 + 0] + nb[1] * inv[c * 4 + 1] + nb[2] * inv[c * 4 + 2] + 0.0f * inv[c * 4 + 3];
+		const float len = sqrtf(r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2]);
+		out_n4[4 * i + 0] = r3[0] / len, out_n4[4 * i + 1] = r3[1] / len, out_n4[4 * i + 2] = r3[2] / len, out_n4[4 * i + 3] = 0.0f;
+	}
+}
+
 #define BLUE_NOISE_WORDS (5u * 65536u)
 int rfwo_set_blue_noise(rfwo_context *c, const uint32_t *table, size_t words)
 {

@@ -64,6 +64,11 @@ int rfwo_trace_rays(rfwo_context *ctx, size_t n, const float *org, const float *
 /* traversal statistics of everything traced since the last reset: rays/inner/tris for closest + shadow */
 int rfwo_get_counters(rfwo_context *ctx, uint64_t out[8], int reset);
 
+/* SceneMesh::set_pose (geometry/gltf/mesh.cpp:31-45) on plain arrays: n vertices, base positions / normals as float4,
+ * joints as 4 uint32 per vertex, mats = column-major 4x4 per joint.  out_n.w = 0. */
+void rfwo_skin_vertices(const float *base_v4, const float *base_n4, const uint32_t *joints4, const float *weights4,
+						const float *mats16, uint32_t joint_count, size_t n, float *out_v4, float *out_n4);
+
 /* ---- known-answer hooks ---- */
 uint32_t rfwo_xor128_next(uint32_t state[4]);				  /* utils/xor128.h:20-27 */
 float rfwo_rng_rand(uint32_t state[4]);						  /* utils/rng.h:14 */

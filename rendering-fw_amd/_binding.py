@@ -66,7 +66,9 @@ class CoreBinding:
             f = self._fn(name)
             f.restype, f.argtypes = res, args
         # device-side presents: only the rendercore (and its emulation build) export these
-        for name, (res, args) in {"read_framebuffer_device": (i32, [vp, vp]),
+        for name, (res, args) in {"set_mesh_skin": (i32, [vp, sz, vp, vp, vp, sz]),
+                                  "pose_mesh": (i32, [vp, sz, vp, sz]),
+                                  "read_framebuffer_device": (i32, [vp, vp]),
                                   "read_local_framebuffer_device": (i32, [vp, vp]),
                                   "deinterleave_device": (i32, [vp, vp, vp]),
                                   "get_counters": (i32, [vp, C.POINTER(abi.Counters), i32])}.items():
@@ -153,6 +155,23 @@ class CoreBinding:
         p = _f32(pixels).reshape(-1, 3)
         assert len(p) == width * height
         self._check(self._fn("set_sky")(self._ctx, p.ctypes.data, int(width), int(height)))
+
+    def set_mesh_skin(self, index, joints, weights, base_normals):
+        """Device skinning: per-vertex joints (V x 4 uint32), weights (V x 4) and bind-pose normals (V x 3|4) of mesh
+        `index`, whose last set_mesh vertices are the bind pose."""
+        j = np.ascontiguousarray(joints, dtype=np.uint32).reshape(-1, 4)
+        w = _f32(weights).reshape(-1, 4)
+        n = _f32(base_normals).reshape(len(j), -1)
+        n4 = np.zeros((len(j), 4), np.float32)
+        n4[:, :3] = n[:, :3]
+        self._keep = (j, w, n4)
+        self._check(self._fn("set_mesh_skin")(self._ctx, int(index), j.ctypes.data, w.ctypes.data, n4.ctypes.data, len(j)))
+
+    def pose_mesh(self, index, joint_matrices):
+        """joint_matrices: (J, 4, 4) row-major numpy matrices acting on column vectors (object -> posed)."""
+        m = _f32(joint_matrices).reshape(-1, 4, 4)
+        cm = np.ascontiguousarray(np.transpose(m, (0, 2, 1)))  # column-major storage
+        self._check(self._fn("pose_mesh")(self._ctx, int(index), cm.ctypes.data, len(cm)))
 
     def set_blue_noise(self, table):
         """The reference's 5 x 65536-word blue-noise table (createBlueNoiseBuffer()); see scenes.synthetic_blue_noise."""

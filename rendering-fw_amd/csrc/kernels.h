@@ -60,5 +60,13 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 
 // after a refit of the BVH2 boxes: copy them into the 4-wide traversal nodes of the same BLAS (Node4::src)
 void launch_refresh4(rt::Node4 *nodes4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
+// linear-blend skinning on the device (geometry/gltf/mesh.cpp:31-45): verts/vnormals <- base * sum(w_k * M[j_k]);
+// mats: joint_count column-major 4x4
+void launch_skin_vertices(rt::f4 *verts, rt::f4 *vnormals, const rt::f4 *base_verts, const rt::f4 *base_normals,
+						  const uint32_t *joints4, const rt::f4 *weights4, const float *mats, uint32_t joint_count,
+						  uint32_t vertex_count, stream_t s);
+// update_triangles() of the same file for the shading records: vertex normals of the three corners + face normal
+void launch_skin_shade(rt::TriShade *shade, const rt::f4 *verts, const rt::f4 *vnormals, const uint32_t *indices,
+					   uint32_t tri_count, stream_t s);
 
 } // namespace rtk

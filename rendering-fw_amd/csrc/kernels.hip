@@ -413,6 +413,61 @@ RT_FN void rng_states_item(uint32_t *states, const uint32_t base[4], const uint3
 	}
 }
 
+// ---- device skinning ------------------------------------------------------------------------------
+// SceneMesh::set_pose (geometry/gltf/mesh.cpp:31-45): skinMatrix = sum_k w_k * jointMatrix[j_k]; vertex = skinMatrix *
+// base; normal = normalize(baseNormal * inverse(skinMatrix)) — a row vector times the inverse, i.e. the
+// inverse-transpose of the upper 3x3 applied to the normal.
+RT_FN void skin_vertex_item(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const uint32_t *joints4,
+							const f4 *weights4, const float *mats, uint32_t joint_count, uint32_t i)
+{
+	const f4 w4 = weights4[i];
+	const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+	float m[16];
+	for (int e = 0; e < 16; e++)
+		m[e] = 0.0f;
+	for (int k = 0; k < 4; k++)
+	{
+		uint32_t j = joints4[4u * i + k];
+		if (j >= joint_count)
+			j = 0;
+		const float *mj = mats + 16u * j;
+		for (int e = 0; e < 16; e++)
+			m[e] += mj[e] * w[k];
+	}
+	const f4 b = base_verts[i];
+	// column-major: element (row r, column c) = m[c * 4 + r]
+	verts[i] = mk4(m[0] * b.x + m[4] * b.y + m[8] * b.z + m[12] * b.w, m[1] * b.x + m[5] * b.y + m[9] * b.z + m[13] * b.w,
+				   m[2] * b.x + m[6] * b.y + m[10] * b.z + m[14] * b.w, m[3] * b.x + m[7] * b.y + m[11] * b.z + m[15] * b.w);
+	// inverse-transpose of the upper 3x3 = cofactor matrix / determinant
+	const float a00 = m[0], a01 = m[4], a02 = m[8], a10 = m[1], a11 = m[5], a12 = m[9], a20 = m[2], a21 = m[6], a22 = m[10];
+	const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+	const float c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
+	const float c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
+	const float det = a00 * c00 + a01 * c01 + a02 * c02;
+	const float id = 1.0f / det;
+	const f4 n = base_normals[i];
+	const f3 r = mk3((c00 * n.x + c01 * n.y + c02 * n.z) * id, (c10 * n.x + c11 * n.y + c12 * n.z) * id,
+					 (c20 * n.x + c21 * n.y + c22 * n.z) * id);
+	const f3 rn = r * (1.0f / length(r));
+	vnormals[i] = mk4(rn.x, rn.y, rn.z, 0.0f);
+}
+// SceneMesh::update_triangles (mesh.cpp:428-485) on the shading record: vN0..2 and N = normalize(cross(v1-v0, v2-v0))
+RT_FN void skin_shade_item(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t i)
+{
+	uint32_t a, b, c;
+	if (indices)
+		a = indices[3u * i], b = indices[3u * i + 1u], c = indices[3u * i + 2u];
+	else
+		a = 3u * i, b = a + 1u, c = a + 2u;
+	const f3 v0 = xyz(verts[a]), v1 = xyz(verts[b]), v2 = xyz(verts[c]);
+	const f3 N = normalize(cross(v1 - v0, v2 - v0));
+	const f4 n0 = vnormals[a], n1 = vnormals[b], n2 = vnormals[c];
+	TriShade &t = shade[i];
+	t.n0 = mk4(n0.x, n0.y, n0.z, N.x);
+	t.n1 = mk4(n1.x, n1.y, n1.z, N.y);
+	t.n2 = mk4(n2.x, n2.y, n2.z, N.z);
+}
+
 RT_FN void refresh4_item(Node4 *nodes4, const Node *nodes2, uint32_t i)
 {
 	Node4 &n = nodes4[i];
@@ -893,6 +948,34 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 					   local_rows, world);
 }
 
+__global__ void __launch_bounds__(BLOCK) k_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals,
+														 const uint32_t *joints4, const f4 *weights4, const float *mats,
+														 uint32_t joint_count, uint32_t vertex_count)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < vertex_count)
+		skin_vertex_item(verts, vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices,
+													  uint32_t tri_count)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < tri_count)
+		skin_shade_item(shade, verts, vnormals, indices, i);
+}
+void launch_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const uint32_t *joints4,
+						  const f4 *weights4, const float *mats, uint32_t joint_count, uint32_t vertex_count, stream_t s)
+{
+	if (vertex_count)
+		hipLaunchKernelGGL(k_skin_vertices, dim3((vertex_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, verts,
+						   vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, vertex_count);
+}
+void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t tri_count, stream_t s)
+{
+	if (tri_count)
+		hipLaunchKernelGGL(k_skin_shade, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, shade, verts,
+						   vnormals, indices, tri_count);
+}
 void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t s)
 {
 	if (count4)
@@ -976,6 +1059,17 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 {
 	for (uint32_t i = 0; i < W * H; i++)
 		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+void launch_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const uint32_t *joints4,
+						  const f4 *weights4, const float *mats, uint32_t joint_count, uint32_t vertex_count, stream_t)
+{
+	for (uint32_t i = 0; i < vertex_count; i++)
+		skin_vertex_item(verts, vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, i);
+}
+void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t tri_count, stream_t)
+{
+	for (uint32_t i = 0; i < tri_count; i++)
+		skin_shade_item(shade, verts, vnormals, indices, i);
 }
 void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t)
 {

@@ -272,6 +272,10 @@ struct MeshRec
 	bool resident = false; // placed in the global arrays by the last update()
 	bool dirty = true;	   // host staging newer than the global arrays
 	bool refit_pending = false;
+	// device skinning (rfwhip_set_mesh_skin / rfwhip_pose_mesh)
+	bool skinned = false, posed = false;
+	DevBuf d_base_verts, d_base_normals, d_joints, d_weights, d_vnormals, d_joint_mats;
+	uint32_t joint_count = 0;
 };
 
 struct InstRec
@@ -732,6 +736,9 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	}
 	m.vertexCount = mesh->vertexCount, m.triCount = mesh->triangleCount, m.indexed = mesh->indices != nullptr;
 	m.used = true;
+	m.posed = false; // host vertices again; skinning data (if any) stays valid while the counts stay
+	if (m.skinned && !same_topology)
+		m.skinned = false;
 	fill_shade_records(m, mesh->triangles);
 	// mesh bounds (for the instance boxes of the TLAS)
 	for (int a = 0; a < 3; a++)
@@ -863,6 +870,88 @@ extern "C" int rfwhip_set_lights(rfwhip_context *c, rfwhip_light_count n, const 
 	return RFWHIP_OK;
 }
 
+// ---- device skinning (not part of the RenderContext interface: rfw::system skins on the host,
+// geometry/gltf/mesh.cpp:18-125, and hands the result to set_mesh) ---------------------------------------------------
+extern "C" int rfwhip_set_mesh_skin(rfwhip_context *c, size_t index, const uint32_t *joints4, const float *weights4,
+									const float *base_normals4, size_t vertex_count)
+{
+	CTX_ENTER(c);
+	if (index >= c->meshes.size() || !c->meshes[index].used)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_set_mesh_skin: mesh %zu has not been set", index);
+	MeshRec &m = c->meshes[index];
+	if (!joints4 || !weights4 || !base_normals4 || vertex_count != m.vertexCount)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_mesh_skin: need joints, weights and normals for the mesh's %zu vertices", m.vertexCount);
+	if (m.posed)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_set_mesh_skin: mesh %zu is posed; set_mesh the bind pose first", index);
+	RF_TRY(sync_all(c));
+	const size_t n = vertex_count;
+	RF_TRY(m.d_base_verts.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_base_normals.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_vnormals.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_joints.ensure(n * 16));
+	RF_TRY(m.d_weights.ensure(n * sizeof(f4)));
+	RF_TRY(dm::d2d(m.d_base_verts.p, m.d_verts.p, n * sizeof(f4), c->stream)); // the vertices of the last set_mesh = bind pose
+	RF_TRY(dm::h2d(m.d_base_normals.p, base_normals4, n * sizeof(f4), c->stream));
+	RF_TRY(dm::h2d(m.d_joints.p, joints4, n * 16, c->stream));
+	RF_TRY(dm::h2d(m.d_weights.p, weights4, n * sizeof(f4), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	m.skinned = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_pose_mesh(rfwhip_context *c, size_t index, const float *joint_matrices16, size_t joint_count)
+{
+	CTX_ENTER(c);
+	if (index >= c->meshes.size() || !c->meshes[index].used || !c->meshes[index].skinned)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_pose_mesh: mesh %zu has no skin (rfwhip_set_mesh_skin)", index);
+	MeshRec &m = c->meshes[index];
+	if (!joint_matrices16 || !joint_count)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_pose_mesh: no joint matrices");
+	if (!m.resident || m.dirty)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_pose_mesh: mesh %zu is not resident yet (rfwhip_update first)", index);
+	RF_TRY(sync_all(c));
+	RF_TRY(m.d_joint_mats.ensure(joint_count * 64));
+	RF_TRY(dm::h2d(m.d_joint_mats.p, joint_matrices16, joint_count * 64, c->stream));
+	m.joint_count = (uint32_t)joint_count;
+	dm::event_t ea, eb;
+	const bool timed = c->stage_timing != 0;
+	if (timed)
+	{
+		dm::event_create(&ea), dm::event_create(&eb);
+		dm::event_record(ea, c->stream);
+	}
+	rtk::launch_skin_vertices(m.d_verts.as<f4>(), m.d_vnormals.as<f4>(), m.d_base_verts.as<f4>(), m.d_base_normals.as<f4>(),
+							  m.d_joints.as<uint32_t>(), m.d_weights.as<f4>(), m.d_joint_mats.as<float>(), m.joint_count,
+							  (uint32_t)m.vertexCount, c->stream);
+	rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(), m.d_vnormals.as<f4>(),
+						   m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, c->stream);
+	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+					  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
+					  (uint32_t)m.triCount, m.d_flags.as<uint32_t>(), c->stream);
+	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base,
+						 c->stream);
+	RF_TRY(dm::last_launch_error());
+	if (timed)
+		dm::event_record(eb, c->stream);
+	// the instance boxes of the TLAS come from the mesh bounds = the refitted root (its two children's union)
+	rt::Node root[2];
+	const rt::Node *dn = c->d_nodes.as<rt::Node>() + m.node_base;
+	RF_TRY(dm::d2h(&root[0], dn, sizeof(rt::Node), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	for (int a = 0; a < 3; a++)
+		m.bounds_min[a] = root[0].bmin[a] - 2e-5f, m.bounds_max[a] = root[0].bmax[a] + 2e-5f;
+	if (timed)
+	{
+		c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
+		c->kernel_launches[KF_REFIT] += 5;
+		c->stats.animationTime = dm::event_ms(ea, eb);
+		dm::event_destroy(ea), dm::event_destroy(eb);
+	}
+	m.posed = true;
+	c->scene_dirty = true; // instance boxes change: the TLAS is rebuilt in update()
+	return RFWHIP_OK;
+}
+
 extern "C" int rfwhip_update(rfwhip_context *c)
 {
 	CTX_ENTER(c);
@@ -956,6 +1045,10 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 								  m.d_flags.as<uint32_t>(), c->stream);
 				rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(),
 									 c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+				if (m.posed) // the host copy of the shading records is the bind pose
+					rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(),
+										   m.d_vnormals.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
+										   (uint32_t)m.triCount, c->stream);
 				RF_TRY(dm::last_launch_error());
 			}
 			m.resident = true, m.dirty = false;

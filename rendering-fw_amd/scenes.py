@@ -726,3 +726,25 @@ def skinned_tube_pose(frame, rings=160, seg=96):
     fn = np.cross(pos[idx[:, 1]] - pos[idx[:, 0]], pos[idx[:, 2]] - pos[idx[:, 0]])
     vn = _accumulate_vertex_normals(len(pos), idx, fn)
     return pos, idx, vn
+
+
+def skinned_tube_rig(rings=160, seg=96):
+    """The tube of skinned_tube as a RIG: bind-pose vertices / indices / vertex normals plus per-vertex joints and
+    weights for two joints (0: root, 1: the bone that bends the upper half) — what a glTF skin provides
+    (geometry/gltf/mesh.cpp:360-372)."""
+    v, idx, vn = skinned_tube_pose(0.0, rings, seg)  # frame 0: the bend angle is 0 = bind pose
+    w1 = np.clip((v[:, 1] - 3.0) / 2.0, 0, 1).astype(np.float32)
+    joints = np.zeros((len(v), 4), np.uint32)
+    joints[:, 1] = 1
+    weights = np.zeros((len(v), 4), np.float32)
+    weights[:, 0], weights[:, 1] = 1.0 - w1, w1
+    return v, idx, vn, joints, weights
+
+
+def skinned_tube_joint_matrices(frame):
+    """(2, 4, 4) joint matrices of the rig at `frame` (row-major, acting on column vectors)."""
+    ang = 0.9 * math.sin(frame * 0.35)
+    c, s_ = math.cos(ang), math.sin(ang)
+    rot = np.array([[c, -s_, 0, 0], [s_, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    m1 = _translate(0.0, 4.0, 0.0) @ rot @ _translate(0.0, -4.0, 0.0)
+    return np.stack([np.eye(4), m1]).astype(np.float32)

@@ -229,3 +229,67 @@ def test_blue_noise_primary_sampler(pkg, make_emu, make_oracle, orc):
     e.set_setting("sampler", "bluenoise")
     with pytest.raises(RuntimeError):
         e.render_frame(scene.camera, pkg.RESET)  # no table: the core refuses instead of silently using the hash RNG
+
+
+def _host_skin(orc, v, vn, joints, weights, mats):
+    """rfwo_skin_vertices = SceneMesh::set_pose restated (geometry/gltf/mesh.cpp:31-45)."""
+    L = orc.load()
+    n = len(v)
+    v4 = np.ones((n, 4), np.float32)
+    v4[:, :3] = v
+    n4 = np.zeros((n, 4), np.float32)
+    n4[:, :3] = vn
+    j = np.ascontiguousarray(joints, np.uint32)
+    w = np.ascontiguousarray(weights, np.float32)
+    cm = np.ascontiguousarray(np.transpose(np.asarray(mats, np.float32), (0, 2, 1)))
+    ov, on = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    import ctypes as C
+    L.rfwo_skin_vertices.restype = None
+    L.rfwo_skin_vertices.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.rfwo_skin_vertices(v4.ctypes.data, n4.ctypes.data, j.ctypes.data, w.ctypes.data, cm.ctypes.data, len(cm), n,
+                         ov.ctypes.data, on.ctypes.data)
+    return ov[:, :3].copy(), on[:, :3].copy()
+
+
+def test_device_skinning_equals_host_skinning(pkg, make_emu, make_oracle, orc):
+    """rfwhip_set_mesh_skin + rfwhip_pose_mesh (skin, update the shading normals, refit — all on the
+    device side) give the image of host skinning + set_mesh, on the product and on the oracle."""
+    w, h = 96, 64
+    rings, seg = 24, 16
+    scene = pkg.scenes.skinned_tube(0.0, rings=rings, seg=seg, width=w, height=h)
+    v, idx, vn, joints, weights = pkg.scenes.skinned_tube_rig(rings, seg)
+    tris0 = pkg.scenes.make_triangles(v, idx, normals=vn, material=scene.meshes[0]["triangles"]["material"][0])
+    scene.meshes[0]["triangles"] = tris0
+    live = make_emu()
+    live.init(w, h)
+    scene.upload(live)
+    live.set_setting("integrator", "pt")
+    live.set_setting("spp", 4)
+    live.set_mesh_skin(0, joints, weights, vn)
+    for frame in (2.0, 5.0):
+        mats = pkg.scenes.skinned_tube_joint_matrices(frame)
+        live.pose_mesh(0, mats)
+        live.update()
+        live.render_frame(scene.camera, pkg.RESET)
+        sv, sn = _host_skin(orc, v, vn, joints, weights, mats)
+        # the rig reproduces the analytic pose of scenes.skinned_tube_pose
+        assert np.abs(sv - pkg.scenes.skinned_tube_pose(frame, rings, seg)[0]).max() < 1e-5
+        posed = pkg.scenes.skinned_tube(0.0, rings=rings, seg=seg, width=w, height=h)
+        m = posed.meshes[0]
+        v4 = np.ones((len(sv), 4), np.float32)
+        v4[:, :3] = sv
+        m["vertices"] = v4
+        m["triangles"] = pkg.scenes.make_triangles(sv, idx, normals=sn, material=tris0["material"][0])
+        imgs = _run(pkg, [make_emu(), make_oracle()], posed, w, h, {"integrator": "pt", "spp": 4})
+        frac, rmse, _ = image_stats(live.framebuffer(), imgs[0], 1e-3)
+        assert frac <= 5e-3, ("device skin vs host skin", frame, frac, rmse)
+        frac, rmse, _ = image_stats(live.framebuffer(), imgs[1], 2e-2)
+        assert frac <= 2e-2, ("device skin vs oracle", frame, frac, rmse)
+    # a rebuild of another mesh moves the arrays: the posed mesh keeps its pose and its shading normals
+    other = pkg.scenes.skinned_tube(0.0, rings=4, seg=6, width=w, height=h).meshes[0]
+    live.set_mesh(2, other["vertices"], other["triangles"], other["indices"])
+    live.update()
+    before = live.framebuffer().copy()
+    live.render_frame(scene.camera, pkg.RESET)
+    frac, rmse, _ = image_stats(live.framebuffer(), before, 1e-4)
+    assert frac <= 1e-3, (frac, rmse)

@@ -162,6 +162,43 @@ def test_alpha_cards_layers_and_normal_maps(pkg, make_hip, make_oracle, faithful
     assert abs(total - oc["rays_extend"]) <= 0.002 * oc["rays_extend"]
 
 
+def test_device_skinning_equals_host_skinning(pkg, make_hip, make_oracle, orc):
+    """SURVEY §8 f4 on the GPU: skin + shading normals + refit on the device == host skinning (oracle's restatement of
+    SceneMesh::set_pose) + set_mesh, at config-5 size (30 720 triangles)."""
+    from test_emu_parity import _host_skin
+    w, h = 480, 270
+    scene = pkg.scenes.skinned_tube(0.0, width=w, height=h)
+    v, idx, vn, joints, weights = pkg.scenes.skinned_tube_rig()
+    mat = scene.meshes[0]["triangles"]["material"][0]
+    scene.meshes[0]["triangles"] = pkg.scenes.make_triangles(v, idx, normals=vn, material=mat)
+    live = make_hip()
+    live.init(w, h)
+    scene.upload(live)
+    live.set_setting("integrator", "pt")
+    live.set_setting("spp", 4)
+    live.set_setting("stage_timing", 1)
+    live.set_mesh_skin(0, joints, weights, vn)
+    for frame in (1.0, 3.5):
+        mats = pkg.scenes.skinned_tube_joint_matrices(frame)
+        live.pose_mesh(0, mats)
+        live.update()
+        live.render_frame(scene.camera, pkg.RESET)
+        sv, sn = _host_skin(orc, v, vn, joints, weights, mats)
+        posed = pkg.scenes.skinned_tube(0.0, width=w, height=h)
+        m = posed.meshes[0]
+        v4 = np.ones((len(sv), 4), np.float32)
+        v4[:, :3] = sv
+        m["vertices"] = v4
+        m["triangles"] = pkg.scenes.make_triangles(sv, idx, normals=sn, material=mat)
+        fresh, ref = _pair(pkg, make_hip, make_oracle, posed, w, h, {"integrator": "pt", "spp": 4})
+        frac, rmse, _ = image_stats(live.framebuffer(), fresh.framebuffer(), 1e-3)
+        assert frac <= 5e-3, (frame, frac, rmse)
+        frac, rmse, _ = image_stats(live.framebuffer(), ref.framebuffer(), 3e-2)
+        assert frac <= 2e-2, (frame, frac, rmse)
+    ms, launches = live.get_kernel_time("refit")
+    assert launches == 10 and ms > 0.0  # per pose: skin vertices, skin shading records, triangles, BVH2 boxes, Node4s
+
+
 def test_blue_noise_primary_sampler(pkg, make_hip, make_oracle):
     """The blue-noise primary sampler on the GPU (synthetic table of the reference's layout) against the oracle."""
     table = pkg.scenes.synthetic_blue_noise()
