@@ -44,9 +44,11 @@ def usable_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one wavefront batch; config 3: >= 64 spp)")
+    ap.add_argument("--spp", type=int, default=128,
+                    help="samples per pixel per step (one wavefront batch; config 3: >= 64 spp; 128 keeps the launches of an "
+                         "8-GPU strip split large: path state = 53 GB of the 288 GB per GPU at N = 1)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=708, help="terrain cells per side (708 -> 1 002 528 triangles)")
@@ -56,6 +58,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
     ap.add_argument("--lds-nodes", type=int, default=-1,
                     help="top-of-tree 4-wide nodes kept in LDS by the traversal kernels (-1: kernel capacity, 0: off)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="N > 1: 1 = stream-ordered present/gather/de-interleave overlapping the next step's kernels; "
+                         "0 = host-synchronous gather per step (reports gather_ms_per_step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -119,7 +124,16 @@ def main():
     def step(k, first):
         # render_frame(camera, status): RESET on the first step of a series, CONVERGE afterwards (context.h:19-23)
         ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
-        if world > 1:
+        if world > 1 and args.pipeline:
+            # everything stream-ordered, nothing blocks the host: present on torch's current stream (ordered behind the
+            # frame's kernels by an event), RCCL gather behind it, de-interleave on the root behind the gather; the
+            # next step's kernels run on the core's own streams meanwhile (its accumulate waits for this present).
+            ts = torch.cuda.current_stream().cuda_stream
+            ctx.read_local_framebuffer_stream(local_fb.data_ptr(), ts)
+            dist.gather(local_fb, gathered, dst=0)
+            if rank == 0:
+                ctx.deinterleave_stream(gathered_flat.data_ptr(), full_fb.data_ptr(), ts)
+        elif world > 1:
             ctx.wait()
             t = time.perf_counter()
             ctx.read_local_framebuffer_device(local_fb.data_ptr())
@@ -248,12 +262,14 @@ def main():
                                    "triangles + %d point lights, synthetic 2048x1024 HDR sky"
                                    % (scene.name, scene.triangle_count(), W, H, args.integrator, args.max_depth, args.spp,
                                       len(scene.area_lights), len(scene.point_lights)),
-                       "parallelism": "image strips of 8 rows interleaved over %d rank(s), one RCCL gather per step" % world,
-                       "spp_per_step": args.spp},
+                       "parallelism": "image strips of 8 rows interleaved over %d rank(s), one RCCL gather per step%s"
+                                      % (world, " (stream-ordered, overlapping the next step)" if (world > 1 and args.pipeline) else ""),
+                       "spp_per_step": args.spp, "streams": args.streams},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_times.items()},
             "last_frame_counts": {k: stats[k] for k in ("primaryCount", "secondaryCount", "deepCount", "shadowCount")},
-            "gather_ms_per_step": round(sum(gather_ms) / len(gather_ms), 4) if gather_ms else 0.0,
+            "gather_ms_per_step": (round(sum(gather_ms) / len(gather_ms), 4) if gather_ms else
+                                   (None if (world > 1 and args.pipeline) else 0.0)),
             "setup_s": {"scene": round(t_scene, 2), "upload_and_bvh": round(t_upload, 2)},
             "image_mean": float(full_fb[..., :3].mean().item()),
         }

@@ -111,6 +111,13 @@ RFWHIP_API int rfwhip_read_local_framebuffer_device(rfwhip_context *ctx, void *r
 /* Root-side inverse of the strip interleave: gathered = [world][local_rows][width] float4 -> [height][width]. */
 RFWHIP_API int rfwhip_deinterleave_device(rfwhip_context *ctx, const void *gathered_device, void *rgba_device);
 
+/* Stream-ordered forms of the two calls above: enqueue only, no host synchronisation.  hip_stream is a hipStream_t of the
+ * caller (e.g. torch's current stream); the present is ordered behind everything this context has enqueued and the
+ * context's next rfwhip_render waits on the device until the present has read the accumulator. */
+RFWHIP_API int rfwhip_read_local_framebuffer_stream(rfwhip_context *ctx, void *rgba_device, void *hip_stream);
+RFWHIP_API int rfwhip_deinterleave_stream(rfwhip_context *ctx, const void *gathered_device, void *rgba_device,
+										  void *hip_stream);
+
 /* get_probe_results / set_probe_index                                                       context.h:104,109 */
 RFWHIP_API int rfwhip_set_probe_index(rfwhip_context *ctx, uint32_t x, uint32_t y);
 RFWHIP_API int rfwhip_get_probe_results(rfwhip_context *ctx, uint32_t *instance_index, uint32_t *primitive_index,

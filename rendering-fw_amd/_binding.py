@@ -69,6 +69,8 @@ class CoreBinding:
         for name, (res, args) in {"set_mesh_skin": (i32, [vp, sz, vp, vp, vp, sz]),
                                   "pose_mesh": (i32, [vp, sz, vp, sz]),
                                   "read_framebuffer_device": (i32, [vp, vp]),
+                                  "read_local_framebuffer_stream": (i32, [vp, vp, vp]),
+                                  "deinterleave_stream": (i32, [vp, vp, vp, vp]),
                                   "read_local_framebuffer_device": (i32, [vp, vp]),
                                   "deinterleave_device": (i32, [vp, vp, vp]),
                                   "get_counters": (i32, [vp, C.POINTER(abi.Counters), i32])}.items():
@@ -231,6 +233,15 @@ class CoreBinding:
     def deinterleave_device(self, gathered_ptr, out_ptr):
         """Root side of the multi-GPU gather: [world][local_rows][width] float4 -> [height][width] float4."""
         self._check(self._fn("deinterleave_device")(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr)))
+
+    def read_local_framebuffer_stream(self, device_ptr, stream):
+        """Stream-ordered present of this rank's strips on the caller's hipStream_t (an int, e.g.
+        torch.cuda.current_stream().cuda_stream); no host synchronisation."""
+        self._check(self._fn("read_local_framebuffer_stream")(self._ctx, C.c_void_p(device_ptr), C.c_void_p(stream)))
+
+    def deinterleave_stream(self, gathered_ptr, out_ptr, stream):
+        self._check(self._fn("deinterleave_stream")(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr),
+                                                    C.c_void_p(stream)))
 
     def local_rows(self):
         return int(self._fn("local_rows")(self._ctx))

@@ -312,6 +312,8 @@ struct rfwhip_context
 	void *sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	DevBuf d_counters_sub[MAX_SUB]; // [0] is d_counters' alias slot (unused), 1.. are the extra sub-batches' counters
 	dm::event_t ev_prologue, ev_resolve, ev_sub_done[MAX_SUB];
+	dm::event_t ev_present_in, ev_present_out; // hand-off to / from a caller's stream (rfwhip_*_stream)
+	bool present_pending = false;
 	bool events_ready = false;
 	int subs_last = 1; // sub-batches of the most recent render call
 	bool cleaned = false;
@@ -511,9 +513,10 @@ static void free_all(rfwhip_context *c)
 	if (c->events_ready)
 	{
 		dm::event_destroy(c->ev_prologue), dm::event_destroy(c->ev_resolve);
+		dm::event_destroy(c->ev_present_in), dm::event_destroy(c->ev_present_out);
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
 			dm::event_destroy(c->ev_sub_done[i]);
-		c->events_ready = false;
+		c->events_ready = false, c->present_pending = false;
 	}
 	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
 	{
@@ -1299,6 +1302,8 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 	{
 		RF_TRY(dm::event_create(&c->ev_prologue));
 		RF_TRY(dm::event_create(&c->ev_resolve));
+		RF_TRY(dm::event_create(&c->ev_present_in));
+		RF_TRY(dm::event_create(&c->ev_present_out));
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
 			RF_TRY(dm::event_create(&c->ev_sub_done[i]));
 		c->events_ready = true;
@@ -1351,6 +1356,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	}
 	void *s0 = c->stream;
 	// ---- prologue on stream 0 ----
+	if (c->present_pending)
+	{
+		// a present enqueued on the caller's stream (rfwhip_read_local_framebuffer_stream) still reads the accumulator
+		RF_TRY(dm::stream_wait_event(s0, c->ev_present_out));
+		c->present_pending = false;
+	}
 	if (status == RFWHIP_RESET)
 	{
 		RF_TRY(dm::zero(c->d_acc.p, (size_t)c->fr.local_rows * c->W * sizeof(f4), s0));
@@ -1581,6 +1592,39 @@ extern "C" int rfwhip_read_local_framebuffer_device(rfwhip_context *c, void *rgb
 		return set_error(RFWHIP_ERR_STATE, "no render target");
 	RF_TRY(present(c, (f4 *)rgba_device, 0));
 	return dm::sync(c->stream);
+}
+
+// Stream-ordered variants: nothing blocks the host.  The present runs on the CALLER's stream after everything this
+// context has enqueued so far; the context's next render waits (on the device) until that present has read the
+// accumulator.  With torch.distributed the caller passes torch's current stream, so the RCCL gather that follows is
+// ordered behind the present by plain stream order, and the next frame's kernels overlap the gather.
+extern "C" int rfwhip_read_local_framebuffer_stream(rfwhip_context *c, void *rgba_device, void *hip_stream)
+{
+	CTX_ENTER(c);
+	if (!rgba_device)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null destination");
+	if (!c->W)
+		return set_error(RFWHIP_ERR_STATE, "no render target");
+	RF_TRY(ensure_sub_batches(c, 1)); // creates the hand-off events
+	RF_TRY(dm::event_record(c->ev_present_in, c->stream));
+	RF_TRY(dm::stream_wait_event(hip_stream, c->ev_present_in));
+	rtk::Params p;
+	fill_params(c, nullptr, p);
+	const float scale = c->samples_done ? 1.0f / (float)c->samples_done : 0.0f;
+	rtk::launch_present(p, (f4 *)rgba_device, scale, 0, hip_stream);
+	RF_TRY(dm::last_launch_error());
+	RF_TRY(dm::event_record(c->ev_present_out, hip_stream));
+	c->present_pending = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_deinterleave_stream(rfwhip_context *c, const void *gathered_device, void *rgba_device, void *hip_stream)
+{
+	CTX_ENTER(c);
+	if (!gathered_device || !rgba_device)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null buffer");
+	rtk::launch_deinterleave((const f4 *)gathered_device, (f4 *)rgba_device, c->W, c->H, local_rows_of(c), (uint32_t)c->world, hip_stream);
+	return dm::last_launch_error();
 }
 
 extern "C" int rfwhip_deinterleave_device(rfwhip_context *c, const void *gathered_device, void *rgba_device)

@@ -10,19 +10,27 @@ import torch
 from __graft_entry__ import load_package
 pkg = load_package()
 W, H = 1920, 1080
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+streams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+pipeline = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 scene = pkg.scenes.terrain(n=708, width=W, height_px=H)
 
 def run(rank, world, steps=10, warm=3):
     ctx = pkg.RenderContext(0, rank, world); ctx.init(W, H); scene.upload(ctx)
-    ctx.set_setting("integrator", "pt"); ctx.set_setting("spp", spp)
+    ctx.set_setting("integrator", "pt"); ctx.set_setting("spp", spp); ctx.set_setting("streams", streams)
     rows = ctx.local_rows()
     local = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0")
     flat = torch.empty((world, rows, W, 4), dtype=torch.float32, device="cuda:0")
     full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    ts = torch.cuda.current_stream().cuda_stream
     def step(first):
         ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
-        if world > 1:
+        if world > 1 and pipeline:
+            ctx.read_local_framebuffer_stream(local.data_ptr(), ts)
+            flat[rank].copy_(local, non_blocking=True)   # stands in for the gather's landing copy
+            if rank == 0:
+                ctx.deinterleave_stream(flat.data_ptr(), full.data_ptr(), ts)
+        elif world > 1:
             ctx.wait()
             ctx.read_local_framebuffer_device(local.data_ptr())
             flat[rank].copy_(local)                      # stands in for the gather's landing copy
@@ -39,8 +47,9 @@ def run(rank, world, steps=10, warm=3):
     return dt
 
 t1 = run(0, 1)
-print("spp", spp, "world 1: %.3f ms/step" % t1, flush=True)
-for world in (2, 4, 8):
+print("spp", spp, "streams", streams, "pipeline", pipeline, "world 1: %.3f ms/step" % t1, flush=True)
+worlds = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 4, 8]
+for world in worlds:
     ts = [run(r, world) for r in range(world)]
     tn = max(ts)
-    print("world %d: slowest rank %.3f ms/step (min %.3f)  projected efficiency %.3f" % (world, tn, min(ts), t1 / (world * tn)), flush=True)
+    print("world %d: slowest rank %.3f ms/step (min %.3f)  projected efficiency %.3f  ranks %s" % (world, tn, min(ts), t1 / (world * tn), " ".join("%.2f" % t for t in ts)), flush=True)

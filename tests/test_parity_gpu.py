@@ -199,6 +199,57 @@ def test_device_skinning_equals_host_skinning(pkg, make_hip, make_oracle, orc):
     assert launches == 10 and ms > 0.0  # per pose: skin vertices, skin shading records, triangles, BVH2 boxes, Node4s
 
 
+def test_stream_ordered_present_and_deinterleave(pkg, make_hip):
+    """bench.py's N > 1 step without host synchronisation: two ranks' contexts on one device, each frame presented on a
+    torch side stream (rfwhip_read_local_framebuffer_stream), "gathered" by a stream-ordered copy, de-interleaved on
+    that stream while the next frame is already enqueued — the images of every step equal the synchronous path's."""
+    import torch
+    w, h, world, steps = 480, 270, 2, 4
+    scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+    ctxs = []
+    for r in range(world):
+        c = pkg.RenderContext(device=0, rank=r, world=world)
+        c.init(w, h)
+        scene.upload(c)
+        c.set_setting("integrator", "pt")
+        c.set_setting("spp", 4)
+        ctxs.append(c)
+    rows = ctxs[0].local_rows()
+    dev = torch.device("cuda", 0)
+
+    def run(pipelined):
+        side = torch.cuda.Stream(device=dev)
+        local = [torch.zeros((rows, w, 4), dtype=torch.float32, device=dev) for _ in range(world)]
+        flat = torch.zeros((world, rows, w, 4), dtype=torch.float32, device=dev)
+        fulls = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(steps)]
+        with torch.cuda.stream(side):
+            for k in range(steps):
+                for r, c in enumerate(ctxs):
+                    c.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+                    if pipelined:
+                        c.read_local_framebuffer_stream(local[r].data_ptr(), side.cuda_stream)
+                    else:
+                        c.wait()
+                        c.read_local_framebuffer_device(local[r].data_ptr())
+                    flat[r].copy_(local[r], non_blocking=True)  # stands in for the gather's landing copy
+                if pipelined:
+                    ctxs[0].deinterleave_stream(flat.data_ptr(), fulls[k].data_ptr(), side.cuda_stream)
+                else:
+                    torch.cuda.synchronize()
+                    ctxs[0].deinterleave_device(flat.data_ptr(), fulls[k].data_ptr())
+        for c in ctxs:
+            c.wait()
+        torch.cuda.synchronize()
+        return [f.cpu().numpy() for f in fulls]
+
+    a, b = run(False), run(True)
+    for k in range(steps):
+        assert np.array_equal(a[k], b[k]), k
+    assert a[steps - 1][..., :3].mean() > 0.01
+    for c in ctxs:
+        c.destroy()
+
+
 def test_blue_noise_primary_sampler(pkg, make_hip, make_oracle):
     """The blue-noise primary sampler on the GPU (synthetic table of the reference's layout) against the oracle."""
     table = pkg.scenes.synthetic_blue_noise()
