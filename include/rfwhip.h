@@ -130,6 +130,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   spp          = samples per pixel enqueued by one rfwhip_render call (default 1)
  *   max_depth    = MAX_PATH_LENGTH of the pt integrator (settings.h:5, default 2)
  *   jitter       = "xor128" (EmbreeRT: rfw::utils::xor128 stream) | "center" (r0=r1=0.5) — parity integrator only
+ *   builder      = "host" (parallel binned SAH on the CPU, the default) | "device" (Morton order + Karras hierarchy on the
+ *                  GPU, lbvh.hip; applies to the next rfwhip_set_mesh that (re)builds)
  *   sampler      = "hash" (WangHash + xorshift32, tools.h:218-235; default) | "bluenoise" (needs rfwhip_set_blue_noise)
  *                  — pt integrator, primary rays
  *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)

@@ -854,7 +854,7 @@ int rfwo_set_setting(rfwo_context *c, const char *key, const char *val)
 		c->use_bvh = atoi(val) != 0;
 	else if (!strcmp(key, "threads"))
 		c->threads = atoi(val);
-	else if (!strcmp(key, "stage_timing") || !strcmp(key, "count_traversal") || !strcmp(key, "lds_nodes") || !strcmp(key, "refill") || !strcmp(key, "streams"))
+	else if (!strcmp(key, "stage_timing") || !strcmp(key, "count_traversal") || !strcmp(key, "lds_nodes") || !strcmp(key, "refill") || !strcmp(key, "streams") || !strcmp(key, "builder"))
 		return 0;
 	else
 		return fail("unknown setting");

@@ -1,6 +1,7 @@
 // kernels.h — host-callable launchers of the wavefront stages (implemented in kernels.hip).
 #pragma once
 #include "rt_types.h"
+#include <stddef.h>
 
 namespace rtk
 {
@@ -60,6 +61,12 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 
 // after a refit of the BVH2 boxes: copy them into the 4-wide traversal nodes of the same BLAS (Node4::src)
 void launch_refresh4(rt::Node4 *nodes4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
+// BVH construction on the device (lbvh.hip): BVH2 in device form over chunks of four Morton-consecutive triangles, boxes
+// fitted, leaf-ordered vertices written; mesh-local arrays (node_base = tri_base = 0).  nodes: 2 * ceil(n / 4) entries,
+// parents / flags the same, tri_verts 3 n.  Returns 0, or 1 when the mesh is a single leaf (build it on the host).
+size_t lbvh_scratch_bytes(uint32_t tri_count);
+int launch_lbvh_build(const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, void *scratch, size_t scratch_bytes,
+					  rt::Node *nodes, int *parents, rt::f4 *tri_verts, uint32_t *flags, float bounds_out_device[6], stream_t s);
 // linear-blend skinning on the device (geometry/gltf/mesh.cpp:31-45): verts/vnormals <- base * sum(w_k * M[j_k]);
 // mats: joint_count column-major 4x4
 void launch_skin_vertices(rt::f4 *verts, rt::f4 *vnormals, const rt::f4 *base_verts, const rt::f4 *base_normals,

@@ -326,6 +326,8 @@ struct rfwhip_context
 	int jitter = 0; // 0 xor128, 1 center
 	int stage_timing = 0;
 	int count_traversal = 0;
+	int builder = 0;	// 0 host (binned SAH), 1 device (Morton / Karras, lbvh.hip)
+	DevBuf d_lbvh_scratch, d_lbvh_nodes, d_lbvh_tri_verts;
 	int sampler = 0;	// 0 hash RNG, 1 blue noise
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
@@ -795,25 +797,94 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	}
 	// (re)build
 	const size_t n = mesh->triangleCount;
-	std::vector<float> bmin(3 * n), bmax(3 * n);
-	for (size_t i = 0; i < n; i++)
+	bool device_built = false;
+	if (c->builder == 1 && n > 4)
 	{
-		uint32_t ia, ib, ic;
-		tri_indices(mesh, i, ia, ib, ic);
-		const f4 &p0 = V[ia], &p1 = V[ib], &p2 = V[ic];
-		// per-triangle box grown by 1e-5 (bvh_tree.cpp:407-412)
-		bmin[3 * i + 0] = std::min(p0.x, std::min(p1.x, p2.x)) - 1e-5f, bmax[3 * i + 0] = std::max(p0.x, std::max(p1.x, p2.x)) + 1e-5f;
-		bmin[3 * i + 1] = std::min(p0.y, std::min(p1.y, p2.y)) - 1e-5f, bmax[3 * i + 1] = std::max(p0.y, std::max(p1.y, p2.y)) + 1e-5f;
-		bmin[3 * i + 2] = std::min(p0.z, std::min(p1.z, p2.z)) - 1e-5f, bmax[3 * i + 2] = std::max(p0.z, std::max(p1.z, p2.z)) + 1e-5f;
+		// construction on the device (lbvh.hip) in mesh-local arrays; topology, boxes and leaf-ordered vertices come back
+		// and take the same road as a host-built tree (4-wide collapse, placement in update())
+		const uint32_t m2 = 2u * (uint32_t)((n + 3) / 4);
+		RF_TRY(c->d_lbvh_scratch.ensure(rtk::lbvh_scratch_bytes((uint32_t)n)));
+		RF_TRY(c->d_lbvh_nodes.ensure((size_t)m2 * sizeof(rt::Node)));
+		RF_TRY(c->d_lbvh_tri_verts.ensure(3 * n * sizeof(f4)));
+		RF_TRY(m.d_parents.ensure((size_t)m2 * sizeof(int)));
+		RF_TRY(m.d_flags.ensure((size_t)m2 * sizeof(uint32_t)));
+		dm::event_t ea, eb;
+		const bool timed = c->stage_timing != 0;
+		if (timed)
+		{
+			dm::event_create(&ea), dm::event_create(&eb);
+			dm::event_record(ea, c->stream);
+		}
+		const int rc = rtk::launch_lbvh_build(m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)n,
+											  c->d_lbvh_scratch.p, c->d_lbvh_scratch.cap, c->d_lbvh_nodes.as<rt::Node>(),
+											  m.d_parents.as<int>(), c->d_lbvh_tri_verts.as<f4>(), m.d_flags.as<uint32_t>(),
+											  nullptr, c->stream);
+		if (rc != 0)
+			return set_error(RFWHIP_ERR_HIP, "rfwhip_set_mesh: device BVH build failed (%d)", rc);
+		RF_TRY(dm::last_launch_error());
+		if (timed)
+			dm::event_record(eb, c->stream);
+		m.bvh.nodes.resize(m2), m.bvh.parents.resize(m2), m.bvh.order.resize(n), m.leaf_verts.resize(3 * n);
+		RF_TRY(dm::d2h(m.bvh.nodes.data(), c->d_lbvh_nodes.p, (size_t)m2 * sizeof(rt::Node), c->stream));
+		RF_TRY(dm::d2h(m.bvh.parents.data(), m.d_parents.p, (size_t)m2 * sizeof(int), c->stream));
+		RF_TRY(dm::d2h(m.leaf_verts.data(), c->d_lbvh_tri_verts.p, 3 * n * sizeof(f4), c->stream));
+		RF_TRY(dm::sync(c->stream));
+		if (timed)
+		{
+			c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
+			c->kernel_launches[KF_REFIT] += 8;
+			dm::event_destroy(ea), dm::event_destroy(eb);
+		}
+		// device form -> the reference's host form (left_first = first primitive / left child, bvh_node.h:23-28)
+		for (uint32_t k = 0; k < m2; k++)
+		{
+			rt::Node &nd = m.bvh.nodes[k];
+			if (nd.count > 0)
+				nd.left_first = (int)((uint32_t)nd.left_first & rt::ENTRY_FIRST_MASK);
+			else if (nd.count < 0)
+				nd.left_first = (int)((uint32_t)nd.left_first & rt::ENTRY_INDEX_MASK);
+		}
+		for (size_t s = 0; s < n; s++)
+			memcpy(&m.bvh.order[s], &m.leaf_verts[3 * s].w, 4);
+		// depth of the Morton tree (iterative walk): the traversal stacks are sized for BLAS_DEPTH_LIMIT
+		{
+			std::vector<std::pair<int, int>> st;
+			st.push_back({0, 1});
+			int deepest = 0;
+			while (!st.empty())
+			{
+				const auto [node, depth] = st.back();
+				st.pop_back();
+				deepest = std::max(deepest, depth);
+				if (m.bvh.nodes[node].count < 0)
+					st.push_back({m.bvh.nodes[node].left_first, depth + 1}), st.push_back({m.bvh.nodes[node].left_first + 1, depth + 1});
+			}
+			m.bvh.max_depth = deepest;
+		}
+		device_built = m.bvh.max_depth <= BLAS_DEPTH_LIMIT; // a degenerate Morton tree falls back to the host builder
 	}
-	bvh::build(bmin.data(), bmax.data(), n, 4, BLAS_DEPTH_LIMIT, m.bvh);
+	if (!device_built)
+	{
+		std::vector<float> bmin(3 * n), bmax(3 * n);
+		for (size_t i = 0; i < n; i++)
+		{
+			uint32_t ia, ib, ic;
+			tri_indices(mesh, i, ia, ib, ic);
+			const f4 &p0 = V[ia], &p1 = V[ib], &p2 = V[ic];
+			// per-triangle box grown by 1e-5 (bvh_tree.cpp:407-412)
+			bmin[3 * i + 0] = std::min(p0.x, std::min(p1.x, p2.x)) - 1e-5f, bmax[3 * i + 0] = std::max(p0.x, std::max(p1.x, p2.x)) + 1e-5f;
+			bmin[3 * i + 1] = std::min(p0.y, std::min(p1.y, p2.y)) - 1e-5f, bmax[3 * i + 1] = std::max(p0.y, std::max(p1.y, p2.y)) + 1e-5f;
+			bmin[3 * i + 2] = std::min(p0.z, std::min(p1.z, p2.z)) - 1e-5f, bmax[3 * i + 2] = std::max(p0.z, std::max(p1.z, p2.z)) + 1e-5f;
+		}
+		bvh::build(bmin.data(), bmax.data(), n, 4, BLAS_DEPTH_LIMIT, m.bvh);
+	}
 	if (m.bvh.max_depth > BLAS_DEPTH_LIMIT)
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: BVH depth %d exceeds the traversal stack", m.bvh.max_depth);
 	for (int a = 0; a < 3; a++)
 		m.bounds_min[a] = m.bvh.nodes[0].bmin[a], m.bounds_max[a] = m.bvh.nodes[0].bmax[a];
 	bvh::collapse4(m.bvh, false, m.n4);
 	m.leaf_verts.resize(3 * n);
-	for (size_t s = 0; s < n; s++)
+	for (size_t s = 0; s < n && !device_built; s++)
 	{
 		const uint32_t prim = m.bvh.order[s];
 		uint32_t ia, ib, ic;
@@ -1666,7 +1737,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -1705,6 +1776,15 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 			c->jitter = 1;
 		else
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "jitter must be \"xor128\" or \"center\"");
+	}
+	else if (k == "builder")
+	{
+		if (!strcmp(value, "host"))
+			c->builder = 0;
+		else if (!strcmp(value, "device"))
+			c->builder = 1;
+		else
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "builder must be \"host\" or \"device\"");
 	}
 	else if (k == "sampler")
 	{
@@ -1749,6 +1829,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->max_depth);
 	else if (k == "jitter")
 		snprintf(value, cap, "%s", c->jitter ? "center" : "xor128");
+	else if (k == "builder")
+		snprintf(value, cap, "%s", c->builder ? "device" : "host");
 	else if (k == "sampler")
 		snprintf(value, cap, "%s", c->sampler ? "bluenoise" : "hash");
 	else if (k == "stage_timing")

@@ -1,6 +1,6 @@
 """Host-emulation build of the rendercore sources — TEST INFRASTRUCTURE ONLY.
 
-Compiles rendering-fw_amd/csrc/{rfwhip_api.cpp,bvh_build.cpp,kernels.hip} with g++ and -DRFWHIP_HOST_EMULATION into
+Compiles rendering-fw_amd/csrc/{rfwhip_api.cpp,bvh_build.cpp,kernels.hip,lbvh.hip} with g++ and -DRFWHIP_HOST_EMULATION into
 tests/_emu/librfwhip_emu.so: device memory becomes heap memory and every kernel launch becomes a plain loop over the
 same per-ray / per-path functions (rt_core.h, the *_item functions of kernels.hip).  This lets the CPU test tier
 (-m "not gpu") check the host logic (BVH build, TLAS, packing, strip interleave, xor128 jump-ahead, counters) and
@@ -17,7 +17,7 @@ OUT = os.path.join(OUT_DIR, "librfwhip_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):

@@ -106,3 +106,66 @@ def test_refit_equals_rebuild(pkg, make_emu, make_oracle):
         for p in prims[n["left_first"]:n["left_first"] + n["count"]]:
             tri = v[m["indices"][p]]
             assert np.all(tri.min(0) >= n["bmin"] - 1e-6) and np.all(tri.max(0) <= n["bmax"] + 1e-6)
+
+
+def _device_vs_host(pkg, make_ctx, make_oracle, scene, w, h, check_tree=True):
+    """builder=device (lbvh.hip: Morton order, Karras hierarchy, device fit) must give a valid tree in the reference's
+    node layout and the same closest hits / image as the host-built SAH tree and the oracle."""
+    dev, host, ref = make_ctx(), make_ctx(), make_oracle()
+    dev.set_setting("builder", "device")
+    out = []
+    for c in (dev, host, ref):
+        c.init(w, h)
+        scene.upload(c)
+        c.set_setting("jitter", "center")
+        c.render_frame(scene.camera, pkg.RESET)
+        out.append((c.primary_hits(), c.framebuffer()))
+    if check_tree:
+        for mi, m in enumerate(scene.meshes):
+            ntri = len(m["triangles"])
+            nodes, prims = dev.get_bvh(mi)
+            if ntri > 4:
+                assert len(nodes) == 2 * ((ntri + 3) // 4)       # the device layout: one node pair per chunk
+            _check_tree(nodes, prims, ntri)
+    (a, ia), (b, ib), (r, ir) = out
+    for other in (b, r):
+        assert (a["prim"] != other["prim"]).mean() <= 2e-3
+        same = (a["prim"] == other["prim"]) & (a["prim"] >= 0)
+        assert (np.abs(a["t"][same] - other["t"][same]) <= 1e-4 + 2e-5 * np.abs(other["t"][same])).all()
+    assert image_stats(ia, ib, 1e-3)[0] <= 5e-3
+    assert image_stats(ia, ir, 1e-3)[0] <= 5e-3
+    return dev
+
+
+def test_device_builder_terrain_and_instances(pkg, make_emu, make_oracle):
+    scene = pkg.scenes.terrain(n=40, width=96, height_px=64, lights=False)
+    # lights handed over through set_lights only: shadow rays that END on emitter geometry are a coin toss in fp32
+    scene.add_area_light_quad((0.0, -1.0, 0.0), (0.0, 30.0, 0.0), 6.0, 6.0, (400.0, 380.0, 350.0))
+    scene.add_point_light((10.0, 20.0, -10.0), (900.0, 900.0, 800.0))
+    _device_vs_host(pkg, make_emu, make_oracle, scene, 96, 64)
+    # instanced boxes + room: several small meshes (some with <= 4 triangles take the host path inside)
+    _device_vs_host(pkg, make_emu, make_oracle, pkg.scenes.cornell(96, 64), 96, 64)
+
+
+def test_device_builder_then_refit(pkg, make_emu, make_oracle):
+    """A device-built mesh refits like a host-built one (same parent links / flags machinery)."""
+    w, h = 64, 48
+    base = pkg.scenes.skinned_tube(0.0, rings=20, seg=12, width=w, height=h)
+    live = make_emu()
+    live.set_setting("builder", "device")
+    live.init(w, h)
+    base.upload(live)
+    live.set_setting("jitter", "center")
+    pose = pkg.scenes.skinned_tube(3.0, rings=20, seg=12, width=w, height=h)
+    m = pose.meshes[0]
+    live.set_mesh(0, m["vertices"], m["triangles"], m["indices"])
+    live.update()
+    live.render_frame(pose.camera, pkg.RESET)
+    ref = make_oracle()
+    ref.init(w, h)
+    pose.upload(ref)
+    ref.set_setting("jitter", "center")
+    ref.render_frame(pose.camera, pkg.RESET)
+    assert image_stats(live.framebuffer(), ref.framebuffer(), 1e-3)[0] <= 5e-3
+    nodes, prims = live.get_bvh(0)
+    _check_tree(nodes, prims, len(m["triangles"]))

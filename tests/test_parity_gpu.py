@@ -250,6 +250,37 @@ def test_stream_ordered_present_and_deinterleave(pkg, make_hip):
         c.destroy()
 
 
+def test_device_bvh_builder(pkg, make_hip, make_oracle):
+    """SURVEY §8 f2 on the GPU: builder=device (Morton sort with rocPRIM, Karras hierarchy, device fit) gives a valid
+    tree and the same hits / image as the host SAH build and the oracle; a later same-count set_mesh refits it."""
+    from test_bvh import _device_vs_host, _check_tree
+    scene = pkg.scenes.terrain(n=96, width=480, height_px=270, lights=False)
+    scene.add_area_light_quad((0.0, -1.0, 0.0), (0.0, 30.0, 0.0), 6.0, 6.0, (400.0, 380.0, 350.0))
+    scene.add_point_light((10.0, 20.0, -10.0), (900.0, 900.0, 800.0))
+    _device_vs_host(pkg, make_hip, make_oracle, scene, 480, 270)
+    # build time and traversal cost at the bench size, for DESIGN.md
+    import time
+    big = pkg.scenes.terrain(n=708, width=960, height_px=540)
+    res = {}
+    for builder in ("host", "device"):
+        c = make_hip()
+        c.set_setting("builder", builder)
+        c.init(960, 540)
+        t0 = time.perf_counter()
+        big.upload(c)
+        res[builder + "_upload_s"] = round(time.perf_counter() - t0, 4)
+        c.set_setting("integrator", "pt")
+        c.set_setting("spp", 8)
+        c.render_frame(big.camera, pkg.RESET)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            c.render_frame(big.camera, pkg.CONVERGE)
+        res[builder + "_ms_per_frame"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        res[builder + "_mean"] = float(c.framebuffer()[..., :3].mean())
+    print("DEVICE_BUILDER", res)
+    assert abs(res["host_mean"] - res["device_mean"]) <= 2e-3 * res["host_mean"]
+
+
 def test_blue_noise_primary_sampler(pkg, make_hip, make_oracle):
     """The blue-noise primary sampler on the GPU (synthetic table of the reference's layout) against the oracle."""
     table = pkg.scenes.synthetic_blue_noise()
