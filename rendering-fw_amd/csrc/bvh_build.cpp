@@ -36,7 +36,10 @@ struct Box
 };
 
 constexpr int BINS = 16;
-constexpr float TRAVERSAL_COST = 1.0f; // relative to one triangle test
+#ifndef RT_SAH_TRAVERSAL_COST
+#define RT_SAH_TRAVERSAL_COST 1.0f
+#endif
+constexpr float TRAVERSAL_COST = RT_SAH_TRAVERSAL_COST; // relative to one triangle test
 constexpr size_t PARALLEL_MIN = 1u << 15;
 
 struct Builder

@@ -709,6 +709,10 @@ static inline void tri_indices(const rfwhip_mesh *mesh, size_t i, uint32_t &a, u
 		a = (uint32_t)(3 * i), b = a + 1, cidx = a + 2;
 }
 
+#ifndef RT_MAX_LEAF
+#define RT_MAX_LEAF 4
+#endif
+constexpr int BLAS_MAX_LEAF = RT_MAX_LEAF; // triangles per leaf (<= rt::MAX_LEAF_PRIMS = 8)
 constexpr int BLAS_DEPTH_LIMIT = 42;
 constexpr int TLAS_DEPTH_LIMIT = 20; // + 1 sentinel < LDS_STACK + SPILL_STACK = 64
 
@@ -876,7 +880,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 			bmin[3 * i + 1] = std::min(p0.y, std::min(p1.y, p2.y)) - 1e-5f, bmax[3 * i + 1] = std::max(p0.y, std::max(p1.y, p2.y)) + 1e-5f;
 			bmin[3 * i + 2] = std::min(p0.z, std::min(p1.z, p2.z)) - 1e-5f, bmax[3 * i + 2] = std::max(p0.z, std::max(p1.z, p2.z)) + 1e-5f;
 		}
-		bvh::build(bmin.data(), bmax.data(), n, 4, BLAS_DEPTH_LIMIT, m.bvh);
+		bvh::build(bmin.data(), bmax.data(), n, BLAS_MAX_LEAF, BLAS_DEPTH_LIMIT, m.bvh);
 	}
 	if (m.bvh.max_depth > BLAS_DEPTH_LIMIT)
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: BVH depth %d exceeds the traversal stack", m.bvh.max_depth);
