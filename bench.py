@@ -268,6 +268,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_times.items()},
             "last_frame_counts": {k: stats[k] for k in ("primaryCount", "secondaryCount", "deepCount", "shadowCount")},
+            # rays of one step (this rank's strips) over the step time: closest-hit (primary + extension) and any-hit
+            "grays_per_s": {"closest_hit": round((stats["primaryCount"] + stats["secondaryCount"] + stats["deepCount"])
+                                                 / (elapsed / args.steps) / 1e9, 3),
+                            "shadow": round(stats["shadowCount"] / (elapsed / args.steps) / 1e9, 3)},
             "gather_ms_per_step": (round(sum(gather_ms) / len(gather_ms), 4) if gather_ms else
                                    (None if (world > 1 and args.pipeline) else 0.0)),
             "setup_s": {"scene": round(t_scene, 2), "upload_and_bvh": round(t_upload, 2)},
