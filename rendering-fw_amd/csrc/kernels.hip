@@ -595,6 +595,9 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Para
 // stay busy although rays of one wave need very different numbers of steps (measured lane utilisation of the
 // one-ray-per-lane form on the bounce waves: 18-30 %).
 // ----------------------------------------------------------------------------------------------------------------
+#ifndef RT_SHADE_COMPACT
+#define RT_SHADE_COMPACT 1
+#endif
 #ifndef RT_REFILL_IDLE_EXT
 #define RT_REFILL_IDLE_EXT 40 // extension rays: refill once 40 of 64 lanes are idle (swept 1..56 on MI355X: eager
 							  // refills cost more than they save; 32..56 are equivalent, +6 % over no refill)
@@ -707,11 +710,60 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
+#if RT_SHADE_COMPACT
+	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by
+	// lane on the bounce waves (PMC: 34 of 64 lanes active per VALU instruction).  Per chunk of 256 paths: pass 0 shades
+	// the misses in place, pass 1 the hits through a workgroup-compacted index list — the first waves are full of hits,
+	// the rest of the workgroup skips the pass.  Which lane shades a path does not affect its result.
+	__shared__ uint32_t s_list[BLOCK];
+	__shared__ uint32_t s_wave_hits[BLOCK / 64];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+	{
+		const uint32_t i = c * BLOCK + threadIdx.x;
+		bool valid = i < count;
+		if (p.depth == 0 && valid)
+			valid = slot_to_pixel(p.fr, i).valid;
+		bool is_hit = false;
+		if (valid)
+			is_hit = (int)fbits((p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i].w) >= 0;
+		const unsigned long long m = __ballot(is_hit);
+		if (lane == 0)
+			s_wave_hits[wave] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t base = 0, nhits = 0;
+		for (uint32_t w = 0; w < BLOCK / 64; w++)
+		{
+			const uint32_t n = s_wave_hits[w];
+			base += w < wave ? n : 0u;
+			nhits += n;
+		}
+		if (is_hit)
+			s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
+		__syncthreads();
+#pragma nounroll
+		for (int pass = 0; pass < 2; pass++)
+		{
+			uint32_t idx = i;
+			bool act = valid && !is_hit;
+			if (pass == 1)
+			{
+				act = threadIdx.x < nhits;
+				idx = act ? s_list[threadIdx.x] : 0u;
+				if (wave * 64u >= nhits)
+					break; // wave-uniform: nothing left for this wave
+			}
+			shade_pt_item(p, idx, act, ctx);
+		}
+		__syncthreads(); // s_list / s_wave_hits are rewritten by the next chunk
+	}
+#else
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
 	{
 		const uint32_t i = c * BLOCK + threadIdx.x;
 		shade_pt_item(p, i, i < count, ctx);
 	}
+#endif
 }
 
 template <bool COUNT>
