@@ -79,7 +79,7 @@ struct Ctx
 struct Ctx
 {
 	TravStack stk;
-	uint32_t lds[LDS_STACK], spill[SPILL_STACK];
+	uint32_t lds[LDS_STACK_MAX], spill[SPILL_STACK];
 	float potbuf[POT_CACHE];
 	float *pot;
 	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0; }
@@ -550,8 +550,8 @@ struct ChunkQueue
 };
 
 static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of the workgroup]");
-#define RT_STACK_DECL                                                                       \
-	__shared__ uint32_t s_stack[LDS_STACK * BLOCK];                                         \
+#define RT_STACK_DECL_(DEPTH)                                                                \
+	__shared__ uint32_t s_stack[(DEPTH)*BLOCK];                                             \
 	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
 	uint32_t spill_[SPILL_STACK];                                                           \
 	Ctx ctx;                                                                                \
@@ -559,6 +559,8 @@ static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of
 	ctx.stk.spill = spill_;                                                                 \
 	stage_top(p, s_top);                                                                    \
 	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;
+#define RT_STACK_DECL_CLOSEST RT_STACK_DECL_(LDS_STACK)
+#define RT_STACK_DECL_ANY RT_STACK_DECL_(LDS_STACK_ANY)
 
 // every workgroup copies the top-of-tree rows into its LDS once (the grids are persistent)
 __device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
@@ -576,7 +578,7 @@ __device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
-	RT_STACK_DECL
+	RT_STACK_DECL_CLOSEST
 	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext[p.depth] : fixed_count;
 	ChunkQueue w(p, count);
 	uint32_t c;
@@ -614,7 +616,7 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
 {
-	RT_STACK_DECL
+	RT_STACK_DECL_(ANY ? LDS_STACK_ANY : LDS_STACK)
 	WaveCounters *const wc = p.wv.counters;
 	const uint32_t count = ANY ? wc->shadow[p.depth] : wc->ext[p.depth];
 	uint32_t *const head = &wc->work[p.queue][0];
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_trace_stream(cons
 template <bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(const Params p, const uint32_t count)
 {
-	RT_STACK_DECL
+	RT_STACK_DECL_ANY
 	ChunkQueue w(p, count);
 	uint32_t c;
 	while (w.next(c))
@@ -769,7 +771,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 template <bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_connect(const Params p)
 {
-	RT_STACK_DECL
+	RT_STACK_DECL_ANY
 	const uint32_t count = p.wv.counters->shadow[p.depth];
 	ChunkQueue w(p, count);
 	uint32_t c;

@@ -714,7 +714,7 @@ static inline void tri_indices(const rfwhip_mesh *mesh, size_t i, uint32_t &a, u
 #endif
 constexpr int BLAS_MAX_LEAF = RT_MAX_LEAF; // triangles per leaf (<= rt::MAX_LEAF_PRIMS = 8)
 constexpr int BLAS_DEPTH_LIMIT = 42;
-constexpr int TLAS_DEPTH_LIMIT = 20; // + 1 sentinel < LDS_STACK + SPILL_STACK = 64
+constexpr int TLAS_DEPTH_LIMIT = 20; // + 1 sentinel; the traversal stack holds LDS_STACK(_ANY) + SPILL_STACK >= 48 entries
 
 extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mesh *mesh)
 {
