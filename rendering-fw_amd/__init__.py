@@ -8,9 +8,10 @@ The directory name contains a hyphen (it is the reference repository's name + "_
 `__graft_entry__.load_package()` under the module name `rendering_fw_amd`.
 """
 from . import _binding, abi, scenes
+from . import gltf
 from .abi import CONVERGE, RESET
 from .camera import Camera
 from .context import LIB_PATH, RenderContext, load_library
 from .build import build as build_native
 
-__all__ = ["abi", "scenes", "Camera", "RenderContext", "load_library", "LIB_PATH", "build_native", "RESET", "CONVERGE"]
+__all__ = ["abi", "scenes", "gltf", "Camera", "RenderContext", "load_library", "LIB_PATH", "build_native", "RESET", "CONVERGE"]
