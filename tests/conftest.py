@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import torch  # noqa: F401  first, so that torch's bundled HIP runtime initialises before librfwhip.so pulls in /opt/rocm's
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

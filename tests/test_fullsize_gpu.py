@@ -1,0 +1,123 @@
+"""BASELINE config 3 at its full size on the GPU (1 002 536 triangles, 1920x1080, pt integrator depth 2), checked through
+properties that do not need a full-size oracle render:
+  * traversal: 300 000 random rays through the 1 M-triangle BVH against the oracle's own BVH (closest hit id, t, u, v);
+  * accumulation: two CONVERGE batches of 8 spp == one batch of 16 spp (the sample index keys the RNG, the resolve
+    sums a pixel's samples in a fixed order per batch) up to float summation order;
+  * strips: 8 ranks' local framebuffers, gathered and de-interleaved, == the single-rank image, bit for bit;
+  * sub-batch streams: the image does not depend on how a batch is cut into concurrent sub-batches;
+  * energy: with the lights off the image is linear in the sky radiance, the firefly clamp bounds every sample, a black
+    sky gives a black image.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def terrain(pkg):
+    return pkg.scenes.terrain(n=708, width=W, height_px=H)
+
+
+def _ctx(pkg, make_hip, scene, rank=0, world=1, **settings):
+    c = make_hip(rank, world)
+    c.init(W, H)
+    scene.upload(c)
+    c.set_setting("integrator", "pt")
+    for k, v in settings.items():
+        c.set_setting(k, v)
+    return c
+
+
+def test_traversal_1m_triangles(pkg, make_hip, make_oracle, terrain):
+    from test_trace_rays import _rays
+    core, ref = make_hip(), make_oracle()
+    for c in (core, ref):
+        c.init(64, 64)
+        terrain.upload(c)
+    rng = np.random.default_rng(5)
+    o, d = _rays(rng, 300000, 48.0)
+    a, b = core.trace_rays(o, d), ref.trace_rays(o, d)
+    assert (a["prim"] != b["prim"]).mean() <= 2e-3 and (a["inst"] != b["inst"]).mean() <= 2e-3
+    same = (a["prim"] == b["prim"]) & (a["prim"] >= 0)
+    assert same.sum() > 0.5 * len(same)
+    assert (np.abs(a["t"][same] - b["t"][same]) <= 1e-4 + 2e-5 * np.abs(b["t"][same])).all()
+    # barycentrics of 0.14-unit triangles seen from ~100 units: the cross products cancel to ~1e-3 in fp32
+    assert np.abs(a["u"][same] - b["u"][same]).max() <= 5e-3 and np.abs(a["v"][same] - b["v"][same]).max() <= 5e-3
+
+
+def test_accumulation_and_subbatch_independence(pkg, make_hip, terrain):
+    a = _ctx(pkg, make_hip, terrain, spp=16, streams=4)
+    a.render_frame(terrain.camera, pkg.RESET)
+    img16 = a.framebuffer()
+    b = _ctx(pkg, make_hip, terrain, spp=8, streams=1)
+    b.render_frame(terrain.camera, pkg.RESET)
+    b.render_frame(terrain.camera, pkg.CONVERGE)
+    img8x2 = b.framebuffer()
+    assert np.abs(img16 - img8x2).max() <= 1e-4 * max(1.0, float(img16.max()))
+    c = _ctx(pkg, make_hip, terrain, spp=16, streams=3)
+    c.render_frame(terrain.camera, pkg.RESET)
+    assert np.array_equal(c.framebuffer(), img16)           # 16 spp cut 4/4/4/4 or 5/5/6: same samples, same order
+    st = a.get_stats()
+    assert st.primaryCount == W * H * 16
+    assert st.secondaryCount > 0 and st.deepCount > 0 and st.shadowCount > 0
+
+
+def test_eight_strip_ranks_equal_single_rank(pkg, make_hip, terrain):
+    import torch
+    world = 8
+    single = _ctx(pkg, make_hip, terrain, spp=4)
+    single.render_frame(terrain.camera, pkg.RESET)
+    rows = None
+    gathered = None
+    root = None
+    for r in range(world):
+        c = _ctx(pkg, make_hip, terrain, rank=r, world=world, spp=4)
+        c.render_frame(terrain.camera, pkg.RESET)
+        if gathered is None:
+            rows = c.local_rows()
+            gathered = torch.empty((world, rows, W, 4), dtype=torch.float32, device="cuda:0")
+        c.read_local_framebuffer_device(gathered[r].data_ptr())
+        if r == 0:
+            root = c
+        else:
+            c.destroy()
+    full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    root.deinterleave_device(gathered.data_ptr(), full.data_ptr())
+    assert np.array_equal(full.cpu().numpy(), single.framebuffer())
+
+
+def test_sky_linearity_and_clamp(pkg, make_hip):
+    """With the lights off every path ends on the sky (or dies): the image is linear in the sky's radiance, because no
+    discrete decision of a path depends on it.  (It is NOT linear in the lights' radiance: lights.h makes the light
+    pdf 1 / energy, so a light's estimate grows with radiance x energy — restated as is.)  With the clamp on, every
+    contribution is bounded by clampIntensity (tools.h:184-192)."""
+    def scene(scale, clamp):
+        s = pkg.scenes.terrain(n=708, width=W, height_px=H, lights=False)
+        pix, w, h = s.sky
+        s.sky = (pix * np.float32(scale), w, h)
+        s.camera.clampValue = clamp
+        return s
+    imgs = []
+    for scale in (1.0, 2.0):
+        s = scene(scale, 1e30)
+        c = _ctx(pkg, make_hip, s, spp=4)
+        c.render_frame(s.camera, pkg.RESET)
+        imgs.append(c.framebuffer()[..., :3].astype(np.float64))
+        st = c.get_stats()
+        assert st.shadowCount == 0                                  # no lights, no connections
+        c.destroy()
+    lit = imgs[0] > 1e-3
+    assert lit.mean() > 0.3
+    assert np.abs(imgs[1][lit] / imgs[0][lit] - 2.0).max() <= 1e-4
+    s = scene(1.0, 0.25)
+    c = _ctx(pkg, make_hip, s, spp=2)
+    c.render_frame(s.camera, pkg.RESET)
+    assert c.framebuffer()[..., :3].max() <= 0.25 * 1.001           # one sky contribution per path, clamped
+    s = scene(0.0, 10.0)
+    c = _ctx(pkg, make_hip, s, spp=1)
+    c.render_frame(s.camera, pkg.RESET)
+    assert c.framebuffer()[..., :3].max() == 0.0
