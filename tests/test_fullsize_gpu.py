@@ -92,8 +92,8 @@ def test_eight_strip_ranks_equal_single_rank(pkg, make_hip, terrain):
 
 def test_sky_linearity_and_clamp(pkg, make_hip):
     """With the lights off every path ends on the sky (or dies): the image is linear in the sky's radiance, because no
-    discrete decision of a path depends on it.  (It is NOT linear in the lights' radiance: lights.h makes the light
-    pdf 1 / energy, so a light's estimate grows with radiance x energy — restated as is.)  With the clamp on, every
+    discrete decision of a path depends on it.  (It is NOT linear in the lights' radiance: every light pdf in
+    lights.h carries 1 / energy, so a light's estimate grows with radiance x energy — restated as is.)  With the clamp on, every
     contribution is bounded by clampIntensity (tools.h:184-192)."""
     def scene(scale, clamp):
         s = pkg.scenes.terrain(n=708, width=W, height_px=H, lights=False)
