@@ -341,93 +341,52 @@ RT_FN bool slab(const f4 &a, const f4 &b, f3 id, f3 oid, float t, float &tnear)
 	return tmax > tmin && tmin < t && tmax >= 0.0f;
 }
 
-// The seven 16-byte rows of a Node4 a ray needs (entries, and per axis the entry-plane row and the exit-plane row of
-// its four children), turned into plane distances p * id - oid.
-//  * device: the seven loads are pinned by one empty asm that names every row, so they are issued back to back (one
-//    round trip; none is sunk into the branch that uses it, none is waited for while others are still to be issued),
-//    and the 24 fmas are 12 v_pk_fma_f32 on the natural register pairs of the loaded rows.
-//  * emulation: the same fma arithmetic, scalar.
-#ifndef RT_NODE_VARIANT
-#define RT_NODE_VARIANT 4
-#endif
+// The seven 16-byte rows of a Node4 a ray needs: the entries and, per axis, the entry-plane row and the exit-plane row of
+// its four children (which of lo / hi that is depends on the sign of the direction: near_* are row offsets).
+//  * device, global table (PIN): the seven loads are pinned by one empty asm that names every row, so they are issued
+//    back to back (one round trip; none is sunk into the branch that uses it, none is waited for while others are still
+//    to be issued).  The LDS copy of the top of the tree needs no pin.
+//  * The plane distances p * id - oid (24 fma) are computed once, after whichever path loaded the rows: in a wave with
+//    lanes on both paths only the loads run twice.
+struct Node4Rows
+{
+	f4 en, nx, fx, ny, fy, nz, fz;
+};
 struct Node4Planes
 {
 	f4 ax, ay, az; // distances to the entry planes of children 0..3
 	f4 bx, by, bz; // distances to the exit planes
-	f4 en;		   // the four entries (bit patterns)
 };
 template <bool PIN>
-RT_FN Node4Planes load_node4(const char *base, uint32_t nb, uint32_t near_x, uint32_t near_y, uint32_t near_z, f3 id, f3 oid)
+RT_FN Node4Rows load_rows(const char *base, uint32_t nb, uint32_t near_x, uint32_t near_y, uint32_t near_z)
 {
-	Node4Planes r;
+	Node4Rows r;
 #if defined(__HIP_DEVICE_COMPILE__)
 	typedef float v4f __attribute__((ext_vector_type(4)));
-	typedef float v2f __attribute__((ext_vector_type(2)));
-	const v2f ix = {id.x, id.x}, iy = {id.y, id.y}, iz = {id.z, id.z};
-	const v2f ox = {-oid.x, -oid.x}, oy = {-oid.y, -oid.y}, oz = {-oid.z, -oid.z};
-#define RT_ROW(OUT, ROW, I, O)                                            \
-	{                                                                     \
-		const v2f lo_ = __builtin_elementwise_fma(ROW.xy, I, O);          \
-		const v2f hi_ = __builtin_elementwise_fma(ROW.zw, I, O);          \
-		OUT = mk4(lo_.x, lo_.y, hi_.x, hi_.y);                            \
-	}
-#if RT_NODE_VARIANT <= 1
-	const v4f *p = (const v4f *)(base + nb);
-	v4f nx = p[0], ny = p[1], nz = p[2], fx = p[3], fy = p[4], fz = p[5], en = p[6];
-	f4 x1, x2, y1, y2, z1, z2;
-#if RT_NODE_VARIANT == 1
-	RT_ROW(x1, nx, ix, ox)
-	RT_ROW(y1, ny, iy, oy)
-	RT_ROW(z1, nz, iz, oz)
-	RT_ROW(x2, fx, ix, ox)
-	RT_ROW(y2, fy, iy, oy)
-	RT_ROW(z2, fz, iz, oz)
-#else
-#define RT_ROWS(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
-	x1 = RT_ROWS(nx, id.x, oid.x), y1 = RT_ROWS(ny, id.y, oid.y), z1 = RT_ROWS(nz, id.z, oid.z);
-	x2 = RT_ROWS(fx, id.x, oid.x), y2 = RT_ROWS(fy, id.y, oid.y), z2 = RT_ROWS(fz, id.z, oid.z);
-#undef RT_ROWS
-#endif
-#define RT_MM(A, B, F) mk4(F(A.x, B.x), F(A.y, B.y), F(A.z, B.z), F(A.w, B.w))
-	r.ax = RT_MM(x1, x2, fminf), r.ay = RT_MM(y1, y2, fminf), r.az = RT_MM(z1, z2, fminf);
-	r.bx = RT_MM(x1, x2, fmaxf), r.by = RT_MM(y1, y2, fmaxf), r.bz = RT_MM(z1, z2, fmaxf);
-#undef RT_MM
-#else
 	v4f en = *(const v4f *)(base + (nb + 96u));
 	v4f nx = *(const v4f *)(base + (nb + near_x)), fx = *(const v4f *)(base + (nb + (near_x ^ 48u)));
 	v4f ny = *(const v4f *)(base + (nb + near_y)), fy = *(const v4f *)(base + (nb + (near_y ^ 80u)));
 	v4f nz = *(const v4f *)(base + (nb + near_z)), fz = *(const v4f *)(base + (nb + (near_z ^ 112u)));
-#if RT_NODE_VARIANT == 2 || RT_NODE_VARIANT == 4
 	if (PIN)
 		asm volatile("" : "+v"(en), "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz));
-#endif
-#if RT_NODE_VARIANT >= 4
-#define RT_ROWS(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
-	r.ax = RT_ROWS(nx, id.x, oid.x), r.ay = RT_ROWS(ny, id.y, oid.y), r.az = RT_ROWS(nz, id.z, oid.z);
-	r.bx = RT_ROWS(fx, id.x, oid.x), r.by = RT_ROWS(fy, id.y, oid.y), r.bz = RT_ROWS(fz, id.z, oid.z);
-#undef RT_ROWS
+#define RT_F4(V) mk4(V.x, V.y, V.z, V.w)
+	r.en = RT_F4(en), r.nx = RT_F4(nx), r.fx = RT_F4(fx), r.ny = RT_F4(ny), r.fy = RT_F4(fy), r.nz = RT_F4(nz), r.fz = RT_F4(fz);
+#undef RT_F4
 #else
-	RT_ROW(r.ax, nx, ix, ox)
-	RT_ROW(r.ay, ny, iy, oy)
-	RT_ROW(r.az, nz, iz, oz)
-	RT_ROW(r.bx, fx, ix, ox)
-	RT_ROW(r.by, fy, iy, oy)
-	RT_ROW(r.bz, fz, iz, oz)
+	r.en = *(const f4 *)(base + (nb + 96u));
+	r.nx = *(const f4 *)(base + (nb + near_x)), r.fx = *(const f4 *)(base + (nb + (near_x ^ 48u)));
+	r.ny = *(const f4 *)(base + (nb + near_y)), r.fy = *(const f4 *)(base + (nb + (near_y ^ 80u)));
+	r.nz = *(const f4 *)(base + (nb + near_z)), r.fz = *(const f4 *)(base + (nb + (near_z ^ 112u)));
 #endif
-#endif
-#undef RT_ROW
-	r.en = mk4(en.x, en.y, en.z, en.w);
-#else
-	const f4 en = *(const f4 *)(base + (nb + 96u));
-	const f4 nx = *(const f4 *)(base + (nb + near_x)), fx = *(const f4 *)(base + (nb + (near_x ^ 48u)));
-	const f4 ny = *(const f4 *)(base + (nb + near_y)), fy = *(const f4 *)(base + (nb + (near_y ^ 80u)));
-	const f4 nz = *(const f4 *)(base + (nb + near_z)), fz = *(const f4 *)(base + (nb + (near_z ^ 112u)));
+	return r;
+}
+RT_FN Node4Planes plane_distances(const Node4Rows &q, f3 id, f3 oid)
+{
+	Node4Planes r;
 #define RT_ROW(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
-	r.ax = RT_ROW(nx, id.x, oid.x), r.ay = RT_ROW(ny, id.y, oid.y), r.az = RT_ROW(nz, id.z, oid.z);
-	r.bx = RT_ROW(fx, id.x, oid.x), r.by = RT_ROW(fy, id.y, oid.y), r.bz = RT_ROW(fz, id.z, oid.z);
+	r.ax = RT_ROW(q.nx, id.x, oid.x), r.ay = RT_ROW(q.ny, id.y, oid.y), r.az = RT_ROW(q.nz, id.z, oid.z);
+	r.bx = RT_ROW(q.fx, id.x, oid.x), r.by = RT_ROW(q.fy, id.y, oid.y), r.bz = RT_ROW(q.fz, id.z, oid.z);
 #undef RT_ROW
-	r.en = en;
-#endif
 	return r;
 }
 
@@ -532,11 +491,12 @@ struct Traverser
 		{
 			const uint32_t idx = cur & ENTRY_INDEX_MASK;
 			const uint32_t rel = idx - stk.top_first;
-			Node4Planes n;
+			Node4Rows rows;
 			if (rel < stk.top_count)
-				n = load_node4<false>((const char *)stk.top, rel * (TOP_ROWS * 16u), near_x, near_y, near_z, id, oid);
+				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u), near_x, near_y, near_z);
 			else // byte offset of the Node4 in the table (tables stay below 4 GiB)
-				n = load_node4<true>((const char *)sc.nodes4, idx << 7, near_x, near_y, near_z, id, oid);
+				rows = load_rows<true>((const char *)sc.nodes4, idx << 7, near_x, near_y, near_z);
+			const Node4Planes n = plane_distances(rows, id, oid);
 			if (COUNT)
 				st.inner++;
 			// slab test of the four children (aabb.cpp:39-77 in fma form, entry/exit planes picked by the direction
@@ -554,7 +514,7 @@ struct Traverser
 			RT_SLAB4(z, t2)
 			RT_SLAB4(w, t3)
 #undef RT_SLAB4
-			uint32_t e0 = fbits(n.en.x), e1 = fbits(n.en.y), e2 = fbits(n.en.z), e3 = fbits(n.en.w);
+			uint32_t e0 = fbits(rows.en.x), e1 = fbits(rows.en.y), e2 = fbits(rows.en.z), e3 = fbits(rows.en.w);
 			if (!ANY)
 			{
 				// order the four children by entry distance (5-comparator network), nearest first
