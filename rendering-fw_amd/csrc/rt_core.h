@@ -471,17 +471,43 @@ struct Traverser
 			stk.spill[sp - LDS_DEPTH] = e;
 		sp++;
 	}
-	// next entry from the stack; ENTRY_SENTINEL comes back like a leaf and is resolved in visit()
+	// next entry from the stack; ENTRY_SENTINEL comes back like a leaf and is resolved in visit().  The common case
+	// (stack within its LDS part) is branch-free: an unconditional read of the clamped slot and two selects.
 	RT_FN uint32_t pop(const TravStack stk)
 	{
-		if (sp == 0)
-			return ENTRY_DONE;
-		sp--;
-		if (sp < LDS_DEPTH)
-			return stk.lds[sp * STACK_STRIDE];
-		if (sp < LDS_DEPTH + SPILL_STACK)
-			return stk.spill[sp - LDS_DEPTH];
-		return ENTRY_DONE; // unreachable: the builders bound the depth (bvh_build.cpp)
+		if (sp > LDS_DEPTH)
+		{
+			sp--;
+			return sp < LDS_DEPTH + SPILL_STACK ? stk.spill[sp - LDS_DEPTH] : ENTRY_DONE; // builders bound the depth
+		}
+		const int s = sp > 0 ? sp - 1 : 0;
+		const uint32_t e = stk.lds[s * STACK_STRIDE];
+		const uint32_t r = sp > 0 ? e : ENTRY_DONE;
+		sp = s;
+		return r;
+	}
+	// Up to three entries at once, in this order, each only if its flag is set.  While the stack stays within its LDS
+	// part the three stores are unconditional — an unwanted entry lands on the slot the next wanted one overwrites, or
+	// just above the new top — so the usual case costs one branch instead of nine.
+	RT_FN void push3(const TravStack stk, uint32_t ea, bool fa, uint32_t eb, bool fb, uint32_t ec, bool fc)
+	{
+		if (sp + 3 <= LDS_DEPTH)
+		{
+			const int na = fa ? 1 : 0, nb = fb ? 1 : 0, nc = fc ? 1 : 0;
+			stk.lds[sp * STACK_STRIDE] = ea;
+			stk.lds[(sp + na) * STACK_STRIDE] = eb;
+			stk.lds[(sp + na + nb) * STACK_STRIDE] = ec;
+			sp += na + nb + nc;
+		}
+		else
+		{
+			if (fa)
+				push(stk, ea);
+			if (fb)
+				push(stk, eb);
+			if (fc)
+				push(stk, ec);
+		}
 	}
 
 	// phase 1: walk 4-wide inner nodes until this lane holds a leaf entry (or ENTRY_DONE / ENTRY_SENTINEL)
@@ -535,12 +561,7 @@ struct Traverser
 				if (t0 < INF)
 				{
 					// far children first, so the nearest of them is popped first
-					if (t3 < INF)
-						push(stk, e3);
-					if (t2 < INF)
-						push(stk, e2);
-					if (t1 < INF)
-						push(stk, e1);
+					push3(stk, e3, t3 < INF, e2, t2 < INF, e1, t1 < INF);
 					cur = e0;
 				}
 				else
@@ -548,32 +569,12 @@ struct Traverser
 			}
 			else
 			{
-				// occlusion query: any order will do
-				uint32_t next = ENTRY_DONE;
-				bool have = false;
-				if (t0 < INF)
-					next = e0, have = true;
-				if (t1 < INF)
-				{
-					if (have)
-						push(stk, e1);
-					else
-						next = e1, have = true;
-				}
-				if (t2 < INF)
-				{
-					if (have)
-						push(stk, e2);
-					else
-						next = e2, have = true;
-				}
-				if (t3 < INF)
-				{
-					if (have)
-						push(stk, e3);
-					else
-						next = e3, have = true;
-				}
+				// occlusion query: any order will do — the first child hit is next, later hits are stacked
+				const bool h0 = t0 < INF, h1 = t1 < INF, h2 = t2 < INF, h3 = t3 < INF;
+				const bool have = h0 || h1 || h2 || h3;
+				const uint32_t next = h0 ? e0 : (h1 ? e1 : (h2 ? e2 : e3));
+				if (have)
+					push3(stk, e1, h1 && h0, e2, h2 && (h0 || h1), e3, h3 && (h0 || h1 || h2));
 				cur = have ? next : pop(stk);
 			}
 		}
