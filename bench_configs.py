@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Side measurements of BASELINE.json configs 4 and 5 at their full sizes on ONE MI355X (the driver's contract bench is
-bench.py = config 3).  Prints one JSON line per config.
+"""Side measurements of the BASELINE.json configs bench.py does not time, at their full sizes on ONE MI355X (the driver's
+contract bench is bench.py = config 3 with the pt integrator).  Prints one JSON line per config.
+
+  config 2  Cornell scene, 1920x1080, 64 spp, parity integrator (the L2-checked algorithm): Msamples/s
+  config 3  the 1 M-triangle terrain with the parity integrator (SURVEY §8d asks for both integrators)
 
   config 4  atrium (263 288 instanced triangles, 46 instances, 25 materials, 12 textures with mips), 1920x1080,
             pt integrator depth 2: Msamples/s
@@ -26,6 +29,30 @@ def main():
         raise SystemExit("needs an MI355X")
     pkg = load_package()
     W, H = 1920, 1080
+
+    # ---- configs 2 and 3 with the parity integrator (the algorithm that is L2-checked against the oracle) -------------
+    for cfg, scene in ((2, pkg.scenes.cornell(W, H)), ("3 (parity integrator)", pkg.scenes.terrain(n=708, width=W, height_px=H))):
+        ctx = pkg.RenderContext(device=0)
+        ctx.init(W, H)
+        scene.upload(ctx)
+        for k, v in {"integrator": "parity", "jitter": "xor128", "spp": 64}.items():
+            ctx.set_setting(k, v)
+        for k in range(5):
+            ctx.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+        ctx.wait()
+        steps = 6
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ctx.render_async(scene.camera, pkg.CONVERGE)
+        ctx.wait()
+        el = time.perf_counter() - t0
+        st = ctx.get_stats().as_dict()
+        print(json.dumps({"config": cfg, "workload": "%s: %d triangles, 1920x1080, parity integrator (1 primary ray + one "
+                          "shadow ray per light), 64 spp per step, xor128 jitter" % (scene.name, scene.triangle_count()),
+                          "metric": "Msamples/s", "value": round(W * H * 64 * steps / el / 1e6, 1),
+                          "ms_per_step": round(el / steps * 1e3, 3),
+                          "rays_last_frame": {k: st[k] for k in ("primaryCount", "shadowCount")}}))
+        del ctx
 
     # ---- config 4 -------------------------------------------------------------------------------------------------
     scene = pkg.scenes.atrium(W, H)
