@@ -35,7 +35,10 @@ struct Box
 	}
 };
 
-constexpr int BINS = 16;
+#ifndef RT_SAH_BINS
+#define RT_SAH_BINS 16
+#endif
+constexpr int BINS = RT_SAH_BINS;
 #ifndef RT_SAH_TRAVERSAL_COST
 #define RT_SAH_TRAVERSAL_COST 1.0f
 #endif
