@@ -78,6 +78,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = os.environ.get("RFWHIP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        # development aid for a 1-GPU box: all ranks on GPU 0 and — RCCL refuses two ranks on one device — gloo with host
+        # staging for the gather.  Walks through the N > 1 control flow only; its numbers mean nothing.
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
@@ -90,7 +95,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -124,7 +132,17 @@ def main():
     def step(k, first):
         # render_frame(camera, status): RESET on the first step of a series, CONVERGE afterwards (context.h:19-23)
         ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
-        if world > 1 and args.pipeline:
+        if world > 1 and one_device:
+            ctx.wait()
+            ctx.read_local_framebuffer_device(local_fb.data_ptr())
+            host = local_fb.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                gathered_flat.copy_(torch.stack(parts))
+                torch.cuda.synchronize()
+                ctx.deinterleave_device(gathered_flat.data_ptr(), full_fb.data_ptr())
+        elif world > 1 and args.pipeline:
             # everything stream-ordered, nothing blocks the host: present on torch's current stream (ordered behind the
             # frame's kernels by an event), RCCL gather behind it, de-interleave on the root behind the gather; the
             # next step's kernels run on the core's own streams meanwhile (its accumulate waits for this present).
@@ -162,7 +180,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if world == 1:
