@@ -1,5 +1,6 @@
 """BVH construction and refit of the product (through the host-emulation build)."""
 import numpy as np
+import pytest
 
 from conftest import image_stats
 
@@ -169,3 +170,73 @@ def test_device_builder_then_refit(pkg, make_emu, make_oracle):
     assert image_stats(live.framebuffer(), ref.framebuffer(), 1e-3)[0] <= 5e-3
     nodes, prims = live.get_bvh(0)
     _check_tree(nodes, prims, len(m["triangles"]))
+
+
+def _soup(kind, rng, n):
+    if kind == "uniform":
+        c = rng.uniform(-10, 10, (n, 1, 3)); e = rng.normal(0, 0.4, (n, 3, 3))
+    elif kind == "clustered":
+        centers = rng.uniform(-20, 20, (6, 3))
+        c = centers[rng.integers(0, 6, n)][:, None, :] + rng.normal(0, 0.3, (n, 1, 3)); e = rng.normal(0, 0.05, (n, 3, 3))
+    elif kind == "slivers":           # long thin triangles, all overlapping each other's boxes
+        c = rng.uniform(-2, 2, (n, 1, 3)); e = rng.normal(0, 1.0, (n, 3, 3)) * np.array([30.0, 0.02, 0.02])
+    elif kind == "far_from_origin":   # fp32 cancellation: coordinates ~1e4, sizes ~1
+        c = 1.0e4 + rng.uniform(-50, 50, (n, 1, 3)); e = rng.normal(0, 1.0, (n, 3, 3))
+    else:                             # "duplicates": every triangle four times + a few degenerate (zero-area) ones
+        base = rng.uniform(-5, 5, (n // 4, 1, 3)) + rng.normal(0, 0.5, (n // 4, 3, 3))
+        v = np.concatenate([base] * 4)
+        v[:3, 1] = v[:3, 0]
+        return v.reshape(-1, 3).astype(np.float32)
+    return (c + e).reshape(-1, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "slivers", "far_from_origin", "duplicates"])
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_random_soups_against_brute_force(pkg, make_emu, make_oracle, kind, builder):
+    _soup_case(pkg, make_emu, make_oracle, kind, builder)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "slivers", "far_from_origin", "duplicates"])
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_random_soups_against_brute_force_gpu(pkg, make_hip, make_oracle, kind, builder):
+    _soup_case(pkg, make_hip, make_oracle, kind, builder)
+
+
+def _soup_case(pkg, make_emu, make_oracle, kind, builder):
+    """Triangle soups the builders do not like, traced with rays aimed at the geometry: the product's BVH (either
+    builder, then the 4-wide collapse) must find what the oracle finds by testing EVERY triangle (bvh=0)."""
+    rng = np.random.default_rng(sum(map(ord, kind + builder)))
+    verts = _soup(kind, rng, 600)
+    s = pkg.scenes.Scene()
+    s.add_material(color=(0.8, 0.8, 0.8))
+    s.add_instance(s.add_mesh(verts, None))
+    s.set_test_sky(16, 8)
+    cam = pkg.Camera(aperture=0.0)
+    lo, hi = verts.min(0), verts.max(0)
+    cam.look_at(tuple(lo - (hi - lo)), tuple((lo + hi) / 2))
+    cam.resize(16, 16)
+    s.camera = cam
+    core, ref = make_emu(), make_oracle()
+    core.set_setting("builder", builder)
+    ref.set_setting("bvh", 0)
+    for c in (core, ref):
+        c.init(16, 16)
+        s.upload(c)
+    nodes, prims = core.get_bvh(0)
+    _check_tree(nodes, prims, len(verts) // 3)
+    n = 4000
+    tri_c = verts.reshape(-1, 3, 3).mean(1)
+    org = (tri_c[rng.integers(0, len(tri_c), n)] + rng.normal(0, 1.0, (n, 3)) * (hi - lo) * 0.7).astype(np.float32)
+    tgt = tri_c[rng.integers(0, len(tri_c), n)] + rng.normal(0, 0.05, (n, 3))
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a, b = core.trace_rays(org, d), ref.trace_rays(org, d)
+    assert np.array_equal(a["prim"] >= 0, b["prim"] >= 0)
+    hit = a["prim"] >= 0
+    assert hit.mean() > 0.1
+    scale = float(np.abs(verts).max())
+    assert (np.abs(a["t"][hit] - b["t"][hit]) <= 1e-6 * scale + 2e-5 * np.abs(b["t"][hit])).all()
+    # the same primitive unless two triangles tie at the hit distance (the duplicates soup is all ties)
+    if kind != "duplicates":
+        assert (a["prim"][hit] != b["prim"][hit]).mean() <= 5e-3
