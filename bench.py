@@ -252,6 +252,25 @@ def main():
             "hbm_traffic_gbs": round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if (traffic and ms_per_launch > 0) else None,
         }
 
+    # ---- rays per second per stage, the way the reference's stats window shows them (imgui_app/main.cpp:279-286): one
+    # extra frame with the launches serialised (streams = 1), so every stage's time is its own -------------------------------
+    stage_rates = None
+    if not args.no_roofline and rank == 0 and world == 1:
+        ctx.set_setting("streams", 1)
+        ctx.set_setting("stage_timing", 1)
+        ctx.set_setting("spp", max(1, args.spp // 4))
+        ctx.render_frame(scene.camera, pkg.RESET)
+        ctx.render_frame(scene.camera, pkg.RESET)
+        st1 = ctx.get_stats().as_dict()
+        def rate(count, ms):
+            return round(st1[count] / (st1[ms] * 1e-3) / 1e6, 1) if st1[ms] > 0 else None
+        stage_rates = {"spp": max(1, args.spp // 4), "streams": 1,
+                       "primary": rate("primaryCount", "primaryTime"), "secondary": rate("secondaryCount", "secondaryTime"),
+                       "deep": rate("deepCount", "deepTime"), "shadow": rate("shadowCount", "shadowTime"),
+                       "stage_ms": {k: round(st1[k], 3) for k in ("primaryTime", "secondaryTime", "deepTime", "shadowTime", "shadeTime")}}
+        ctx.set_setting("streams", args.streams)
+        ctx.set_setting("spp", args.spp)
+
     # ---- CPU baseline: the oracle (a port, not the reference build) on this box's host cores ----------------------------
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -301,6 +320,7 @@ def main():
             "grays_per_s": {"closest_hit": round((stats["primaryCount"] + stats["secondaryCount"] + stats["deepCount"])
                                                  / (elapsed / args.steps) / 1e9, 3),
                             "shadow": round(stats["shadowCount"] / (elapsed / args.steps) / 1e9, 3)},
+            "mrays_per_s_per_stage_serialised": stage_rates,
             "gather_ms_per_step": (round(sum(gather_ms) / len(gather_ms), 4) if gather_ms else
                                    (None if (world > 1 and args.pipeline) else 0.0)),
             "setup_s": {"scene": round(t_scene, 2), "upload_and_bvh": round(t_upload, 2)},
