@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/emu/evidence.sh <tag>   (on the GPU box)  — the per-round evidence set:
+# usage: tools/evidence.sh <tag>   (on the GPU box)  — the per-round evidence set:
 #   gpurun_out/<tag>_bench.json          python bench.py (default flags)
 #   gpurun_out/<tag>_kernel_stats.md     rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/<tag>_pmc_fetch.md/_write.md   FETCH_SIZE / WRITE_SIZE, separate passes, no trace flags

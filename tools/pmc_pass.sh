@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/emu/pmc_pass.sh <tag> "<counters of one pass>" ["<counters of another pass>" ...]
+# usage: tools/pmc_pass.sh <tag> "<counters of one pass>" ["<counters of another pass>" ...]
 # Each pass is its own rocprofv3 --pmc run (no trace flags), summarised into gpurun_out/pmc_<tag>_<n>.md
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

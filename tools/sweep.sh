@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/emu/sweep.sh "<flags A>" "<flags B>" ...   — rebuild librfwhip.so with each flag set, run a short bench
+# usage: tools/sweep.sh "<flags A>" "<flags B>" ...   — rebuild librfwhip.so with each flag set, run a short bench
 # (development helper for the GPU box; results go to gpurun_out/sweep.log)
 mkdir -p gpurun_out
 for flags in "$@"; do
