@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="N > 1: 1 = stream-ordered present/gather/de-interleave overlapping the next step's kernels; "
                          "0 = host-synchronous gather per step (reports gather_ms_per_step)")
+    ap.add_argument("--stage-rates", action="store_true",
+                    help="also render one serialised frame (streams = 1) and report Mrays/s per stage; off by default so "
+                         "that a kernel trace of the default command holds the timed region's launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -255,7 +258,7 @@ def main():
     # ---- rays per second per stage, the way the reference's stats window shows them (imgui_app/main.cpp:279-286): one
     # extra frame with the launches serialised (streams = 1), so every stage's time is its own -------------------------------
     stage_rates = None
-    if not args.no_roofline and rank == 0 and world == 1:
+    if args.stage_rates and rank == 0 and world == 1:
         ctx.set_setting("streams", 1)
         ctx.set_setting("stage_timing", 1)
         ctx.set_setting("spp", max(1, args.spp // 4))
