@@ -880,10 +880,20 @@ __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4 *nodes4, uint32_t coun
 		refresh4_item(nodes4, nodes2, i);
 }
 
-static inline uint32_t persistent_grid(uint32_t items)
+// Grid of the persistent kernels: more workgroups than fit on the chip at once (4-7 per CU).  The queue-driven kernels
+// do not care much (late workgroups find their queue empty), the shade kernel walks its chunks with a static stride
+// and balances better the finer that stride is.  Swept on MI355X: 8 / 16 / 32 / 64 / 128 per CU -> 1820 / 1835 /
+// 1857 / 1829 / 1780 Msamples/s (beyond 32 every extra workgroup still stages the LDS node cache and polls a queue).
+#ifndef RT_GRID_BLOCKS_PER_CU
+#define RT_GRID_BLOCKS_PER_CU 32u
+#endif
+#ifndef RT_SHADE_BLOCKS_PER_CU
+#define RT_SHADE_BLOCKS_PER_CU RT_GRID_BLOCKS_PER_CU
+#endif
+static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID_BLOCKS_PER_CU)
 {
 	uint32_t blocks = (items + BLOCK - 1) / BLOCK;
-	uint32_t cap = (uint32_t)g_cus * 8u;
+	uint32_t cap = (uint32_t)g_cus * per_cu;
 	if (blocks > cap)
 		blocks = cap;
 	blocks = (blocks + 7u) & ~7u; // multiple of 8 so every XCD gets the same number of blocks
@@ -965,7 +975,7 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 {
-	hipLaunchKernelGGL(k_shade_pt, dim3(persistent_grid(max_items)), dim3(BLOCK), 0, (hipStream_t)s, p);
+	hipLaunchKernelGGL(k_shade_pt, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
 }
 
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
