@@ -890,12 +890,17 @@ __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4 *nodes4, uint32_t coun
 #ifndef RT_SHADE_BLOCKS_PER_CU
 #define RT_SHADE_BLOCKS_PER_CU RT_GRID_BLOCKS_PER_CU
 #endif
+#ifndef RT_GRID_CHUNKS_PER_BLOCK
+#define RT_GRID_CHUNKS_PER_BLOCK 32u // a workgroup should find about this many 256-item chunks to be worth launching
+#endif
 static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID_BLOCKS_PER_CU)
 {
-	uint32_t blocks = (items + BLOCK - 1) / BLOCK;
-	uint32_t cap = (uint32_t)g_cus * per_cu;
-	if (blocks > cap)
-		blocks = cap;
+	const uint32_t chunks = (items + BLOCK - 1) / BLOCK;
+	const uint32_t lo = (uint32_t)g_cus * 8u, hi = (uint32_t)g_cus * per_cu;
+	uint32_t blocks = chunks / RT_GRID_CHUNKS_PER_BLOCK;
+	blocks = blocks < lo ? lo : (blocks > hi ? hi : blocks);
+	if (blocks > chunks)
+		blocks = chunks;
 	blocks = (blocks + 7u) & ~7u; // multiple of 8 so every XCD gets the same number of blocks
 	return blocks ? blocks : 8u;
 }
