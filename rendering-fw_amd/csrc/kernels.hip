@@ -31,9 +31,11 @@ namespace rtk
 {
 
 constexpr int BLOCK = 256;
-// minimum waves per SIMD the register allocator must leave room for in the traversal kernels (tuned on MI355X)
+// minimum waves per SIMD the register allocator must leave room for in the traversal kernels.  Swept on MI355X with
+// the final kernels: 4 / 5 / 6 / 7 / 8 -> 1863 / 1910 / 1923 / 1864 / 1863 Msamples/s (the 85-register budget of 6 makes
+// the compiler schedule the node loop tighter; the kernels need 36-52 registers either way)
 #ifndef RT_TRAVERSAL_WAVES
-#define RT_TRAVERSAL_WAVES 4
+#define RT_TRAVERSAL_WAVES 6
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
