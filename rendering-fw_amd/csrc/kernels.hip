@@ -37,6 +37,9 @@ constexpr int BLOCK = 256;
 #ifndef RT_TRAVERSAL_WAVES
 #define RT_TRAVERSAL_WAVES 6
 #endif
+#ifndef RT_ANY_WAVES
+#define RT_ANY_WAVES RT_TRAVERSAL_WAVES // occlusion kernels (fewer registers, less LDS)
+#endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
@@ -616,7 +619,7 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 }
 
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
+__global__ void __launch_bounds__(BLOCK, ANY ? RT_ANY_WAVES : RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
 {
 	RT_STACK_DECL_(ANY ? LDS_STACK_ANY : LDS_STACK)
 	WaveCounters *const wc = p.wv.counters;
@@ -771,7 +774,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_connect(const Params p)
+__global__ void __launch_bounds__(BLOCK, RT_ANY_WAVES) k_connect(const Params p)
 {
 	RT_STACK_DECL_ANY
 	const uint32_t count = p.wv.counters->shadow[p.depth];
