@@ -606,8 +606,8 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Para
 #define RT_SHADE_COMPACT 1
 #endif
 #ifndef RT_REFILL_IDLE_EXT
-#define RT_REFILL_IDLE_EXT 40 // extension rays: refill once 40 of 64 lanes are idle (swept 1..56 on MI355X: eager
-							  // refills cost more than they save; 32..56 are equivalent, +6 % over no refill)
+#define RT_REFILL_IDLE_EXT 52 // extension rays: refill once 52 of 64 lanes are idle (swept on MI355X: eager refills cost
+							  // more than they save: 1 -> -45 %; 32 / 40 / 48 / 52 / 56 / 60 / 64 -> 1900 / 1919 / 1935 / 1934 / 1934 / 1922 / 1898)
 #endif
 #ifndef RT_REFILL_IDLE_ANY
 #define RT_REFILL_IDLE_ANY 56 // shadow rays are short: only nearly-empty waves are worth refilling (+3 %)
