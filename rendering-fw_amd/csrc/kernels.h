@@ -62,8 +62,11 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 // after a refit of the BVH2 boxes: copy them into the 4-wide traversal nodes of the same BLAS (Node4::src)
 void launch_refresh4(rt::Node4 *nodes4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
 // BVH construction on the device (lbvh.hip): BVH2 in device form over chunks of four Morton-consecutive triangles, boxes
-// fitted, leaf-ordered vertices written; mesh-local arrays (node_base = tri_base = 0).  nodes: 2 * ceil(n / 4) entries,
+// fitted, leaf-ordered vertices written; mesh-local arrays (node_base = tri_base = 0).  nodes: 2 * ceil(n / LBVH_CHUNK) entries,
 // parents / flags the same, tri_verts 3 n.  Returns 0, or 1 when the mesh is a single leaf (build it on the host).
+#ifndef LBVH_CHUNK
+#define LBVH_CHUNK 4
+#endif
 size_t lbvh_scratch_bytes(uint32_t tri_count);
 int launch_lbvh_build(const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, void *scratch, size_t scratch_bytes,
 					  rt::Node *nodes, int *parents, rt::f4 *tri_verts, uint32_t *flags, float bounds_out_device[6], stream_t s);

@@ -3,7 +3,7 @@
 // inner node adjacent, node 1 unused) and fitted bottom-up by the refit kernels of kernels.hip.
 //
 //   k_lbvh_bounds    per triangle: union of the triangle boxes (ordered-int atomics)                 -> bounds[6]
-//   k_lbvh_morton    per triangle: 30-bit Morton code of the centroid in those bounds                -> keys, vals
+//   k_lbvh_morton    per triangle: 63-bit Morton code of the centroid in those bounds                -> keys, vals
 //   radix sort       rocPRIM radix_sort_pairs on (code, triangle)   [a library primitive, like a GEMM would be]
 //   k_lbvh_hierarchy per inner node of the chunk tree: range + split (Karras 2012), children's slots
 //   k_lbvh_emit      per inner node / per chunk: rt::Node in device form + parent links
@@ -30,6 +30,7 @@ namespace rtk
 {
 using namespace rt;
 
+constexpr uint32_t CHUNK = LBVH_CHUNK; // Morton-consecutive triangles per leaf
 constexpr uint32_t LEAF_REF = 0x80000000u; // child reference: chunk (leaf) index instead of inner-node index
 
 // floats as unsigned keys that order like the floats (for atomicMin / atomicMax)
@@ -50,16 +51,19 @@ RT_FN void tri_corners(const f4 *verts, const uint32_t *indices, uint32_t t, f3 
 		i0 = indices[3ull * t], i1 = indices[3ull * t + 1], i2 = indices[3ull * t + 2];
 	a = xyz(verts[i0]), b = xyz(verts[i1]), c = xyz(verts[i2]);
 }
-RT_FN uint32_t expand10(uint32_t v)
+// 21 bits per axis -> 63-bit code (a 30-bit code leaves many of a million triangles with equal keys, and equal keys
+// split by index, not by space)
+RT_FN uint64_t expand21(uint32_t v)
 {
-	v &= 1023u;
-	v = (v | (v << 16)) & 0x030000FFu;
-	v = (v | (v << 8)) & 0x0300F00Fu;
-	v = (v | (v << 4)) & 0x030C30C3u;
-	v = (v | (v << 2)) & 0x09249249u;
-	return v;
+	uint64_t x = v & 0x1FFFFFu;
+	x = (x | (x << 32)) & 0x1F00000000FFFFull;
+	x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+	x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+	x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
 }
-RT_FN uint32_t morton_item(const f4 *verts, const uint32_t *indices, const uint32_t *bounds, uint32_t t)
+RT_FN uint64_t morton_item(const f4 *verts, const uint32_t *indices, const uint32_t *bounds, uint32_t t)
 {
 	f3 a, b, c;
 	tri_corners(verts, indices, t, a, b, c);
@@ -73,25 +77,25 @@ RT_FN uint32_t morton_item(const f4 *verts, const uint32_t *indices, const uint3
 		const float e = hi[k] - lo[k];
 		float u = e > 0.0f ? (p[k] - lo[k]) / e : 0.0f;
 		u = fminf(fmaxf(u, 0.0f), 1.0f);
-		q[k] = (uint32_t)(u * 1023.0f);
+		q[k] = (uint32_t)(u * 2097151.0f);
 	}
-	return (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+	return (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
 }
 
 // Karras 2012: common-prefix length of the keys of chunks i and j; equal keys fall back to the indices.
-RT_FN int lbvh_delta(const uint32_t *keys, int m, int i, int j)
+RT_FN int lbvh_delta(const uint64_t *keys, int m, int i, int j)
 {
 	if (j < 0 || j >= m)
 		return -1;
-	const uint32_t x = keys[4 * i] ^ keys[4 * j];
+	const uint64_t x = keys[CHUNK * (uint32_t)i] ^ keys[CHUNK * (uint32_t)j];
 #if defined(__HIP_DEVICE_COMPILE__)
-	return x ? __clz((int)x) : 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+	return x ? __clzll((long long)x) : 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
 #else
-	return x ? __builtin_clz(x) : 32 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
+	return x ? __builtin_clzll(x) : 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
 #endif
 }
 // inner node i of the tree over m chunks: children + where they will live (the pair of slots behind inner node i)
-RT_FN void hierarchy_item(const uint32_t *keys, int m, uint32_t *child, uint32_t *slot_inner, uint32_t *slot_leaf, int i)
+RT_FN void hierarchy_item(const uint64_t *keys, int m, uint32_t *child, uint32_t *slot_inner, uint32_t *slot_leaf, int i)
 {
 	const int d = lbvh_delta(keys, m, i, i + 1) - lbvh_delta(keys, m, i, i - 1) >= 0 ? 1 : -1;
 	const int dmin = lbvh_delta(keys, m, i, i - d);
@@ -145,8 +149,8 @@ RT_FN void emit_inner_item(Node *nodes, int *parents, const uint32_t *slot_inner
 }
 RT_FN void emit_leaf_item(Node *nodes, const uint32_t *slot_leaf, uint32_t tri_count, uint32_t k)
 {
-	const uint32_t first = 4u * k;
-	const uint32_t cnt = tri_count - first < 4u ? tri_count - first : 4u;
+	const uint32_t first = CHUNK * k;
+	const uint32_t cnt = tri_count - first < CHUNK ? tri_count - first : CHUNK;
 	Node n;
 	memset(&n, 0, sizeof(n));
 	n.left_first = (int)make_entry((int)first, (int)cnt, false);
@@ -180,13 +184,13 @@ __global__ void __launch_bounds__(256) k_lbvh_bounds(const f4 *verts, const uint
 	}
 }
 __global__ void __launch_bounds__(256) k_lbvh_morton(const f4 *verts, const uint32_t *indices, const uint32_t *bounds, uint32_t n,
-												  uint32_t *keys, uint32_t *vals)
+												  uint64_t *keys, uint32_t *vals)
 {
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t < n)
 		keys[t] = morton_item(verts, indices, bounds, t), vals[t] = t;
 }
-__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint32_t *keys, int m, uint32_t *child, uint32_t *slot_inner,
+__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint64_t *keys, int m, uint32_t *child, uint32_t *slot_inner,
 													 uint32_t *slot_leaf)
 {
 	const int i = (int)(blockIdx.x * 256u + threadIdx.x);
@@ -212,11 +216,12 @@ __global__ void __launch_bounds__(256) k_lbvh_leaf_ids(f4 *tri_verts, const uint
 size_t lbvh_scratch_bytes(uint32_t tri_count)
 {
 	size_t sort_tmp = 0;
-	uint32_t *k = nullptr;
-	(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, k, k, k, k, (size_t)tri_count, 0u, 30u, (hipStream_t)0);
-	const size_t n = tri_count, m = (n + 3) / 4;
-	// bounds[8] | keys | vals | keys_sorted | vals_sorted | child[2m] | slot_inner[m] | slot_leaf[m] | sort temp
-	return 256 + 4 * (4 * n + 4 * m) + 64 * 8 + sort_tmp + 256;
+	uint64_t *k = nullptr;
+	uint32_t *v = nullptr;
+	(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, k, k, v, v, (size_t)tri_count, 0u, 63u, (hipStream_t)0);
+	const size_t n = tri_count, m = (n + CHUNK - 1) / CHUNK;
+	// bounds[8] | keys (8 B) | vals | keys_sorted (8 B) | vals_sorted | child[2m] | slot_inner[m] | slot_leaf[m] | sort temp
+	return 256 + 24 * n + 16 * m + 64 * 8 + sort_tmp + 256;
 }
 
 int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_count, void *scratch, size_t scratch_bytes,
@@ -224,7 +229,7 @@ int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_cou
 {
 	(void)bounds_out_device;
 	hipStream_t st = (hipStream_t)s;
-	const uint32_t n = tri_count, m = (n + 3u) / 4u;
+	const uint32_t n = tri_count, m = (n + CHUNK - 1u) / CHUNK;
 	if (m < 2u)
 		return 1; // a single leaf: the caller builds those on the host
 	uint8_t *p = (uint8_t *)scratch;
@@ -234,11 +239,11 @@ int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_cou
 		return r;
 	};
 	uint32_t *bounds = (uint32_t *)take(32);
-	uint32_t *keys = (uint32_t *)take(4ull * n), *vals = (uint32_t *)take(4ull * n);
-	uint32_t *keys2 = (uint32_t *)take(4ull * n), *vals2 = (uint32_t *)take(4ull * n);
+	uint64_t *keys = (uint64_t *)take(8ull * n), *keys2 = (uint64_t *)take(8ull * n);
+	uint32_t *vals = (uint32_t *)take(4ull * n), *vals2 = (uint32_t *)take(4ull * n);
 	uint32_t *child = (uint32_t *)take(8ull * m), *slot_inner = (uint32_t *)take(4ull * m), *slot_leaf = (uint32_t *)take(4ull * m);
 	size_t sort_tmp = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, vals2, (size_t)n, 0u, 30u, st);
+	(void)rocprim::radix_sort_pairs(nullptr, sort_tmp, keys, keys2, vals, vals2, (size_t)n, 0u, 63u, st);
 	void *tmp = take(sort_tmp);
 	if ((size_t)(p - (uint8_t *)scratch) > scratch_bytes)
 		return 2;
@@ -247,7 +252,7 @@ int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_cou
 	const uint32_t blocks = (n + 255u) / 256u;
 	hipLaunchKernelGGL(k_lbvh_bounds, dim3(blocks < 2048u ? blocks : 2048u), dim3(256), 0, st, verts, indices, n, bounds);
 	hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, verts, indices, bounds, n, keys, vals);
-	if (rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, vals2, (size_t)n, 0u, 30u, st) != hipSuccess)
+	if (rocprim::radix_sort_pairs(tmp, sort_tmp, keys, keys2, vals, vals2, (size_t)n, 0u, 63u, st) != hipSuccess)
 		return 3;
 	hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((m + 255u) / 256u), dim3(256), 0, st, keys2, (int)m, child, slot_inner, slot_leaf);
 	hipLaunchKernelGGL(k_lbvh_emit, dim3((m + 255u) / 256u), dim3(256), 0, st, nodes, parents, slot_inner, slot_leaf, m, n);
@@ -259,12 +264,12 @@ int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_cou
 
 #else // host emulation: the same items, plain loops; std::stable_sort stands in for the radix sort
 
-size_t lbvh_scratch_bytes(uint32_t tri_count) { return 64 + 32ull * tri_count; }
+size_t lbvh_scratch_bytes(uint32_t tri_count) { return 64 + 48ull * tri_count; }
 
 int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_count, void *, size_t, Node *nodes, int *parents,
 					  f4 *tri_verts, uint32_t *flags, float *, stream_t s)
 {
-	const uint32_t n = tri_count, m = (n + 3u) / 4u;
+	const uint32_t n = tri_count, m = (n + CHUNK - 1u) / CHUNK;
 	if (m < 2u)
 		return 1;
 	uint32_t bounds[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
@@ -280,11 +285,12 @@ int launch_lbvh_build(const f4 *verts, const uint32_t *indices, uint32_t tri_cou
 			bounds[3 + k] = std::max(bounds[3 + k], float_key(hi[k]));
 		}
 	}
-	std::vector<uint32_t> keys(n), vals(n), order(n);
+	std::vector<uint64_t> keys(n);
+	std::vector<uint32_t> vals(n), order(n);
 	for (uint32_t t = 0; t < n; t++)
 		keys[t] = morton_item(verts, indices, bounds, t), order[t] = t;
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-	std::vector<uint32_t> keys2(n);
+	std::vector<uint64_t> keys2(n);
 	for (uint32_t t = 0; t < n; t++)
 		keys2[t] = keys[order[t]], vals[t] = order[t];
 	std::vector<uint32_t> child(2ull * m), slot_inner(m), slot_leaf(m);

@@ -802,11 +802,11 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	// (re)build
 	const size_t n = mesh->triangleCount;
 	bool device_built = false;
-	if (c->builder == 1 && n > 4)
+	if (c->builder == 1 && n > LBVH_CHUNK)
 	{
 		// construction on the device (lbvh.hip) in mesh-local arrays; topology, boxes and leaf-ordered vertices come back
 		// and take the same road as a host-built tree (4-wide collapse, placement in update())
-		const uint32_t m2 = 2u * (uint32_t)((n + 3) / 4);
+		const uint32_t m2 = 2u * (uint32_t)((n + LBVH_CHUNK - 1) / LBVH_CHUNK);
 		RF_TRY(c->d_lbvh_scratch.ensure(rtk::lbvh_scratch_bytes((uint32_t)n)));
 		RF_TRY(c->d_lbvh_nodes.ensure((size_t)m2 * sizeof(rt::Node)));
 		RF_TRY(c->d_lbvh_tri_verts.ensure(3 * n * sizeof(f4)));
