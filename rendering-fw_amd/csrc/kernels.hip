@@ -37,6 +37,9 @@ constexpr int BLOCK = 256;
 #ifndef RT_TRAVERSAL_WAVES
 #define RT_TRAVERSAL_WAVES 6
 #endif
+#ifndef RT_PRIMARY_WAVES
+#define RT_PRIMARY_WAVES RT_TRAVERSAL_WAVES // k_extend: the kernel that also generates the primary rays
+#endif
 #ifndef RT_ANY_WAVES
 #define RT_ANY_WAVES RT_TRAVERSAL_WAVES // occlusion kernels (fewer registers, less LDS)
 #endif
@@ -581,7 +584,7 @@ __device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
 }
 
 template <int GEN, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_extend(const Params p, const uint32_t fixed_count)
+__global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
 	RT_STACK_DECL_CLOSEST
 	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext[p.depth] : fixed_count;
