@@ -139,7 +139,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   lds_nodes    = top-of-tree 4-wide nodes of the largest mesh BVH that every traversal workgroup keeps in LDS
  *                  (-1 = as many as the kernels were built for, the default; 0 disables)
  *   streams      = sub-batches of one render call that run concurrently on their own HIP streams (1..8, default 4)
- *   refill       = "1"|"0": persistent lanes on the incoherent waves (a lane that finishes its ray pulls the next)
+ *   refill       = bit mask, default 3: bit 0 persistent lanes on the extension (bounce) waves, bit 1 on the shadow waves
+ *                  (a lane that finishes its ray pulls the next one from the wave's queue)
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);
