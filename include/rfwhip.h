@@ -133,7 +133,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   builder      = "host" (parallel binned SAH on the CPU, the default) | "device" (Morton order + Karras hierarchy on the
  *                  GPU, lbvh.hip; applies to the next rfwhip_set_mesh that (re)builds)
  *   sampler      = "hash" (WangHash + xorshift32, tools.h:218-235; default) | "bluenoise" (needs rfwhip_set_blue_noise)
- *                  — pt integrator, primary rays
+ *                  — pt integrator: primary rays (dimensions 0-3, Kernels.cu:391-394) and, for the first 256 samples, the
+ *                  light sample of next-event estimation (dimensions 4-5, Kernels.cu:712-719)
  *   stage_timing = "0"|"1": bracket every stage with hipEvents (fills RenderStats like the reference's timers)
  *   count_traversal = "0"|"1": instrumented traversal (popped inner nodes / triangle tests), for the roofline
  *   lds_nodes    = top-of-tree 4-wide nodes of the largest mesh BVH that every traversal workgroup keeps in LDS
@@ -173,6 +174,12 @@ RFWHIP_API int rfwhip_read_primary_hits(rfwhip_context *ctx, float *t, int32_t *
  * scene with the extend kernel; any output pointer may be NULL.  t = t_max on a miss. */
 RFWHIP_API int rfwhip_trace_rays(rfwhip_context *ctx, size_t n, const float *org, const float *dir, float t_min,
 								 float t_max, float *t, int32_t *prim, int32_t *inst, float *u, float *v);
+
+/* Known-answer hook: one of the path tracer's DEVICE functions (rt_core.h: BSDF, light sampling, packing, samplers — the
+ * very functions the shade kernel calls) evaluated by a kernel on n records; functions and record layout: RFWHIP_KAT_* in
+ * rfwhip_abi.h.  in: n x RFWHIP_KAT_IN floats, out: n x RFWHIP_KAT_OUT floats (host pointers).  The light functions use
+ * the lights of the last rfwhip_update(), BLUE_NOISE the table of rfwhip_set_blue_noise. */
+RFWHIP_API int rfwhip_kat(rfwhip_context *ctx, int function, size_t n, const float *in, float *out);
 
 /* BVH of mesh `index` as built on the device side (bvh_node.h layout) + its primitive order. */
 RFWHIP_API int rfwhip_get_bvh(rfwhip_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,

@@ -247,6 +247,30 @@ enum rfwhip_render_status
 	RFWHIP_CONVERGE = 1
 };
 
+/* Known-answer records of rfwhip_kat(): every function reads one record of RFWHIP_KAT_IN floats and writes one of
+ * RFWHIP_KAT_OUT floats (integers travel as their bit patterns).  BSDF record: [0..2] colour, [3..5] absorption,
+ * [6..8] ShadingData parameters x,y,z (bsdf/compat.h:57-72), [9..11] N, [12..14] wo, [15..17] wi, [18] t,
+ * [19] backfacing, [20] r3 (or r0), [21] r4.  Light record: [0..2] I, [3..5] N, [6] r0, [7] r1, [8] light index,
+ * [9..11] O. */
+enum
+{
+	RFWHIP_KAT_IN = 24,
+	RFWHIP_KAT_OUT = 8
+};
+enum rfwhip_kat_function
+{
+	RFWHIP_KAT_BSDF_EVAL = 0,		   /* disney.h:104-185 BSDFEval            -> rgb */
+	RFWHIP_KAT_BSDF_PDF = 1,		   /* disney.h:83-101  BSDFPdf             -> pdf */
+	RFWHIP_KAT_BSDF_SAMPLE = 2,		   /* disney.h:188-262 BSDFSample, frame by createTangentSpace(N) -> wi, pdf */
+	RFWHIP_KAT_TANGENT_SPACE = 3,	   /* tools.h:204-211                      -> T, B */
+	RFWHIP_KAT_PACK_NORMAL = 4,		   /* tools.h:10-29                        -> packed bits, unpacked normal */
+	RFWHIP_KAT_RANDOM_BARYCENTRICS = 5, /* lights.h:119-157, r0 = [20]          -> barycentrics */
+	RFWHIP_KAT_POINT_ON_LIGHT = 6,	   /* lights.h:159-265 on the context's lights -> P, pickProb, lightPdf, colour */
+	RFWHIP_KAT_LIGHT_PICK_PROB = 7,	   /* lights.h:83-116                      -> probability */
+	RFWHIP_KAT_BLUE_NOISE = 8,		   /* tools.h:163-181, [0..3] = x, y, sample, dimension (ints) -> value */
+	RFWHIP_KAT_HASH = 9				   /* tools.h:218-235, [0] = seed -> WangHash bits, RandomFloat, state bits */
+};
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,8 @@ struct rfwo_context
 	int jitter; /* 0 xor128, 1 center */
 	int sampler;			 /* 0 hash RNG, 1 blue noise */
 	uint32_t *blue_noise; /* 5 x 65536 words or NULL */
+	float *pend;		  /* pt: unoccluded connection contributions per pixel and depth, W*H*pend_depths*3 */
+	size_t pend_cap;
 	int use_bvh;
 	int threads;
 
@@ -680,7 +682,7 @@ void rfwo_destroy(rfwo_context *c)
 		free(c->textures[i].data);
 	free(c->meshes), free(c->instances), free(c->materials), free(c->textures), free(c->sky), free(c->area);
 	free(c->point), free(c->spot), free(c->dir), free(c->acc), free(c->hit_t), free(c->hit_u), free(c->hit_v);
-	free(c->hit_prim), free(c->hit_inst), free(c->blue_noise);
+	free(c->hit_prim), free(c->hit_inst), free(c->blue_noise), free(c->pend);
 	free(c);
 }
 int rfwo_init(rfwo_context *c, uint32_t w, uint32_t h)
@@ -1565,11 +1567,14 @@ static v3 layer_normal(const rfwo_context *c, const rfwhip_map_desc *md, float t
 	return vscale(vsub(V3(p[0], p[1], p[2]), V3(0.5f, 0.5f, 0.5f)), 2.0f);
 }
 
+#define PT_MAX_DEPTHS 16
 typedef struct
 {
-	v3 sum;
-	uint64_t ext, shadow;
-	tstat st, ss;
+	v3 sum;					   /* sky + emissive terms: added unconditionally */
+	v3 pend[PT_MAX_DEPTHS];	   /* unoccluded connection emitted by the shade call of depth d (added if that wave is launched) */
+	uint32_t ext_d[PT_MAX_DEPTHS + 1]; /* rays of this path in the extension wave of depth d */
+	uint32_t shadow_d[PT_MAX_DEPTHS];  /* connections emitted at depth d */
+	tstat st, ss_d[PT_MAX_DEPTHS];
 	int probe_hit, probe_inst, probe_prim;
 	float probe_t;
 	float pt, pu, pv;
@@ -1620,7 +1625,7 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 	{
 		float t = 1e34f, bu = 0, bv = 0;
 		int inst = -1, prim = -1;
-		res->ext++;
+		res->ext_d[pathLength]++;
 		const int hit = scene_closest(c, O, D, 1e-5f, &t, &inst, &prim, &bu, &bv, &res->st);
 		if (pathLength == 0)
 			res->pt = t, res->pu = bu, res->pv = bv, res->pprim = hit ? prim : -1, res->pinst = hit ? inst : -1;
@@ -1751,7 +1756,14 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 		{
 			v3 lightColor = V3(0, 0, 0);
 			float pickProb = 0, lightPdf = 0;
-			const float q0 = random_float(&seed), q1 = random_float(&seed);
+			float q0, q1;
+			if (c->sampler == 1 && c->blue_noise && sampleIdx < 256) /* BLUENOISE, Kernels.cu:712-719: seed not advanced */
+			{
+				q0 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 4);
+				q1 = rfwo_blue_noise_sample(c->blue_noise, sx, sy, (int)sampleIdx, 5);
+			}
+			else
+				q0 = random_float(&seed), q1 = random_float(&seed);
 			v3 L = vsub(random_point_on_light(c, q0, q1, I, iN, &pickProb, &lightPdf, &lightColor), I);
 			const float dist = vlen(L);
 			L = vscale(L, 1.0f / dist);
@@ -1766,12 +1778,16 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 					v3 contribution =
 						vscale(vmul(vmul(T, bs), lightColor), NdotL / (shadowPdf + lightPdf * pickProb));
 					contribution = clamp_intensity(contribution, clampValue);
-					if (!v3_any_nan(contribution))
+					/* The connections of a shade call are traced at the top of the NEXT iteration of the host loop
+					 * (CUDART/src/Context.cpp:109-120): those of the last shade call (pathLength == MAX_PATH_LENGTH)
+					 * never are.  Whether the wave of an earlier depth is launched (activePaths > 0) is known only
+					 * after the whole frame: render_pt_sample decides. */
+					if (!v3_any_nan(contribution) && pathLength < (uint32_t)c->max_depth)
 					{
-						res->shadow++;
+						res->shadow_d[pathLength]++;
 						const v3 so = vadd(I, vscale(N, 1e-5f)); /* SafeOrigin, tools.h:119-123 */
-						if (!scene_occluded(c, so, L, GEO_EPS, dist - 2.0f * GEO_EPS, &res->ss))
-							res->sum = vadd(res->sum, contribution);
+						if (!scene_occluded(c, so, L, GEO_EPS, dist - 2.0f * GEO_EPS, &res->ss_d[pathLength]))
+							res->pend[pathLength] = contribution;
 					}
 				}
 			}
@@ -1798,11 +1814,112 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 	}
 }
 
+/* Known-answer hook (rfw_oracle.h): one of the path tracer's functions on n records, same record layout as the
+ * product's rfwhip_kat (include/rfwhip.h). */
+int rfwo_kat(rfwo_context *c, int function, size_t n, const float *in, float *out)
+{
+	if (!c || !in || !out)
+		return fail("rfwo_kat: null argument");
+	for (size_t i = 0; i < n; i++)
+	{
+		const float *r = in + i * RFWHIP_KAT_IN;
+		float *o = out + i * RFWHIP_KAT_OUT;
+		uint32_t ub[RFWHIP_KAT_IN];
+		memcpy(ub, r, sizeof(ub));
+		for (int k = 0; k < RFWHIP_KAT_OUT; k++)
+			o[k] = 0.0f;
+		oshading sd;
+		sd.color = V3(r[0], r[1], r[2]), sd.absorption = V3(r[3], r[4], r[5]);
+		sd.p[0] = ub[6], sd.p[1] = ub[7], sd.p[2] = ub[8], sd.p[3] = 0;
+		const v3 N = V3(r[9], r[10], r[11]), wo = V3(r[12], r[13], r[14]), wi = V3(r[15], r[16], r[17]);
+		switch (function)
+		{
+		case RFWHIP_KAT_BSDF_EVAL:
+		{
+			const v3 e = bsdf_eval(&sd, N, wo, wi, r[18], ub[19] != 0);
+			o[0] = e.x, o[1] = e.y, o[2] = e.z;
+			break;
+		}
+		case RFWHIP_KAT_BSDF_PDF:
+			o[0] = bsdf_pdf(&sd, N, wo, wi);
+			break;
+		case RFWHIP_KAT_BSDF_SAMPLE:
+		{
+			v3 T, B, R = V3(0, 0, 1);
+			float pdf = 0.0f;
+			create_tangent_space(N, &T, &B);
+			bsdf_sample(&sd, T, B, N, wo, &R, &pdf, r[20], r[21]);
+			o[0] = R.x, o[1] = R.y, o[2] = R.z, o[3] = pdf;
+			break;
+		}
+		case RFWHIP_KAT_TANGENT_SPACE:
+		{
+			v3 T, B;
+			create_tangent_space(N, &T, &B);
+			o[0] = T.x, o[1] = T.y, o[2] = T.z, o[3] = B.x, o[4] = B.y, o[5] = B.z;
+			break;
+		}
+		case RFWHIP_KAT_PACK_NORMAL:
+		{
+			const uint32_t pk = pack_normal(N);
+			const v3 u = unpack_normal(pk);
+			memcpy(&o[0], &pk, 4);
+			o[1] = u.x, o[2] = u.y, o[3] = u.z;
+			break;
+		}
+		case RFWHIP_KAT_RANDOM_BARYCENTRICS:
+		{
+			const v3 b = random_barycentrics(r[20]);
+			o[0] = b.x, o[1] = b.y, o[2] = b.z;
+			break;
+		}
+		case RFWHIP_KAT_POINT_ON_LIGHT:
+		{
+			float pick = 0, pdf = 0;
+			v3 col = V3(0, 0, 0);
+			const v3 P = random_point_on_light(c, r[6], r[7], V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), &pick, &pdf, &col);
+			o[0] = P.x, o[1] = P.y, o[2] = P.z, o[3] = pick, o[4] = pdf, o[5] = col.x, o[6] = col.y, o[7] = col.z;
+			break;
+		}
+		case RFWHIP_KAT_LIGHT_PICK_PROB:
+			o[0] = light_pick_prob(c, (int)ub[8], V3(r[9], r[10], r[11]), V3(r[3], r[4], r[5]), V3(r[0], r[1], r[2]));
+			break;
+		case RFWHIP_KAT_BLUE_NOISE:
+			if (!c->blue_noise)
+				return fail("rfwo_kat: no blue-noise table");
+			o[0] = rfwo_blue_noise_sample(c->blue_noise, (int)ub[0], (int)ub[1], (int)ub[2], (int)ub[3]);
+			break;
+		case RFWHIP_KAT_HASH:
+		{
+			uint32_t st = wang_hash(ub[0]);
+			memcpy(&o[0], &st, 4);
+			o[1] = random_float(&st);
+			memcpy(&o[2], &st, 4);
+			break;
+		}
+		default:
+			return fail("rfwo_kat: unknown function");
+		}
+	}
+	return 0;
+}
+
 static void render_pt_sample(rfwo_context *c, const rfwhip_camera_view *view, float clampValue, uint32_t sampleIdx)
 {
 	const uint32_t W = c->W, H = c->H;
-	uint64_t ext = 0, shadow = 0, tinner = 0, ttris = 0, sinner = 0, stris = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : ext, shadow, tinner, ttris, sinner, stris)
+	const int nd = c->max_depth > 0 ? c->max_depth : 1; /* depths whose connections can be traced: 0 .. max_depth-1 */
+	const size_t need = (size_t)W * H * (size_t)nd * 3;
+	if (need > c->pend_cap)
+	{
+		free(c->pend);
+		c->pend = (float *)malloc(need * sizeof(float));
+		c->pend_cap = need;
+	}
+	uint64_t ext_d[PT_MAX_DEPTHS + 1], shadow_d[PT_MAX_DEPTHS], sinner_d[PT_MAX_DEPTHS], stris_d[PT_MAX_DEPTHS];
+	memset(ext_d, 0, sizeof(ext_d)), memset(shadow_d, 0, sizeof(shadow_d));
+	memset(sinner_d, 0, sizeof(sinner_d)), memset(stris_d, 0, sizeof(stris_d));
+	uint64_t tinner = 0, ttris = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tinner, ttris, ext_d[:PT_MAX_DEPTHS + 1], shadow_d[:PT_MAX_DEPTHS], sinner_d[:PT_MAX_DEPTHS], stris_d[:PT_MAX_DEPTHS])
 	for (int y = 0; y < (int)H; y++)
 	{
 		if (!owns_row(c, (uint32_t)y))
@@ -1815,18 +1932,51 @@ static void render_pt_sample(rfwo_context *c, const rfwhip_camera_view *view, fl
 			pt_path(c, view, clampValue, pixel, sampleIdx, &r);
 			float *a = &c->acc[(size_t)pixel * 4];
 			a[0] += r.sum.x, a[1] += r.sum.y, a[2] += r.sum.z, a[3] += 1.0f;
+			for (int d = 0; d < nd; d++)
+			{
+				float *pd = &c->pend[((size_t)pixel * nd + d) * 3];
+				pd[0] = r.pend[d].x, pd[1] = r.pend[d].y, pd[2] = r.pend[d].z;
+			}
 			c->hit_t[pixel] = r.pt, c->hit_u[pixel] = r.pu, c->hit_v[pixel] = r.pv;
 			c->hit_prim[pixel] = r.pprim, c->hit_inst[pixel] = r.pinst;
 			if (r.probe_hit && sampleIdx == 0)
 				c->probe_inst = (uint32_t)r.probe_inst, c->probe_prim = (uint32_t)r.probe_prim, c->probe_dist = r.probe_t;
-			ext += r.ext, shadow += r.shadow, tinner += r.st.inner, ttris += r.st.tris;
-			sinner += r.ss.inner, stris += r.ss.tris;
+			tinner += r.st.inner, ttris += r.st.tris;
+			for (int d = 0; d < PT_MAX_DEPTHS; d++)
+				ext_d[d] += r.ext_d[d], shadow_d[d] += r.shadow_d[d], sinner_d[d] += r.ss_d[d].inner, stris_d[d] += r.ss_d[d].tris;
+			ext_d[PT_MAX_DEPTHS] += r.ext_d[PT_MAX_DEPTHS];
+		}
+	}
+	/* CUDART/src/Context.cpp:109: while (activePaths > 0 && pathLength < MAX_PATH_LENGTH) { trace the connections of the
+	 * previous shade call; extend; shade }.  The connection wave of depth d runs iff depth d + 1 has extension rays. */
+	uint64_t ext = 0, shadow = 0, sinner = 0, stris = 0;
+	for (int d = 0; d <= PT_MAX_DEPTHS; d++)
+		ext += ext_d[d];
+	for (int d = 0; d < c->max_depth && d < PT_MAX_DEPTHS; d++)
+	{
+		if (ext_d[d + 1] == 0)
+			continue;
+		shadow += shadow_d[d], sinner += sinner_d[d], stris += stris_d[d];
+#pragma omp parallel for schedule(static)
+		for (int y = 0; y < (int)H; y++)
+		{
+			if (!owns_row(c, (uint32_t)y))
+				continue;
+			for (uint32_t x = 0; x < W; x++)
+			{
+				const size_t pixel = (size_t)y * W + x;
+				const float *pd = &c->pend[(pixel * nd + d) * 3];
+				float *a = &c->acc[pixel * 4];
+				a[0] += pd[0], a[1] += pd[1], a[2] += pd[2];
+			}
 		}
 	}
 	c->cnt[0] += ext, c->cnt[1] += shadow, c->cnt[2] += tinner, c->cnt[3] += ttris, c->cnt[4] += sinner;
 	c->cnt[5] += stris;
 	c->stats.shadowCount += (uint32_t)shadow;
-	c->stats.secondaryCount += (uint32_t)(ext - (uint64_t)0);
+	c->stats.secondaryCount += (uint32_t)ext_d[1];
+	for (int d = 2; d <= PT_MAX_DEPTHS; d++)
+		c->stats.deepCount += (uint32_t)ext_d[d];
 }
 
 /* =============================================================================================================

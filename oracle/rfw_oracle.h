@@ -95,6 +95,9 @@ void rfwo_sample_bsdf(const float color[3], const float absorption[3], const uin
 					  const float wo[3], float t, int backfacing, float r3, float r4, float out_rgb[3],
 					  float wi[3], float *pdf);
 
+/* one of the path tracer's functions on n records; functions and record layout: RFWHIP_KAT_* in include/rfwhip_abi.h */
+int rfwo_kat(rfwo_context *ctx, int function, size_t n, const float *in, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ class CoreBinding:
                                   "deinterleave_stream": (i32, [vp, vp, vp, vp]),
                                   "read_local_framebuffer_device": (i32, [vp, vp]),
                                   "deinterleave_device": (i32, [vp, vp, vp]),
+                                  "kat": (i32, [vp, i32, sz, vp, vp]),
                                   "get_counters": (i32, [vp, C.POINTER(abi.Counters), i32])}.items():
             if self._has(name):
                 f = self._fn(name)
@@ -265,6 +266,17 @@ class CoreBinding:
         self._check(self._fn("trace_rays")(self._ctx, n, o.ctypes.data, d.ctypes.data, t_min, t_max, t.ctypes.data,
                                             prim.ctypes.data, inst.ctypes.data, u.ctypes.data, v.ctypes.data))
         return {"t": t, "prim": prim, "inst": inst, "u": u, "v": v}
+
+    # known-answer hook: RFWHIP_KAT_* (include/rfwhip_abi.h)
+    KAT = {"bsdf_eval": 0, "bsdf_pdf": 1, "bsdf_sample": 2, "tangent_space": 3, "pack_normal": 4,
+           "random_barycentrics": 5, "point_on_light": 6, "light_pick_prob": 7, "blue_noise": 8, "hash": 9}
+
+    def kat(self, function, records):
+        """One of the path tracer's functions on n records (n x 24 float32, integers as bit patterns) -> n x 8 float32."""
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 24)
+        out = np.zeros((len(rec), 8), np.float32)
+        self._check(self._fn("kat")(self._ctx, int(self.KAT[function]), len(rec), rec.ctypes.data, out.ctypes.data))
+        return out
 
     def get_counters(self, reset=False):
         """Traversal statistics since the last reset (count_traversal=1): rays, popped inner nodes, triangle tests."""

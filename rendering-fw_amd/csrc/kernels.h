@@ -48,6 +48,8 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s);
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s);
 void launch_resolve(const Params &p, stream_t s);
+// rfwhip_kat: `function` (RFWHIP_KAT_*) on n records of 24 floats -> n records of 8 floats (device pointers)
+void launch_kat(const Params &p, int function, const float *in, float *out, uint32_t n, stream_t s);
 // out: local layout (local_rows x W) when full == 0, else full image (H x W; world must be 1)
 void launch_present(const Params &p, rt::f4 *out, float scale, int full, stream_t s);
 void launch_deinterleave(const rt::f4 *gathered, rt::f4 *out, uint32_t W, uint32_t H, uint32_t local_rows,

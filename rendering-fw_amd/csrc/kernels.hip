@@ -31,6 +31,7 @@ namespace rtk
 {
 
 constexpr int BLOCK = 256;
+constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (static_assert in rfwhip_api.cpp)
 // minimum waves per SIMD the register allocator must leave room for in the traversal kernels.  Swept on MI355X with
 // the final kernels: 4 / 5 / 6 / 7 / 8 -> 1863 / 1910 / 1923 / 1864 / 1863 Msamples/s (the 85-register budget of 6 makes
 // the compiler schedule the node loop tighter; the kernels need 36-52 registers either way)
@@ -261,6 +262,7 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		const PixelRef pr = slot_to_pixel(p.fr, in.slot);
 		{
 			in.pixel = pr.y * p.fr.W + pr.x;
+			in.px = pr.x, in.py = pr.y;
 			in.sampleIdx = p.fr.sample_base + pr.sample;
 			in.depth = p.depth;
 			Hit h;
@@ -329,7 +331,91 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	}
 }
 
-// local pixel (yl, x) -> tiled slot offset within one sample
+// rfwhip_kat: one of the shade kernel's functions on one record (rfwhip_abi.h: RFWHIP_KAT_*)
+RT_FN void kat_item(const Params &p, int function, const float *in, float *out, uint32_t i, float *pot_cache)
+{
+	const float *r = in + (size_t)i * KAT_IN;
+	float *o = out + (size_t)i * KAT_OUT;
+	for (int k = 0; k < KAT_OUT; k++)
+		o[k] = 0.0f;
+	Shading sd;
+	sd.color = mk3(r[0], r[1], r[2]), sd.absorption = mk3(r[3], r[4], r[5]);
+	sd.p0 = fbits(r[6]), sd.p1 = fbits(r[7]), sd.p2 = fbits(r[8]);
+	const f3 N = mk3(r[9], r[10], r[11]), wo = mk3(r[12], r[13], r[14]), wi = mk3(r[15], r[16], r[17]);
+	switch (function)
+	{
+	case 0: // BSDFEval
+	{
+		const f3 e = bsdf_eval(sd, N, wo, wi, r[18], fbits(r[19]) != 0u);
+		o[0] = e.x, o[1] = e.y, o[2] = e.z;
+		break;
+	}
+	case 1: // BSDFPdf
+		o[0] = bsdf_pdf(sd, N, wo, wi);
+		break;
+	case 2: // BSDFSample
+	{
+		f3 T, B, R = mk3(0, 0, 1);
+		float pdf = 0.0f;
+		create_tangent_space(N, T, B);
+		bsdf_sample(sd, T, B, N, wo, R, pdf, r[20], r[21]);
+		o[0] = R.x, o[1] = R.y, o[2] = R.z, o[3] = pdf;
+		break;
+	}
+	case 3: // createTangentSpace
+	{
+		f3 T, B;
+		create_tangent_space(N, T, B);
+		o[0] = T.x, o[1] = T.y, o[2] = T.z, o[3] = B.x, o[4] = B.y, o[5] = B.z;
+		break;
+	}
+	case 4: // PackNormal / UnpackNormal
+	{
+		const uint32_t pk = pack_normal(N);
+		const f3 u = unpack_normal(pk);
+		o[0] = ubits(pk), o[1] = u.x, o[2] = u.y, o[3] = u.z;
+		break;
+	}
+	case 5: // RandomBarycentrics
+	{
+		const f3 b = random_barycentrics(r[20]);
+		o[0] = b.x, o[1] = b.y, o[2] = b.z;
+		break;
+	}
+	case 6: // RandomPointOnLight
+	{
+		float pick = 0, pdf = 0;
+		f3 col = mk3(0, 0, 0);
+		const f3 P = random_point_on_light(p.sc, r[6], r[7], mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), pick, pdf, col, pot_cache);
+		o[0] = P.x, o[1] = P.y, o[2] = P.z, o[3] = pick, o[4] = pdf, o[5] = col.x, o[6] = col.y, o[7] = col.z;
+		break;
+	}
+	case 7: // LightPickProb
+		o[0] = light_pick_prob(p.sc, (int)fbits(r[8]), mk3(r[9], r[10], r[11]), mk3(r[3], r[4], r[5]), mk3(r[0], r[1], r[2]));
+		break;
+	case 8: // blueNoiseSampler
+		o[0] = p.cam.blue_noise ? blue_noise_sample(p.cam.blue_noise, (int)fbits(r[0]), (int)fbits(r[1]), (int)fbits(r[2]), (int)fbits(r[3])) : -1.0f;
+		break;
+	case 9: // WangHash, RandomFloat
+	{
+		uint32_t st = wang_hash(fbits(r[0]));
+		o[0] = ubits(st);
+		o[1] = random_float(st);
+		o[2] = ubits(st);
+		break;
+	}
+	default:
+		break;
+	}
+}
+
+// CUDART/src/Context.cpp:109: the connections of shade call d are traced only if depth d + 1 has extension rays
+// (`while (activePaths > 0 && ...)`); evaluated on the device, per wavefront batch — no host read-back.
+RT_FN uint32_t connection_count(const WaveCounters *c, uint32_t depth)
+{
+	return c->ext[depth + 1] ? c->shadow[depth] : 0u;
+}
+
 RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
 {
 	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
@@ -624,9 +710,11 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, ANY ? RT_ANY_WAVES : RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
 {
-	RT_STACK_DECL_(ANY ? LDS_STACK_ANY : LDS_STACK)
 	WaveCounters *const wc = p.wv.counters;
-	const uint32_t count = ANY ? wc->shadow[p.depth] : wc->ext[p.depth];
+	const uint32_t count = ANY ? connection_count(wc, p.depth) : wc->ext[p.depth];
+	if (count == 0u)
+		return;
+	RT_STACK_DECL_(ANY ? LDS_STACK_ANY : LDS_STACK)
 	uint32_t *const head = &wc->work[p.queue][0];
 	const uint32_t b = p.depth & 1u;
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
@@ -779,8 +867,10 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 template <bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_ANY_WAVES) k_connect(const Params p)
 {
+	const uint32_t count = connection_count(p.wv.counters, p.depth);
+	if (count == 0u)
+		return;
 	RT_STACK_DECL_ANY
-	const uint32_t count = p.wv.counters->shadow[p.depth];
 	ChunkQueue w(p, count);
 	uint32_t c;
 	while (w.next(c))
@@ -811,6 +901,19 @@ __global__ void __launch_bounds__(BLOCK) k_deinterleave(const f4 *gathered, f4 *
 	const uint32_t n = W * H;
 	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
 		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_kat(const Params p, int function, const float *in, float *out, uint32_t n)
+{
+	__shared__ float s_pot[POT_CACHE * BLOCK];
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n)
+		kat_item(p, function, in, out, i, s_pot + threadIdx.x);
+}
+void launch_kat(const Params &p, int function, const float *in, float *out, uint32_t n, stream_t s)
+{
+	if (n)
+		hipLaunchKernelGGL(k_kat, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, p, function, in, out, n);
 }
 
 __global__ void k_init_counters(WaveCounters *c, uint32_t primary_count)
@@ -1118,7 +1221,7 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)
 {
 	Ctx ctx(p);
-	const uint32_t n = p.wv.counters->shadow[p.depth];
+	const uint32_t n = connection_count(p.wv.counters, p.depth);
 	for (uint32_t i = 0; i < n; i++)
 		count ? connect_item<true>(p, i, true, ctx) : connect_item<false>(p, i, true, ctx);
 }
@@ -1136,6 +1239,12 @@ void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, ui
 {
 	for (uint32_t i = 0; i < W * H; i++)
 		deinterleave_item(gathered, out, W, H, local_rows, world, i);
+}
+void launch_kat(const Params &p, int function, const float *in, float *out, uint32_t n, stream_t)
+{
+	float pot[POT_CACHE];
+	for (uint32_t i = 0; i < n; i++)
+		kat_item(p, function, in, out, i, pot);
 }
 void launch_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const uint32_t *joints4,
 						  const f4 *weights4, const float *mats, uint32_t joint_count, uint32_t vertex_count, stream_t)

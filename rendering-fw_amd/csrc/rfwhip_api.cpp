@@ -1517,7 +1517,9 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				StageTimer ts(c, KF_SHADE, -1, s);
 				rtk::launch_shade_pt(p, n, s);
 				ts.stop();
-				if (total_light_count(c))
+				// the connections of the last shade call are never traced (CUDART/src/Context.cpp:109-120): the shade
+				// kernel does not emit them, and no wave is launched for them
+				if (total_light_count(c) && d < c->max_depth)
 				{
 					p.group = 16u, p.queue = queue++;
 					StageTimer tc(c, KF_CONNECT, -1, s);
@@ -1548,15 +1550,23 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 {
 	CTX_ENTER(c);
 	RF_TRY(sync_all(c));
-	// wave counters of the last frame, summed over its sub-batches
+	// wave counters of the last frame, summed over its sub-batches.  A sub-batch's connection wave of depth d ran only
+	// if its depth d + 1 had extension rays (k_connect / k_trace_stream: connection_count)
 	rt::WaveCounters wc;
 	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	for (int d = 0; d + 1 < rt::MAX_DEPTH_SLOTS; d++)
+		if (!wc.ext[d + 1])
+			wc.shadow[d] = 0;
 	for (int i = 1; i < c->subs_last; i++)
 	{
 		rt::WaveCounters w2;
 		RF_TRY(dm::d2h(&w2, c->d_counters_sub[i].p, sizeof(w2), c->stream));
 		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
-			wc.ext[d] += w2.ext[d], wc.shadow[d] += w2.shadow[d];
+		{
+			wc.ext[d] += w2.ext[d];
+			if (d + 1 < rt::MAX_DEPTH_SLOTS && w2.ext[d + 1])
+				wc.shadow[d] += w2.shadow[d];
+		}
 	}
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
@@ -2012,6 +2022,43 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 			inst[i] = pr >= 0 ? hi[i] : -1;
 	}
 	return RFWHIP_OK;
+}
+
+static_assert(RFWHIP_KAT_IN == 24 && RFWHIP_KAT_OUT == 8, "kat_item's record layout (kernels.hip)");
+extern "C" int rfwhip_kat(rfwhip_context *c, int function, size_t n, const float *in, float *out)
+{
+	CTX_ENTER(c);
+	if (n && (!in || !out))
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: null records");
+	if (function < 0 || function > RFWHIP_KAT_HASH)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: unknown function %d", function);
+	if ((function == RFWHIP_KAT_POINT_ON_LIGHT || function == RFWHIP_KAT_LIGHT_PICK_PROB) && c->scene_dirty)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_kat: the light functions use the lights of the last rfwhip_update()");
+	if (function == RFWHIP_KAT_BLUE_NOISE && !c->have_blue_noise)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_kat: no blue-noise table (rfwhip_set_blue_noise)");
+	if (n == 0)
+		return RFWHIP_OK;
+	if (n >= (1ull << 31))
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_kat: too many records");
+	RF_TRY(sync_all(c));
+	DevBuf d_in, d_out;
+	int rc = d_in.ensure(n * RFWHIP_KAT_IN * sizeof(float));
+	if (!rc)
+		rc = d_out.ensure(n * RFWHIP_KAT_OUT * sizeof(float));
+	if (!rc)
+		rc = dm::h2d(d_in.p, in, n * RFWHIP_KAT_IN * sizeof(float), c->stream);
+	if (!rc)
+	{
+		rtk::Params p;
+		fill_params(c, nullptr, p);
+		p.cam.blue_noise = c->have_blue_noise ? c->d_blue_noise.as<uint32_t>() : nullptr;
+		rtk::launch_kat(p, function, d_in.as<float>(), d_out.as<float>(), (uint32_t)n, c->stream);
+		rc = dm::last_launch_error();
+	}
+	if (!rc)
+		rc = dm::d2h(out, d_out.p, n * RFWHIP_KAT_OUT * sizeof(float), c->stream);
+	d_in.free_(), d_out.free_();
+	return rc;
 }
 
 extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap,

@@ -1359,6 +1359,7 @@ struct PathIn
 	float bsdfPdf;
 	uint32_t slot, flags, packedN;
 	uint32_t pixel;		// global pixel id y*W + x (RNG key)
+	uint32_t px, py;	// the same pixel as coordinates (blue-noise tile lookup)
 	uint32_t sampleIdx; // global sample index (RNG key)
 	uint32_t depth;		// pathLength
 };
@@ -1507,12 +1508,21 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	iN = iN * flip;
 	T = T * (1.0f / in.bsdfPdf);
 	const f3 wo = D * -1.0f;
-	// next-event estimation: Kernels.cu:702-755
-	if ((flags & 1u) == 0 && total_lights(sc) > 0)
+	// next-event estimation: Kernels.cu:702-755.  The connections of a shade call are traced by the NEXT iteration of the
+	// reference's host loop (CUDART/src/Context.cpp:109-120), so those of the last call (depth == max_depth) never are:
+	// they are not even computed here (the two random numbers they would consume are followed by no other draw).
+	if ((flags & 1u) == 0 && total_lights(sc) > 0 && in.depth < max_depth)
 	{
 		f3 lightColor = mk3(0, 0, 0);
 		float pickProb = 0, lightPdf = 0;
-		const float q0 = random_float(seed), q1 = random_float(seed);
+		float q0, q1;
+		if (cam.blue_noise && in.sampleIdx < 256u) // BLUENOISE (Kernels.cu:712-719): the hash seed is not advanced
+		{
+			q0 = blue_noise_sample(cam.blue_noise, (int)in.px, (int)in.py, (int)in.sampleIdx, 4);
+			q1 = blue_noise_sample(cam.blue_noise, (int)in.px, (int)in.py, (int)in.sampleIdx, 5);
+		}
+		else
+			q0 = random_float(seed), q1 = random_float(seed);
 		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache) - I;
 		const float dist = length(L);
 		L = L * (1.0f / dist);

@@ -1,0 +1,16 @@
+"""Scenes of the committed golden vectors (tests/golden/make_golden_pt.py) — shared by the generator and the tests, so both
+sides render exactly the same description."""
+
+
+def cornell_pt(pkg, W=96, H=64):
+    """Cornell room, emissive quad as geometry (area lights derived like rfw::system does) + one point light."""
+    return pkg.scenes.cornell(W, H, geometric_emitter=True, point_light=True)
+
+
+def cornell_lights(pkg, W=96, H=64):
+    """The same room lit by every light type of lights.h: 2 area triangles, a point, a spot and a directional light."""
+    s = pkg.scenes.cornell(W, H, geometric_emitter=True, point_light=True)
+    s.name = "cornell_lights"
+    s.add_spot_light((2.5, 8.5, -2.0), 18.0, (60.0, 40.0, 30.0), 32.0, (-0.35, -1.0, 0.45))
+    s.add_directional_light((0.3, -1.0, 0.6), (1.5, 1.6, 2.0))
+    return s

@@ -1,0 +1,215 @@
+"""The path-tracing integrator against the INDEPENDENT numpy restatement of the reference (tests/golden/make_golden_pt.py:
+written from bsdf/disney.h, bsdf/tools.h, CUDART/src/lights.h, getShadingData.h, Kernels.cu:383-794 and
+CUDART/src/Context.cpp:65-159, brute force, no BVH).  Three implementations are held against its committed outputs:
+
+  * the C oracle (CPU tier)                 — pins the checker every other pt parity test uses,
+  * the host-emulation build of rt_core.h   — the product's shade arithmetic without a GPU (CPU tier),
+  * the HIP kernels through the C ABI       — `-m gpu`.
+
+Known answers (pt_kat.npz): BSDFEval / BSDFPdf / BSDFSample, createTangentSpace, PackNormal / UnpackNormal, RandomBarycentrics,
+RandomPointOnLight, LightPickProb, WangHash / RandomFloat, and blueNoiseSampler on the reference's REAL table (through
+oracle/_ref/libbluenoise.so, a build of the reference's blue_noise.h).  Images: Cornell 96x64, 4 spp, depth 2, with the
+per-depth wave counts of every sample.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, image_stats
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import golden_scenes  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KAT = np.load(os.path.join(GOLD, "pt_kat.npz"))
+REF_BLUE_NOISE = os.path.join(ROOT, "oracle", "_ref", "libbluenoise.so")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).astype(np.uint32).view(np.float32)
+
+
+def bsdf_records():
+    n = len(KAT["bsdf_t"])
+    r = np.zeros((n, 24), np.float32)
+    r[:, 0:3], r[:, 3:6] = KAT["bsdf_color"], KAT["bsdf_absorption"]
+    r[:, 6:9] = KAT["bsdf_params"][:, :3].astype(np.uint32).view(np.float32)
+    r[:, 9:12], r[:, 12:15], r[:, 15:18] = KAT["bsdf_N"], KAT["bsdf_wo"], KAT["bsdf_wi"]
+    r[:, 18] = KAT["bsdf_t"]
+    r[:, 19] = bits(KAT["bsdf_backfacing"])
+    r[:, 20], r[:, 21] = KAT["sample_r3"], KAT["sample_r4"]
+    return r
+
+
+def light_records():
+    n = len(KAT["light_r0"])
+    r = np.zeros((n, 24), np.float32)
+    r[:, 0:3], r[:, 3:6] = KAT["light_I"], KAT["light_N"]
+    r[:, 6], r[:, 7] = KAT["light_r0"], KAT["light_r1"]
+    r[:, 8] = bits(KAT["pickprob_idx"])
+    r[:, 9:12] = KAT["pickprob_O"]
+    return r
+
+
+def close(a, b, rtol, atol, what, allow=0.0):
+    """|a - b| <= atol + rtol |b| on all but a fraction `allow` of the entries (discrete branches right at a threshold)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    bad = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
+    bad &= ~(np.isnan(a) & np.isnan(b))
+    assert bad.mean() <= allow, "%s: %d of %d entries differ, worst %g" % (what, bad.sum(), bad.size, np.nanmax(np.abs(a - b)[bad]))
+
+
+def check_kat(ctx, pkg, rtol, have_table):
+    """Every known-answer table against one implementation (ctx.kat = rfwhip_kat / rfwo_kat).  rtol: the worst relative
+    error of well-conditioned fp32 code with fused multiply-adds against numpy's unfused float32 is a few 1e-5 here
+    (cancellation in 1 + (a^2 - 1) cos^2 at grazing angles amplifies the last-bit differences)."""
+    rec = bsdf_records()
+    close(ctx.kat("bsdf_eval", rec)[:, :3], KAT["bsdf_eval"], rtol, 1e-6, "BSDFEval")
+    close(ctx.kat("bsdf_pdf", rec)[:, 0], KAT["bsdf_pdf"], rtol, 1e-7, "BSDFPdf")
+    s = ctx.kat("bsdf_sample", rec)
+    # a sample lands in another lobe when r3 / r4 sit within an ulp of a branch threshold: at most a handful of records
+    close(s[:, :3], KAT["sample_wi"], 10 * rtol, 2e-5, "BSDFSample wi", allow=0.01)
+    close(s[:, 3], KAT["sample_pdf"], 20 * rtol, 1e-6, "BSDFSample pdf", allow=0.01)
+    t = ctx.kat("tangent_space", rec)
+    close(t[:, :3], KAT["tangent_T"], rtol, 1e-6, "createTangentSpace T")
+    close(t[:, 3:6], KAT["tangent_B"], rtol, 1e-6, "createTangentSpace B")
+    pk = ctx.kat("pack_normal", rec)
+    packed = pk[:, 0].copy().view(np.uint32)
+    # the two 16-bit halves are floor()s of float expressions: one unit apart at most, and only rarely
+    dlo = np.abs((packed & 65535).astype(np.int64) - (KAT["pack_out"] & 65535).astype(np.int64))
+    dhi = np.abs((packed >> 16).astype(np.int64) - (KAT["pack_out"] >> 16).astype(np.int64))
+    assert dlo.max() <= 1 and dhi.max() <= 1 and ((dlo + dhi) > 0).mean() < 0.02
+    close(pk[:, 1:4], KAT["unpack_out"], 0, 1e-4, "UnpackNormal(PackNormal)")
+    rb = np.zeros((len(KAT["bary_r0"]), 24), np.float32)
+    rb[:, 20] = KAT["bary_r0"]
+    close(ctx.kat("random_barycentrics", rb)[:, :3], KAT["bary_out"], 0, 1e-6, "RandomBarycentrics")
+    rh = np.zeros((len(KAT["hash_in"]), 24), np.float32)
+    rh[:, 0] = bits(KAT["hash_in"])
+    h = ctx.kat("hash", rh)
+    assert (h[:, 0].copy().view(np.uint32) == KAT["wang_hash"]).all()
+    assert (h[:, 2].copy().view(np.uint32) == KAT["random_state"]).all()
+    assert (h[:, 1] == KAT["random_float"]).all()
+    # light functions on the light set of the "lights" golden scene
+    scene = golden_scenes.cornell_lights(pkg, 96, 64)
+    ctx.init(96, 64)
+    scene.upload(ctx)
+    lr = light_records()
+    pl = ctx.kat("point_on_light", lr)
+    # the picked light changes when r1 * sum sits within an ulp of a partial sum
+    close(pl[:, :3], KAT["light_P"], rtol, 2e-5, "RandomPointOnLight P", allow=0.01)
+    close(pl[:, 3], KAT["light_pick"], 20 * rtol, 1e-6, "RandomPointOnLight pickProb", allow=0.01)
+    close(pl[:, 4], KAT["light_pdf"], 20 * rtol, 1e-6, "RandomPointOnLight lightPdf", allow=0.01)
+    close(pl[:, 5:8], KAT["light_color"], 0, 1e-6, "RandomPointOnLight colour", allow=0.01)
+    close(ctx.kat("light_pick_prob", lr)[:, 0], KAT["pickprob"], 20 * rtol, 1e-6, "LightPickProb")
+    if have_table:
+        ctx.set_blue_noise(reference_blue_noise())
+        rn = np.zeros((len(KAT["bn_x"]), 24), np.float32)
+        for k, name in enumerate(("bn_x", "bn_y", "bn_sample", "bn_dim")):
+            rn[:, k] = bits(KAT[name])
+        assert (ctx.kat("blue_noise", rn)[:, 0] == KAT["bn_value"]).all()
+
+
+def reference_blue_noise():
+    """The reference's createBlueNoiseBuffer() output (oracle/_ref/libbluenoise.so: a build of blue_noise.h itself)."""
+    if not os.path.exists(REF_BLUE_NOISE):
+        pytest.skip("oracle/_ref/libbluenoise.so absent (built from /root/reference by `make -C oracle ref`)")
+    lib = ctypes.CDLL(REF_BLUE_NOISE)
+    lib.rfw_ref_blue_noise_table.restype = ctypes.POINTER(ctypes.c_uint32)
+    return np.ctypeslib.as_array(lib.rfw_ref_blue_noise_table(), shape=(5 * 65536,)).copy()
+
+
+def render_golden(ctx, pkg, name, settings=()):
+    """Render the golden scene `name` sample by sample; returns (sample 0 image, 4-spp image, per-sample wave counts)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    scene = (golden_scenes.cornell_lights if "lights" in name else golden_scenes.cornell_pt)(pkg, 96, 64)
+    ctx.init(96, 64)
+    if "bluenoise" in name:
+        ctx.set_blue_noise(reference_blue_noise())
+        ctx.set_setting("sampler", "bluenoise")
+    scene.upload(ctx)
+    for k, v in (("integrator", "pt"), ("spp", 1), ("max_depth", 2), ("streams", 1)) + tuple(settings):
+        ctx.set_setting(k, v)
+    counts, first = [], None
+    for s in range(int(g["spp"])):
+        ctx.render_frame(scene.camera, pkg.RESET if s == 0 else pkg.CONVERGE)
+        st = ctx.get_stats()
+        counts.append((st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount))
+        if s == 0:
+            first = ctx.framebuffer()[..., :3].copy()
+    return g, first, ctx.framebuffer()[..., :3], counts
+
+
+def check_image(g, first, img, counts, exact_first):
+    # sample 0: every discrete decision falls like the golden's => (nearly) every pixel agrees to rounding
+    d0 = np.abs(first - g["sample0"]).max(-1)
+    assert (d0 > 1e-3).mean() <= (0.0 if exact_first else 2e-3), "sample 0: %g of the pixels differ, worst %g" % ((d0 > 1e-3).mean(), d0.max())
+    frac, rmse, d = image_stats(img, g["image"], 1e-3)
+    assert frac <= 2e-3, "4 spp: %g of the pixels differ (rmse %g)" % (frac, rmse)
+    # wave sizes per sample: extension rays of depth 1 and 2, connections actually traced (depths 0 and 1)
+    for s, (pc, sc, dc, sh) in enumerate(counts):
+        want = (int(g["ext"][s][0]), int(g["ext"][s][1]), int(g["ext"][s][2]), int(g["shadow_traced"][s].sum()))
+        got = (pc, sc, dc, sh)
+        tol = (0, 2, 2, 3) if not exact_first or s else (0, 0, 0, 0)
+        assert all(abs(a - b) <= t for a, b, t in zip(got, want, tol)), "sample %d wave counts %s, golden %s" % (s, got, want)
+
+
+GOLDEN_IMAGES = ["pt_cornell96x64", "pt_lights96x64", "pt_cornell96x64_bluenoise"]
+
+
+# ---- CPU tier -------------------------------------------------------------------------------------------------------
+def test_oracle_known_answers(pkg, make_oracle):
+    check_kat(make_oracle(), pkg, 1e-4, os.path.exists(REF_BLUE_NOISE))
+
+
+def test_emulation_known_answers(pkg, make_emu):
+    check_kat(make_emu(), pkg, 1e-4, os.path.exists(REF_BLUE_NOISE))
+
+
+@pytest.mark.parametrize("name", GOLDEN_IMAGES)
+def test_oracle_reproduces_the_independent_path_tracer(pkg, make_oracle, name):
+    check_image(*render_golden(make_oracle(), pkg, name), exact_first=True)
+
+
+@pytest.mark.parametrize("name", GOLDEN_IMAGES)
+def test_emulation_reproduces_the_independent_path_tracer(pkg, make_emu, name):
+    check_image(*render_golden(make_emu(), pkg, name), exact_first=True)
+
+
+def test_blue_noise_table_is_the_references(pkg):
+    """crc32 of the three byte tables of blue_noise.h as SURVEY §2 records them."""
+    import zlib
+    t = reference_blue_noise()
+    crc = [zlib.crc32(t[a:b].astype(np.uint8).tobytes()) & 0xFFFFFFFF for a, b in ((0, 65536), (65536, 196608), (196608, 327680))]
+    assert crc == [0xd87313bd, 0x12b18559, 0x24c59e1f] and (np.asarray(crc, np.uint32) == KAT["bn_crc32"]).all()
+    assert int(t.astype(np.uint64).sum()) == int(KAT["bn_table_sum"])
+
+
+# ---- GPU tier: the HIP kernels through the C ABI ----------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_known_answers(pkg, make_hip):
+    # v_sin / v_cos / v_rcp / v_log are 1-2 ulp instructions: a little more slack than libm on the host
+    check_kat(make_hip(), pkg, 3e-4, os.path.exists(REF_BLUE_NOISE))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLDEN_IMAGES)
+def test_hip_reproduces_the_independent_path_tracer(pkg, make_hip, name):
+    check_image(*render_golden(make_hip(), pkg, name), exact_first=False)
+
+
+@pytest.mark.gpu
+def test_hip_golden_image_is_independent_of_the_launch_shape(pkg, make_hip):
+    """Same golden scene as one 4-spp batch on 4 concurrent sub-batches: bit-identical to sample-by-sample rendering."""
+    g, _, ref, _ = render_golden(make_hip(), pkg, "pt_cornell96x64")
+    ctx = make_hip()
+    scene = golden_scenes.cornell_pt(pkg, 96, 64)
+    ctx.init(96, 64)
+    scene.upload(ctx)
+    for k, v in (("integrator", "pt"), ("spp", 4), ("max_depth", 2), ("streams", 4)):
+        ctx.set_setting(k, v)
+    ctx.render_frame(scene.camera, pkg.RESET)
+    img = ctx.framebuffer()[..., :3]
+    assert np.abs(img - ref).max() <= 1e-6
