@@ -177,20 +177,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    try:
-        for k in range(args.warmup):
-            step(k, k == 0)
-        fence()
-    except Exception as e:  # noqa: BLE001
-        if not (world > 1 and args.pipeline):
-            raise
-        # the stream-ordered gather is the only part of this file a 1-GPU box cannot rehearse with RCCL: fall back to
-        # the host-synchronous step rather than lose the run (every rank sees the same exception or none)
-        print("bench.py: stream-ordered step failed (%s); continuing with --pipeline 0" % e, file=sys.stderr)
-        args.pipeline = 0
-        for k in range(max(1, args.warmup)):
-            step(k, k == 0)
-        fence()
+    # no protocol fallback: a failing stream-ordered step fails the run (--pipeline 0 selects the host-synchronous step
+    # explicitly, and config.pipeline records which one ran)
+    for k in range(args.warmup):
+        step(k, k == 0)
+    fence()
     for name in ctx.KERNELS:
         ctx.get_kernel_time(name, reset=True)
     del gather_ms[:]
@@ -281,7 +272,7 @@ def main():
         ctx.set_setting("spp", args.spp)
 
     # ---- CPU baseline: the oracle (a port, not the reference build) on this box's host cores ----------------------------
-    cpu_baseline = None
+    cpu_baseline, parity = None, None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from __graft_entry__ import load_oracle
         orc = load_oracle()
@@ -306,8 +297,20 @@ def main():
                         "sample": "%d full %dx%d frame(s) at 1 spp of the same scene/camera/integrator (%s, depth %d), "
                                   "oracle/rfw_oracle.c with OpenMP, %.1f s; oracle BVH build %.1f s not timed"
                                   % (done, W, H, args.integrator, args.max_depth, spent, t_build)}
-        # cross-check while both are here: same first sample => images agree (oracle = checker, not the thing measured)
+        # cross-check while both are here (outside every timed region; the oracle is the checker, not the thing measured):
+        # the oracle has just accumulated sample indices 0..done-1 of this very scene — render the same indices on the GPU
+        ref_img = ref.framebuffer()[..., :3]
         ref.destroy()
+        ctx.set_setting("spp", done)
+        ctx.set_setting("stage_timing", 0)
+        ctx.render_frame(scene.camera, pkg.RESET)
+        hip_img = ctx.framebuffer()[..., :3]
+        ctx.set_setting("spp", args.spp)
+        dist = np.sqrt(((hip_img.astype(np.float64) - ref_img) ** 2).sum(-1))
+        parity = {"samples_per_pixel": done, "tolerance": 3e-2, "frac_gt_3e-2": round(float((dist > 3e-2).mean()), 6),
+                  "rmse": round(float(np.sqrt((dist ** 2).mean())), 6),
+                  "mean_rel": round(float(abs(hip_img.mean() - ref_img.mean()) / ref_img.mean()), 7),
+                  "hip_mean": float(hip_img.mean()), "oracle_mean": float(ref_img.mean())}
 
     if rank == 0:
         out = {
@@ -320,10 +323,14 @@ def main():
                                    "triangles + %d point lights, synthetic 2048x1024 HDR sky"
                                    % (scene.name, scene.triangle_count(), W, H, args.integrator, args.max_depth, args.spp,
                                       len(scene.area_lights), len(scene.point_lights)),
-                       "parallelism": "image strips of 8 rows interleaved over %d rank(s), one RCCL gather per step%s"
-                                      % (world, " (stream-ordered, overlapping the next step)" if (world > 1 and args.pipeline) else ""),
+                       "parallelism": ("single GPU, no collective" if world == 1 else
+                                       "image strips of 8 rows interleaved over %d ranks, one RCCL gather per step%s"
+                                       % (world, " (stream-ordered, overlapping the next step)" if args.pipeline else " (host-synchronous)")),
+                       "pipeline": int(args.pipeline) if world > 1 else None,
                        "spp_per_step": args.spp, "streams": args.streams},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            # per-pixel RGB L2 between the GPU image and the oracle image of the same sample indices (None when the CPU leg is off)
+            "parity_vs_cpu_baseline": parity,
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_times.items()},
             "last_frame_counts": {k: stats[k] for k in ("primaryCount", "secondaryCount", "deepCount", "shadowCount")},
             # rays of one step (this rank's strips) over the step time: closest-hit (primary + extension) and any-hit

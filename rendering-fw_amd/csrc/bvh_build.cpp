@@ -391,4 +391,29 @@ bool collapse4(const Result &bvh2, bool tlas, std::vector<rt::Node4> &out)
 	return true;
 }
 
+int stack_need4(const std::vector<rt::Node4> &nodes4)
+{
+	if (nodes4.empty())
+		return 0;
+	// iterative walk carrying the entries pending above each node (relative entries: inner = index into nodes4)
+	std::vector<std::pair<uint32_t, int>> todo;
+	todo.push_back({0u, 0});
+	int worst = 0;
+	while (!todo.empty())
+	{
+		const auto [idx, above] = todo.back();
+		todo.pop_back();
+		const rt::Node4 &n = nodes4[idx];
+		int kids = 0;
+		for (int k = 0; k < 4; k++)
+			kids += n.entry[k] != rt::ENTRY_EMPTY;
+		const int here = above + (kids > 0 ? kids - 1 : 0);
+		worst = here > worst ? here : worst;
+		for (int k = 0; k < 4; k++)
+			if (n.entry[k] != rt::ENTRY_EMPTY && !(n.entry[k] & rt::ENTRY_LEAF))
+				todo.push_back({n.entry[k] & rt::ENTRY_INDEX_MASK, here});
+	}
+	return worst;
+}
+
 } // namespace bvh

@@ -27,4 +27,9 @@ void build(const float *bmin, const float *bmax, size_t n, int max_leaf, int dep
 // sets ENTRY_TLAS on every entry.  Returns false when the root itself is a leaf (no 4-wide node needed).
 bool collapse4(const Result &bvh2, bool tlas, std::vector<rt::Node4> &out);
 
+// Worst-case number of traversal-stack entries a ray can hold while walking this 4-wide tree: the maximum over root-to-leaf
+// paths of the sum of (children - 1) over the nodes on the path (every visit pushes at most the children it does not
+// descend into; a leaf entry in hand is not on the stack).  0 for an empty tree.
+int stack_need4(const std::vector<rt::Node4> &nodes4);
+
 } // namespace bvh

@@ -10,13 +10,14 @@
 //
 // CDNA4 specifics:
 //   * one wave64 = one 8x8 pixel tile of the primary wave; a 256-thread workgroup = 4 tiles;
-//   * the traversal stack lives in LDS as stack[entry][thread] (bank = thread % 32: conflict-free), 24 entries per
-//     lane, with a private-memory spill that ordinary rays never reach;
+//   * the traversal stack lives in LDS as stack[entry][thread] (bank = thread % 32: conflict-free), 12 entries per lane
+//     in the closest-hit kernels and 8 in the occlusion kernels, with a private-memory spill behind it that ordinary rays
+//     never reach; the top of the largest BLAS (128 4-wide nodes) is staged in LDS by every workgroup;
 //   * stream compaction uses one __ballot + mbcnt prefix and ONE atomicAdd per wave (the reference issues one
 //     atomicAdd per surviving thread, CUDART/src/Kernels.cu:640,747,788);
-//   * persistent grids: blocks = CUs x 8 grid-stride over 256-ray chunks, and the chunk order is XCD-aware — block b
-//     runs on XCD b % 8, so XCD x walks the contiguous chunk range [x*n/8, (x+1)*n/8): neighbouring tiles (which
-//     share BVH nodes and triangles) meet in the same 4 MiB L2;
+//   * persistent grids of 8..32 workgroups per CU (by launch size) pulling 256-ray chunks from per-XCD queues: chunks
+//     are dealt to the 8 XCDs in groups of one tile row, workgroup b (which runs on XCD b % 8) pulls consecutive chunks of
+//     its XCD's sequence, so neighbouring tiles (which share BVH nodes and triangles) meet in the same 4 MiB L2;
 //   * wave counts come from device-side counters; the host never reads a counter between bounces
 //     (contrast CUDART/src/Context.cpp:98,145).
 // No MFMA: the path is divergent pointer chasing, bounded by memory latency/bandwidth.
@@ -91,9 +92,11 @@ struct Ctx
 	uint32_t lds[LDS_STACK_MAX], spill[SPILL_STACK];
 	float potbuf[POT_CACHE];
 	float *pot;
-	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0; }
+	uint32_t overflow_sink = 0;
+	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0, stk.overflow = &overflow_sink; }
 	explicit Ctx(const Params &p) : Ctx()
 	{
+		stk.overflow = &p.wv.counters->stack_overflow;
 		// emulation: the "LDS" rows alias the node table (TOP_ROWS = 8), the range check is the device's
 		stk.top = (const f4 *)(p.sc.nodes4 + p.lds_first), stk.top_first = p.lds_first, stk.top_count = p.lds_count;
 	}
@@ -425,6 +428,7 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
 			c->work[q][x] = 0u;
 	c->ext[0] = primary_count;
 	c->probe_valid = 0u;
+	c->stack_overflow = 0u;
 }
 
 RT_FN uint32_t local_pixel_to_slot(const FrameView &fr, uint32_t x, uint32_t yl)
@@ -652,7 +656,8 @@ static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of
 	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
 	ctx.stk.spill = spill_;                                                                 \
 	stage_top(p, s_top);                                                                    \
-	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;
+	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;            \
+	ctx.stk.overflow = &p.wv.counters->stack_overflow;
 #define RT_STACK_DECL_CLOSEST RT_STACK_DECL_(LDS_STACK)
 #define RT_STACK_DECL_ANY RT_STACK_DECL_(LDS_STACK_ANY)
 
@@ -805,6 +810,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 	__shared__ float s_pot[POT_CACHE * BLOCK];
 	Ctx ctx;
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
+	ctx.stk.overflow = nullptr;
 	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;

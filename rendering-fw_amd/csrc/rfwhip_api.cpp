@@ -165,6 +165,11 @@ static int stream_wait_event(void *s, event_t e)
 	DM_CHECK(hipStreamWaitEvent((hipStream_t)s, e, 0));
 	return 0;
 }
+static int event_sync(event_t e)
+{
+	DM_CHECK(hipEventSynchronize(e));
+	return 0;
+}
 #else
 // ---- host emulation (tests/emu): plain heap memory, "streams" are immediate ----
 static int init(int, int *cus)
@@ -217,6 +222,7 @@ static int event_record(event_t &e, void *)
 }
 static float event_ms(event_t a, event_t b) { return std::chrono::duration<float, std::milli>(b - a).count(); }
 static int stream_wait_event(void *, event_t) { return 0; }
+static int event_sync(event_t) { return 0; }
 #endif
 } // namespace dm
 
@@ -269,6 +275,8 @@ struct MeshRec
 	DevBuf d_verts, d_indices;		   // raw vertices / indices (kept for refit)
 	DevBuf d_parents, d_flags;		   // refit helpers
 	uint32_t node_base = 0, tri_base = 0, shade_base = 0;
+	int stack_need = 0;		   // worst-case traversal-stack entries of the 4-wide tree (bvh::stack_need4)
+	uint32_t max_material = 0; // largest material id any triangle refers to
 	bool resident = false; // placed in the global arrays by the last update()
 	bool dirty = true;	   // host staging newer than the global arrays
 	bool refit_pending = false;
@@ -498,7 +506,14 @@ extern "C" int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_con
 static void free_all(rfwhip_context *c)
 {
 	for (auto &m : c->meshes)
-		m.d_verts.free_(), m.d_indices.free_(), m.d_parents.free_(), m.d_flags.free_();
+	{
+		DevBuf *mb[] = {&m.d_verts, &m.d_indices, &m.d_parents, &m.d_flags, &m.d_base_verts, &m.d_base_normals, &m.d_joints,
+						&m.d_weights, &m.d_vnormals, &m.d_joint_mats};
+		for (DevBuf *b : mb)
+			b->free_();
+	}
+	c->d_lbvh_scratch.free_(), c->d_lbvh_nodes.free_(), c->d_lbvh_tri_verts.free_(), c->d_blue_noise.free_();
+	c->have_blue_noise = false;
 	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
@@ -537,7 +552,7 @@ extern "C" int rfwhip_cleanup(rfwhip_context *c)
 		return RFWHIP_OK; // the reference calls cleanup() twice on unload
 	dm::use(c->device);
 	if (c->stream)
-		dm::sync(c->stream);
+		(void)sync_all(c); // every stream of the context and a present still pending on a caller's stream
 	free_all(c);
 	c->meshes.clear(), c->instances.clear();
 	c->cleaned = true;
@@ -686,6 +701,7 @@ extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *ma
 static void fill_shade_records(MeshRec &m, const rfwhip_triangle *tris)
 {
 	m.shade.resize(m.triCount);
+	m.max_material = 0;
 	for (size_t i = 0; i < m.triCount; i++)
 	{
 		const rfwhip_triangle &t = tris[i];
@@ -698,6 +714,7 @@ static void fill_shade_records(MeshRec &m, const rfwhip_triangle *tris)
 		s.tu = f4{t.u0, t.u1, t.u2, lt};
 		s.tv = f4{t.v0, t.v1, t.v2, mt};
 		s.ex = f4{t.area, t.LOD, 0.0f, 0.0f};
+		m.max_material = std::max(m.max_material, t.material);
 	}
 }
 
@@ -713,8 +730,16 @@ static inline void tri_indices(const rfwhip_mesh *mesh, size_t i, uint32_t &a, u
 #define RT_MAX_LEAF 4
 #endif
 constexpr int BLAS_MAX_LEAF = RT_MAX_LEAF; // triangles per leaf (<= rt::MAX_LEAF_PRIMS = 8)
-constexpr int BLAS_DEPTH_LIMIT = 42;
-constexpr int TLAS_DEPTH_LIMIT = 20; // + 1 sentinel; the traversal stack holds LDS_STACK(_ANY) + SPILL_STACK >= 48 entries
+// Traversal-stack budget (rt::STACK_CAPACITY entries per ray in every traversal kernel): a 4-wide node pushes at most 3
+// entries and spans at least 2 BVH2 levels when it does, so a root-to-leaf path needs <= 1.5 entries per BVH2 level.
+// The depth limits make the budgets hold by construction for the host builder (32 levels -> <= 48 entries, as deep as the
+// reference's MAX_DEPTH, bvh_node.h:56-81; 14 levels -> <= 21 entries for the TLAS), and the exact need of every tree
+// (bvh::stack_need4) is checked against them: BLAS + TLAS + 1 sentinel <= STACK_CAPACITY.
+constexpr int BLAS_DEPTH_LIMIT = 32;
+constexpr int TLAS_DEPTH_LIMIT = 14;
+constexpr int BLAS_STACK_BUDGET = 48;
+constexpr int TLAS_STACK_BUDGET = rt::STACK_CAPACITY - 1 - BLAS_STACK_BUDGET;
+static_assert(TLAS_STACK_BUDGET >= (3 * TLAS_DEPTH_LIMIT) / 2 && BLAS_STACK_BUDGET >= (3 * BLAS_DEPTH_LIMIT) / 2, "traversal stack too small for the builders' depth limits");
 
 extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mesh *mesh)
 {
@@ -799,7 +824,10 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		c->scene_dirty = true; // instance boxes change: the TLAS is rebuilt in update()
 		return RFWHIP_OK;
 	}
-	// (re)build
+	// (re)build.  From here on the record no longer describes what sits in the scene-wide arrays: whatever fails below, the
+	// next set_mesh must not take the refit path and the next update must place the mesh again.
+	m.dirty = true, m.resident = false;
+	c->scene_dirty = true;
 	const size_t n = mesh->triangleCount;
 	bool device_built = false;
 	if (c->builder == 1 && n > LBVH_CHUNK)
@@ -865,7 +893,13 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 			}
 			m.bvh.max_depth = deepest;
 		}
-		device_built = m.bvh.max_depth <= BLAS_DEPTH_LIMIT; // a degenerate Morton tree falls back to the host builder
+		// a Morton tree too deep for the traversal stack falls back to the host builder
+		device_built = m.bvh.max_depth <= 42;
+		if (device_built)
+		{
+			bvh::collapse4(m.bvh, false, m.n4);
+			device_built = bvh::stack_need4(m.n4) <= BLAS_STACK_BUDGET;
+		}
 	}
 	if (!device_built)
 	{
@@ -882,11 +916,14 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		}
 		bvh::build(bmin.data(), bmax.data(), n, BLAS_MAX_LEAF, BLAS_DEPTH_LIMIT, m.bvh);
 	}
-	if (m.bvh.max_depth > BLAS_DEPTH_LIMIT)
-		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: BVH depth %d exceeds the traversal stack", m.bvh.max_depth);
 	for (int a = 0; a < 3; a++)
 		m.bounds_min[a] = m.bvh.nodes[0].bmin[a], m.bounds_max[a] = m.bvh.nodes[0].bmax[a];
-	bvh::collapse4(m.bvh, false, m.n4);
+	if (!device_built) // (the device-built tree was collapsed when its stack need was checked)
+		bvh::collapse4(m.bvh, false, m.n4);
+	m.stack_need = bvh::stack_need4(m.n4);
+	if (m.stack_need > BLAS_STACK_BUDGET)
+		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: the BVH of mesh %zu needs %d traversal-stack entries (budget %d)",
+						 index, m.stack_need, BLAS_STACK_BUDGET);
 	m.leaf_verts.resize(3 * n);
 	for (size_t s = 0; s < n && !device_built; s++)
 	{
@@ -903,8 +940,6 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	RF_TRY(dm::h2d(m.d_parents.p, m.bvh.parents.data(), m.bvh.parents.size() * sizeof(int), c->stream));
 	RF_TRY(m.d_flags.ensure(m.bvh.nodes.size() * sizeof(uint32_t)));
 	RF_TRY(dm::sync(c->stream));
-	m.dirty = true, m.resident = false;
-	c->scene_dirty = true;
 	return RFWHIP_OK;
 }
 
@@ -1034,6 +1069,11 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 {
 	CTX_ENTER(c);
 	RF_TRY(sync_all(c));
+	// the shade kernels index the material table with the triangles' ids unchecked
+	for (size_t i = 0; i < c->meshes.size(); i++)
+		if (c->meshes[i].used && c->meshes[i].max_material >= c->material_count)
+			return set_error(RFWHIP_ERR_STATE, "rfwhip_update: mesh %zu refers to material %u, but %u materials are set",
+							 i, c->meshes[i].max_material, c->material_count);
 	// ---- place meshes in the global arrays (only when some mesh was rebuilt) ----
 	bool relayout = false;
 	size_t live_instances = 0;
@@ -1181,6 +1221,15 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		tprims[k] = live[tl.order[k]];
 	std::vector<rt::Node4> tl4;
 	const bool tl_inner = bvh::collapse4(tl, true, tl4);
+	{
+		const int tlas_need = bvh::stack_need4(tl4);
+		int blas_need = 0;
+		for (uint32_t i : live)
+			blas_need = std::max(blas_need, c->meshes[c->instances[i].mesh].stack_need);
+		if (tlas_need + 1 + blas_need > rt::STACK_CAPACITY)
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_update: top-level tree over %zu instances needs %d traversal-stack "
+							 "entries + 1 + %d for the deepest mesh (capacity %d)", live.size(), tlas_need, blas_need, rt::STACK_CAPACITY);
+	}
 	if (c->blas_nodes4 + tl4.size() > c->node4_capacity)
 		return set_error(RFWHIP_ERR_STATE, "internal: TLAS does not fit behind the BLAS nodes");
 	const uint32_t tlas_base = (uint32_t)c->blas_nodes4;
@@ -1368,6 +1417,13 @@ static int sync_all(rfwhip_context *c)
 	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
 		if (c->sub_stream[i])
 			RF_TRY(dm::sync(c->sub_stream[i]));
+	if (c->present_pending)
+	{
+		// a present enqueued on the CALLER's stream (rfwhip_read_local_framebuffer_stream) still reads the accumulator:
+		// resize, cleanup and the scene setters must not free or rewrite anything under it
+		RF_TRY(dm::event_sync(c->ev_present_out));
+		c->present_pending = false;
+	}
 	return 0;
 }
 
@@ -1554,6 +1610,7 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	// if its depth d + 1 had extension rays (k_connect / k_trace_stream: connection_count)
 	rt::WaveCounters wc;
 	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	uint32_t stack_overflow = wc.stack_overflow;
 	for (int d = 0; d + 1 < rt::MAX_DEPTH_SLOTS; d++)
 		if (!wc.ext[d + 1])
 			wc.shadow[d] = 0;
@@ -1561,6 +1618,7 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	{
 		rt::WaveCounters w2;
 		RF_TRY(dm::d2h(&w2, c->d_counters_sub[i].p, sizeof(w2), c->stream));
+		stack_overflow += w2.stack_overflow;
 		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
 		{
 			wc.ext[d] += w2.ext[d];
@@ -1570,6 +1628,8 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	}
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
+	if (stack_overflow)
+		return set_error(RFWHIP_ERR_STATE, "traversal stack overflow: %u entries dropped in the last frame (the image is wrong)", stack_overflow);
 	rfwhip_render_stats &st = c->stats;
 	const float anim = st.animationTime;
 	memset(&st, 0, sizeof(st));
@@ -2006,6 +2066,12 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 	std::vector<int> hi(n);
 	RF_TRY(dm::d2h(h.data(), c->d_hit.p, n * sizeof(f4), s));
 	RF_TRY(dm::d2h(hi.data(), c->d_hit_inst.p, n * 4, s));
+	{
+		rt::WaveCounters wc;
+		RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), s));
+		if (wc.stack_overflow)
+			return set_error(RFWHIP_ERR_STATE, "traversal stack overflow: %u entries dropped", wc.stack_overflow);
+	}
 	for (size_t i = 0; i < n; i++)
 	{
 		int pr;

@@ -267,19 +267,6 @@ struct TStat
 	uint32_t inner, tris;
 };
 
-// Stack entries per lane kept in LDS; deeper entries go to private memory.  Closest-hit rays stack deeper than occlusion
-// rays (which leave at their first hit), and less LDS per workgroup means more resident waves for the latter: swept
-// on MI355X, closest 16/12/8 -> 1787 / 1831 / 1808 Msamples/s, occlusion kernels alone 8 -> -9 % time.
-#ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12
-#endif
-#ifndef RT_LDS_STACK_ANY
-#define RT_LDS_STACK_ANY 8
-#endif
-constexpr int LDS_STACK = RT_LDS_STACK;			// closest-hit kernels
-constexpr int LDS_STACK_ANY = RT_LDS_STACK_ANY; // occlusion kernels
-constexpr int LDS_STACK_MAX = LDS_STACK > LDS_STACK_ANY ? LDS_STACK : LDS_STACK_ANY;
-constexpr int SPILL_STACK = 40; // further entries in private memory (touched only by pathological rays)
 #if defined(RT_DEVICE_BUILD)
 constexpr int STACK_STRIDE = 256; // = workgroup size: stack[entry][thread], bank = thread % 32, conflict-free
 #else
@@ -308,6 +295,7 @@ struct TravStack
 					 // the traversal state lets that state live in registers)
 	const f4 *top;	 // staged top-of-tree rows (TOP_ROWS per node)
 	uint32_t top_first, top_count;
+	uint32_t *overflow; // WaveCounters::stack_overflow
 };
 
 // 1/d for the slab test.  A direction component of exactly 0 (it happens: jitter r0 == 1.0f puts a ray on the image's
@@ -469,6 +457,14 @@ struct Traverser
 			stk.lds[sp * STACK_STRIDE] = e;
 		else if (sp < LDS_DEPTH + SPILL_STACK)
 			stk.spill[sp - LDS_DEPTH] = e;
+		else // cannot happen for trees rfwhip_update() accepted; counted so that it can never go unnoticed
+		{
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicAdd(stk.overflow, 1u);
+#else
+			(*stk.overflow)++;
+#endif
+		}
 		sp++;
 	}
 	// next entry from the stack; ENTRY_SENTINEL comes back like a leaf and is resolved in visit().  The common case

@@ -40,7 +40,26 @@ constexpr uint32_t ENTRY_SENTINEL = 0xFFFFFFFFu;
 constexpr uint32_t ENTRY_FIRST_MASK = 0x07FFFFFFu; // 27 bits: first primitive of a leaf
 constexpr uint32_t ENTRY_INDEX_MASK = 0x3FFFFFFFu; // 30 bits: left child of an inner node
 constexpr int MAX_LEAF_PRIMS = 8;				   // 3 bits of (count-1) in a leaf entry
-constexpr int STACK_DEPTH = 48;					   // traversal stack entries per lane (LDS)
+
+// Stack entries per lane kept in LDS; deeper entries go to private memory.  Closest-hit rays stack deeper than occlusion
+// rays (which leave at their first hit), and less LDS per workgroup means more resident waves for the latter: swept
+// on MI355X, closest 16/12/8 -> 1787 / 1831 / 1808 Msamples/s, occlusion kernels alone 8 -> -9 % time.
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12
+#endif
+#ifndef RT_LDS_STACK_ANY
+#define RT_LDS_STACK_ANY 8
+#endif
+constexpr int LDS_STACK = RT_LDS_STACK;			// closest-hit kernels
+constexpr int LDS_STACK_ANY = RT_LDS_STACK_ANY; // occlusion kernels
+constexpr int LDS_STACK_MAX = LDS_STACK > LDS_STACK_ANY ? LDS_STACK : LDS_STACK_ANY;
+constexpr int LDS_STACK_MIN = LDS_STACK < LDS_STACK_ANY ? LDS_STACK : LDS_STACK_ANY;
+// Further entries in private memory (touched only by deep or pathological rays).  Capacity = LDS part + SPILL_STACK must
+// cover the worst case of the trees rfwhip_update() accepts: a 4-wide node pushes up to 3 entries and spans >= 2 BVH2 levels
+// when it does, so a path needs <= 1.5 entries per BVH2 level; the exact need of every tree (bvh::stack_need4) is checked
+// against STACK_CAPACITY on the host, and a dropped entry is counted (WaveCounters::stack_overflow -> rfwhip_wait fails).
+constexpr int SPILL_STACK = 64;
+constexpr int STACK_CAPACITY = LDS_STACK_MIN + SPILL_STACK; // entries every traversal kernel can hold per ray
 
 RT_FN uint32_t make_entry(int left_first, int count, bool tlas)
 {
@@ -208,6 +227,8 @@ struct WaveCounters
 	uint32_t probe_inst, probe_prim;
 	float probe_dist;
 	uint32_t probe_valid;
+	uint32_t stack_overflow; // traversal-stack entries dropped (must stay 0: rfwhip_update bounds the trees; rfwhip_wait fails otherwise)
+	uint32_t pad_[3];
 };
 
 // The wavefront state in HBM.

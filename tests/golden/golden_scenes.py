@@ -14,3 +14,9 @@ def cornell_lights(pkg, W=96, H=64):
     s.add_spot_light((2.5, 8.5, -2.0), 18.0, (60.0, 40.0, 30.0), 32.0, (-0.35, -1.0, 0.45))
     s.add_directional_light((0.3, -1.0, 0.6), (1.5, 1.6, 2.0))
     return s
+
+
+def terrain_small(pkg, W=96, H=64):
+    """The bench workload (BASELINE config 3) at 12 x 12 cells = 288 triangles: smooth vertex normals, a glossy metallic and
+    a rough material, 8 emissive light triangles + 2 point lights, the synthetic 2048 x 1024 HDR sky."""
+    return pkg.scenes.terrain(n=12, width=W, height_px=H)

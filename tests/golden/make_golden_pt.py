@@ -944,7 +944,8 @@ def main():
     table = reference_blue_noise_table()
     for name, scene, bn in (("pt_cornell96x64", golden_scenes.cornell_pt(pkg, W, H), None),
                             ("pt_lights96x64", golden_scenes.cornell_lights(pkg, W, H), None),
-                            ("pt_cornell96x64_bluenoise", golden_scenes.cornell_pt(pkg, W, H), table)):
+                            ("pt_cornell96x64_bluenoise", golden_scenes.cornell_pt(pkg, W, H), table),
+                            ("pt_terrain96x64", golden_scenes.terrain_small(pkg, W, H), None)):
         pt = PathTracer(pkg, scene, W, H, blue_noise=bn)
         acc = np.zeros((W * H, 4), f32)
         per_sample = []

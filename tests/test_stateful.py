@@ -108,3 +108,15 @@ def test_editing_session_emulated_core(pkg, make_emu, make_oracle):
 def test_editing_session_gpu(pkg, make_hip, make_oracle):
     log = _session(pkg, make_hip(), make_oracle(), 480, 270)
     assert len(log) == 10
+
+
+def test_material_index_out_of_range_fails_at_update(pkg, make_emu):
+    """The shade kernels index the material table with the triangles' ids: rfwhip_update refuses a scene whose triangles
+    point past the materials that were set (instead of a page fault on the device)."""
+    import pytest
+    s = pkg.scenes.cornell(32, 24)
+    s.meshes[0]["triangles"]["material"][3] = 99
+    ctx = make_emu()
+    ctx.init(32, 24)
+    with pytest.raises(RuntimeError, match="material"):
+        s.upload(ctx)
