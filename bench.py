@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy peak)
+L2_PEAK_GBS = 34500.0  # same guide, §L2: 8 XCDs x 4 MiB, ~34.5 TB/s aggregate
+# a CU's vector L1 serves ONE divergent 16-byte lane-load per clock (profiles/micro/gather_micro.hip: 75 G 128-byte
+# records/s with 8 loads each, whatever the table size) — the ceiling the traversal kernels actually run into
+LANE_LOADS_PEAK = 600.0e9
 
 
 def usable_cores():
@@ -227,14 +231,36 @@ def main():
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
         concurrency = busy_ms / (elapsed * 1e3) if elapsed > 0 else 1.0
-        traffic = None
+        # the same launches alone on the chip: one sub-batch's worth of samples on one stream (what the PMC passes see)
+        sub_spp = max(1, args.spp // max(1, min(args.streams, args.spp)))
+        ctx.set_setting("streams", 1)
+        ctx.set_setting("spp", sub_spp)
+        ctx.set_setting("stage_timing", 1)
+        ctx.render_frame(scene.camera, pkg.RESET)
+        for name in ctx.KERNELS:
+            ctx.get_kernel_time(name, reset=True)
+        ser_frames = 3
+        for k in range(ser_frames):
+            ctx.render_frame(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+        ser_ms, ser_launches = ctx.get_kernel_time("extend")
+        ser_ms_per_launch = ser_ms / max(1, ser_launches)
+        ctx.set_setting("streams", args.streams)
+        ctx.set_setting("spp", args.spp)
+        # vector-L1 lane-loads of the extend stage: 7 rows per 4-wide node fetched from global memory (visits served by the
+        # LDS top-of-tree cache cost none), 3 per triangle test, 2 to read the ray
+        lane_loads = (7.0 * (cnt["inner_extend"] - cnt.get("lds_extend", 0)) + 3.0 * cnt["tris_extend"] + 2.0 * cnt["rays_extend"])
+        lane_loads_per_launch = lane_loads / replay / max(1.0, launches_per_step)
+        pm = {}
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
                 if tj.get("spp") == args.spp and tj.get("workload") == scene.name and tj.get("streams") == args.streams:
-                    traffic = tj.get("hbm_bytes_per_extend_launch")
+                    pm = tj
             except Exception:
-                traffic = None
+                pm = {}
+        traffic = pm.get("hbm_bytes_per_extend_launch")
+        l2_bytes = pm.get("l2_bytes_per_extend_launch")
+        ser_s = ser_ms_per_launch * 1e-3
         roofline = {
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -243,12 +269,31 @@ def main():
             "kernels_in_flight": round(concurrency, 3),
             "achieved_x_kernels_in_flight": round(achieved * max(1.0, concurrency), 2),
             "per_ray": {"inner_nodes": cnt["inner_extend"] / max(1, cnt["rays_extend"]),
+                        "inner_nodes_from_lds": cnt.get("lds_extend", 0) / max(1, cnt["rays_extend"]),
                         "triangle_tests": cnt["tris_extend"] / max(1, cnt["rays_extend"]),
                         "rays_per_sample": cnt["rays_extend"] / max(1.0, primaries),
                         "shadow_rays_per_sample": cnt["rays_shadow"] / max(1.0, primaries)},
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
-            # the BVH (32 MB nodes + 48 MB vertices) is L2 / Infinity-Cache resident, so the algorithmic byte rate is
-            # not an HBM rate and can exceed the HBM peak; the PMC-measured HBM rate of the same launches:
+            # The algorithmic byte rate is NOT an HBM rate: the BVH (42 MB of 4-wide nodes + 48 MB of vertices) is served by
+            # the vector L1s, the L2s and the Infinity Cache, so it exceeds the HBM peak once a launch has the chip to itself.
+            # What the same launches do when serialised, and the ceilings they actually sit under:
+            "serialised": {
+                "ms_per_launch": round(ser_ms_per_launch, 4), "launches": ser_launches, "spp_per_launch": sub_spp,
+                "achieved": round(bytes_per_launch / ser_s / 1e9, 2) if ser_s > 0 else None,
+                "frac": round(bytes_per_launch / ser_s / 1e9 / HBM_PEAK_GBS, 5) if ser_s > 0 else None,
+                # PMC-measured HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/) over the serialised duration
+                "hbm_gbs": round(traffic / ser_s / 1e9, 2) if (traffic and ser_s > 0) else None,
+                "hbm_frac": round(traffic / ser_s / 1e9 / HBM_PEAK_GBS, 5) if (traffic and ser_s > 0) else None,
+                # L2 requests x 128 B (TCC_REQ, profiles/) over the serialised duration, against ~34.5 TB/s
+                "l2_gbs": round(l2_bytes / ser_s / 1e9, 2) if (l2_bytes and ser_s > 0) else None,
+                "l2_frac": round(l2_bytes / ser_s / 1e9 / L2_PEAK_GBS, 5) if (l2_bytes and ser_s > 0) else None,
+                # the binding ceiling: divergent 16-byte lane-loads through the CUs' vector L1s, one per clock per CU
+                "l1_lane_loads_per_launch": lane_loads_per_launch,
+                "l1_lane_load_rate": round(lane_loads_per_launch / ser_s / 1e9, 2) if ser_s > 0 else None,
+                "l1_lane_load_peak": LANE_LOADS_PEAK / 1e9, "l1_lane_load_unit": "G lane-loads/s",
+                "l1_lane_load_frac": round(lane_loads_per_launch / ser_s / LANE_LOADS_PEAK, 5) if ser_s > 0 else None,
+                "binding_ceiling": "vector-L1 lane-load rate (with VALU issue at 15-31 of 64 lanes active: profiles/r02*_pmc_sq*.md)",
+            },
             "hbm_traffic_gbs": round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if (traffic and ms_per_launch > 0) else None,
         }
 

@@ -158,6 +158,8 @@ typedef struct rfwhip_counters
 	uint64_t tris_shadow;
 	uint64_t shaded;		 /* shade-kernel invocations with a hit */
 	uint64_t samples;		 /* pixel samples started */
+	uint64_t lds_extend;	 /* of inner_extend: visits served by the LDS top-of-tree cache (no vector-L1 lane-loads) */
+	uint64_t lds_shadow;	 /* of inner_shadow: the same */
 } rfwhip_counters;
 RFWHIP_API int rfwhip_get_counters(rfwhip_context *ctx, rfwhip_counters *out, int reset);
 

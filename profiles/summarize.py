@@ -33,5 +33,39 @@ def pmc(path):
         print("| `%s` | %s | %d | %.1f | %.1f | %.1f |" % (r[0][:90], r[1], r[2], r[3], r[4], r[5] / 1e3))
 
 
+def traffic(spp, streams, workload, tag, *paths):
+    """profiles/traffic_extend.json from the PMC passes of one evidence run (FETCH_SIZE, WRITE_SIZE and TCC_REQ_sum, each in
+    its own rocprofv3 --pmc pass of the same bench command): per launch of the extend stage = the primary kernel
+    k_extend<1, false> + the bounce kernel k_trace_stream<false, false>."""
+    import json
+    tot, disp = {}, {}
+    for path in paths:
+        c = sqlite3.connect(path).cursor()
+        for name, counter, n, total in c.execute(
+                "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+            if "k_extend<1, false>" in name or "k_trace_stream<false, false>" in name:
+                tot[counter] = tot.get(counter, 0.0) + total
+                disp[counter] = disp.get(counter, 0) + n
+    out = {"workload": workload, "spp": int(spp), "streams": int(streams)}
+    if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+        # gfx950: FETCH_SIZE reports half the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md §HBM; visible on k_resolve in
+        # the same pass), WRITE_SIZE is exact; both in KB
+        out["hbm_bytes_per_extend_launch"] = int((2.0 * tot["FETCH_SIZE"] / disp["FETCH_SIZE"] + tot["WRITE_SIZE"] / disp["WRITE_SIZE"]) * 1024)
+    if "TCC_REQ_sum" in tot:
+        out["l2_requests_per_extend_launch"] = int(tot["TCC_REQ_sum"] / disp["TCC_REQ_sum"])
+        out["l2_bytes_per_extend_launch"] = int(tot["TCC_REQ_sum"] / disp["TCC_REQ_sum"] * 128)  # 128-byte lines
+    for k in ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"):
+        if k in tot:
+            out[k.lower() + "_per_extend_launch"] = int(tot[k] / disp[k])
+    out["dispatches"] = disp
+    out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                         "--no-roofline` (tools/evidence.sh); extend stage = k_extend<1,false> + k_trace_stream<false,false> dispatches; "
+                         "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch, l2 bytes = TCC_REQ_sum x 128" % tag)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:])
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])

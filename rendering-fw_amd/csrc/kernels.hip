@@ -176,7 +176,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	Hit h;
 	h.t = 1e34f, h.u = 0, h.v = 0, h.prim = -1, h.inst = -1;
 	TStat st;
-	st.inner = 0, st.tris = 0;
+	st.inner = 0, st.tris = 0, st.lds = 0;
 	if (active)
 	{
 		trace<false, COUNT>(p.sc, O, D, t_min, t_max, h, ctx.stk, st);
@@ -189,6 +189,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		ctx.add64(&p.wv.counters->inner_extend, st.inner);
 		ctx.add64(&p.wv.counters->tris_extend, st.tris);
+		ctx.add64(&p.wv.counters->lds_extend, st.lds);
 		ctx.add64(&p.wv.counters->rays_extend, active ? 1u : 0u);
 	}
 }
@@ -199,7 +200,7 @@ RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	const PixelRef pr = slot_to_pixel(p.fr, i);
 	active = active && pr.valid && pr.x < (p.fr.W / 4u) * 4u && pr.y < (p.fr.H / 2u) * 2u;
 	TStat st;
-	st.inner = 0, st.tris = 0;
+	st.inner = 0, st.tris = 0, st.lds = 0;
 	uint32_t nshadow = 0;
 	f4 out = mk4(0, 0, 0, 0);
 	if (active)
@@ -228,6 +229,7 @@ RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		ctx.add64(&p.wv.counters->inner_shadow, st.inner);
 		ctx.add64(&p.wv.counters->tris_shadow, st.tris);
+		ctx.add64(&p.wv.counters->lds_shadow, st.lds);
 		ctx.add64(&p.wv.counters->rays_shadow, nshadow);
 		ctx.add64(&p.wv.counters->shaded, (active && out.w > 0.0f) ? 1u : 0u);
 	}
@@ -312,7 +314,7 @@ template <bool COUNT>
 RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 {
 	TStat st;
-	st.inner = 0, st.tris = 0;
+	st.inner = 0, st.tris = 0, st.lds = 0;
 	if (active)
 	{
 		const f4 o4 = p.wv.sh_org[i], d4 = p.wv.sh_dir[i];
@@ -330,6 +332,7 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		ctx.add64(&p.wv.counters->inner_shadow, st.inner);
 		ctx.add64(&p.wv.counters->tris_shadow, st.tris);
+		ctx.add64(&p.wv.counters->lds_shadow, st.lds);
 		ctx.add64(&p.wv.counters->rays_shadow, active ? 1u : 0u);
 	}
 }
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(BLOCK, ANY ? RT_ANY_WAVES : RT_TRAVERSAL_WAVES
 	bool has_ray = false, exhausted = false;
 	uint32_t ray = 0, slot = 0, nrays = 0;
 	TStat st;
-	st.inner = 0, st.tris = 0;
+	st.inner = 0, st.tris = 0, st.lds = 0;
 	const uint32_t lane = __lane_id();
 	for (;;)
 	{
@@ -786,6 +789,7 @@ __global__ void __launch_bounds__(BLOCK, ANY ? RT_ANY_WAVES : RT_TRAVERSAL_WAVES
 	{
 		ctx.add64(ANY ? &wc->inner_shadow : &wc->inner_extend, st.inner);
 		ctx.add64(ANY ? &wc->tris_shadow : &wc->tris_extend, st.tris);
+		ctx.add64(ANY ? &wc->lds_shadow : &wc->lds_extend, st.lds);
 		ctx.add64(ANY ? &wc->rays_shadow : &wc->rays_extend, nrays);
 	}
 }

@@ -1949,9 +1949,11 @@ extern "C" int rfwhip_get_counters(rfwhip_context *c, rfwhip_counters *out, int 
 		out->inner_extend += wc.inner_extend, out->tris_extend += wc.tris_extend;
 		out->inner_shadow += wc.inner_shadow, out->tris_shadow += wc.tris_shadow;
 		out->shaded += wc.shaded;
+		out->lds_extend += wc.lds_extend, out->lds_shadow += wc.lds_shadow;
 		if (reset)
 		{
 			wc.rays_extend = wc.rays_shadow = wc.inner_extend = wc.tris_extend = wc.inner_shadow = wc.tris_shadow = wc.shaded = 0;
+			wc.lds_extend = wc.lds_shadow = 0;
 			RF_TRY(dm::h2d(buf, &wc, sizeof(wc), c->stream));
 			RF_TRY(dm::sync(c->stream));
 		}

@@ -265,6 +265,7 @@ struct Hit
 struct TStat
 {
 	uint32_t inner, tris;
+	uint32_t lds; // of `inner`: node visits served by the LDS top-of-tree cache (no vector-L1 traffic)
 };
 
 #if defined(RT_DEVICE_BUILD)
@@ -515,7 +516,11 @@ struct Traverser
 			const uint32_t rel = idx - stk.top_first;
 			Node4Rows rows;
 			if (rel < stk.top_count)
+			{
 				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u), near_x, near_y, near_z);
+				if (COUNT)
+					st.lds++;
+			}
 			else // byte offset of the Node4 in the table (tables stay below 4 GiB)
 				rows = load_rows<true>((const char *)sc.nodes4, idx << 7, near_x, near_y, near_z);
 			const Node4Planes n = plane_distances(rows, id, oid);

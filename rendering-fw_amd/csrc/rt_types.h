@@ -224,6 +224,7 @@ struct WaveCounters
 	uint32_t shadow[MAX_DEPTH_SLOTS];
 	uint32_t work[WORK_QUEUES][8]; // per launch, per XCD: head of the chunk queue the persistent workgroups pull from
 	unsigned long long rays_extend, rays_shadow, inner_extend, tris_extend, inner_shadow, tris_shadow, shaded, samples;
+	unsigned long long lds_extend, lds_shadow; // node visits served by the LDS top-of-tree cache
 	uint32_t probe_inst, probe_prim;
 	float probe_dist;
 	uint32_t probe_valid;

@@ -2,19 +2,30 @@
 # usage: tools/evidence.sh <tag>   (on the GPU box)  — the per-round evidence set:
 #   gpurun_out/<tag>_bench.json          python bench.py (default flags)
 #   gpurun_out/<tag>_kernel_stats.md     rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/<tag>_pmc_fetch.md/_write.md   FETCH_SIZE / WRITE_SIZE, separate passes, no trace flags
+#   gpurun_out/<tag>_pmc_{fetch,write,tcc,tcp,sq_issue,sq_lanes}.md   one rocprofv3 --pmc pass each (no trace flags)
+#   gpurun_out/<tag>_traffic_extend.json HBM / L2 bytes per extend launch derived from the passes (-> profiles/traffic_extend.json)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
 mkdir -p $R/gpurun_out
-cd $R && timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-tail -c 3000 gpurun_out/${tag}_bench.json
+cd $R && timeout 900 python bench.py --stage-rates > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -c 1500 gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
 d=$R/gpurun_out/${tag}_stats; rm -rf $d
 (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $d -- python bench.py > $d.log 2>&1)
 (cd $R && python profiles/summarize.py stats $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_kernel_stats.md; head -12 gpurun_out/${tag}_kernel_stats.md)
-for c in FETCH_SIZE WRITE_SIZE; do
-  d=$R/gpurun_out/${tag}_pmc_$c; rm -rf $d
-  (cd $R && timeout 1200 rocprofv3 --pmc $c -d $d -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $d.log 2>&1)
-  lc=$(echo $c | tr A-Z a-z | sed 's/_size//')
-  (cd $R && python profiles/summarize.py pmc $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_pmc_$lc.md; head -8 gpurun_out/${tag}_pmc_$lc.md)
-done
+dbs=""
+pass() { # name counters...
+  name=$1; shift
+  d=$R/gpurun_out/${tag}_pmc_$name; rm -rf $d
+  (cd $R && timeout 1200 rocprofv3 --pmc "$@" -d $d -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $d.log 2>&1)
+  db=$(find $d -name "*.db" | head -1)
+  (cd $R && python profiles/summarize.py pmc $db > gpurun_out/${tag}_pmc_$name.md; head -6 gpurun_out/${tag}_pmc_$name.md)
+  echo $db
+}
+f=$(pass fetch FETCH_SIZE | tail -1)
+w=$(pass write WRITE_SIZE | tail -1)
+t=$(pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum | tail -1)
+p=$(pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum | tail -1)
+pass sq_issue SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY > /dev/null
+pass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE > /dev/null
+(cd $R && python profiles/summarize.py traffic 128 4 terrain_1002k "$tag" $f $w $t $p > gpurun_out/${tag}_traffic_extend.json; cat gpurun_out/${tag}_traffic_extend.json)
