@@ -82,6 +82,45 @@ __global__ __launch_bounds__(256) void k_coop(const u4 *tab, uint32_t mask, uint
 	out[tid] = acc;
 }
 
+// 8 lanes per record through LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): instruction k lands the
+// record of lane L = 8k + g at stage + L * 128; the 16-byte pieces are XOR-swizzled on the SOURCE side (piece slot j holds
+// row j ^ s(L), s(L) = (L >> 1) & 7) so that the owner's ds_read_b128 of row r at slot r ^ s(L) is bank-conflict free.
+// ROWS rows are used by the owner (the traversal kernel needs 7 of the 8).
+template <int ROWS> __global__ __launch_bounds__(256) void k_coop_dma(const u4 *tab, uint32_t mask, uint32_t *out)
+{
+	__shared__ u4 stage[4][64 * 8];
+	const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t g = lane >> 3, j = lane & 7;
+	const uint32_t sL = (lane >> 1) & 7;
+	uint32_t cur = (tid * 2654435761u) & mask;
+	uint32_t acc = 0;
+	for (int s = 0; s < STEPS; s++)
+	{
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+		{
+			const uint32_t L = 8 * k + g;
+			const uint32_t c = __shfl(cur, (int)L);
+			const uint32_t row = j ^ ((L >> 1) & 7);
+			if (row < ROWS)
+				__builtin_amdgcn_global_load_lds((const void *)(tab + size_t(c) * 8 + row), (__attribute__((address_space(3))) void *)&stage[w][k * 64], 16, 0, 0);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		uint32_t x = 0;
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+		{
+			const u4 v = stage[w][lane * 8 + (r ^ sL)];
+			x += v.x ^ v.y ^ v.z ^ v.w;
+		}
+		acc += x;
+		cur = (x + tid) & mask;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	}
+	out[tid] = acc;
+}
+
 // 4 lanes per record: lane (q = lane >> 2, c = lane & 3) loads 32 B at record + 32 c of the record its quad walks
 __global__ __launch_bounds__(256) void k_quad(const u4 *tab, uint32_t mask, uint32_t *out)
 {
@@ -141,6 +180,9 @@ int main()
 		report("direct<2>", time_ms([&] { k_direct<2><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 32);
 		report("direct<4>", time_ms([&] { k_direct<4><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 64);
 		report("direct<8>", time_ms([&] { k_direct<8><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 128);
+		report("direct<7>", time_ms([&] { k_direct<7><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 112);
+		report("dma<8>", time_ms([&] { k_coop_dma<8><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 128);
+		report("dma<7>", time_ms([&] { k_coop_dma<7><<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 112);
 		report("coop", time_ms([&] { k_coop<<<threads / 256, 256>>>(tab, n - 1, out); }, 5), 128);
 		// same number of record visits: 4 lanes per ray
 		{

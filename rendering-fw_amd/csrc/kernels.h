@@ -61,8 +61,9 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 				  uint32_t tri_base, const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags,
 				  stream_t s);
 
-// after a refit of the BVH2 boxes: copy them into the 4-wide traversal nodes of the same BLAS (Node4::src)
-void launch_refresh4(rt::Node4 *nodes4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
+// after a refit of the BVH2 boxes: re-quantise the child boxes of the compressed 4-wide nodes of the same BLAS; src4 = four
+// BLAS-relative BVH2 node indices per 4-wide node (Node4::src of the host's collapse)
+void launch_refresh4(rt::Node4c *nodes4, const uint32_t *src4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
 // BVH construction on the device (lbvh.hip): BVH2 in device form over chunks of four Morton-consecutive triangles, boxes
 // fitted, leaf-ordered vertices written; mesh-local arrays (node_base = tri_base = 0).  nodes: 2 * ceil(n / LBVH_CHUNK) entries,
 // parents / flags the same, tri_verts 3 n.  Returns 0, or 1 when the mesh is a single leaf (build it on the host).

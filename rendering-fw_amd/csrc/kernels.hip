@@ -25,6 +25,7 @@
 #include "rt_core.h"
 
 #include <string.h>
+#include <algorithm>
 
 using namespace rt;
 
@@ -93,7 +94,7 @@ struct Ctx
 	float potbuf[POT_CACHE];
 	float *pot;
 	uint32_t overflow_sink = 0;
-	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0, stk.overflow = &overflow_sink; }
+	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0, stk.overflow = &overflow_sink, stk.stride = 1; }
 	explicit Ctx(const Params &p) : Ctx()
 	{
 		stk.overflow = &p.wv.counters->stack_overflow;
@@ -569,17 +570,20 @@ RT_FN void skin_shade_item(TriShade *shade, const f4 *verts, const f4 *vnormals,
 	t.n2 = mk4(n2.x, n2.y, n2.z, N.z);
 }
 
-RT_FN void refresh4_item(Node4 *nodes4, const Node *nodes2, uint32_t i)
+// after a refit: re-quantise the child boxes of one compressed node from the refitted BVH2 boxes (src4: the BVH2 node, BLAS-
+// relative, each child box came from; 0xFFFFFFFF = unused slot)
+RT_FN void refresh4_item(Node4c *nodes4, const uint32_t *src4, const Node *nodes2, uint32_t i)
 {
-	Node4 &n = nodes4[i];
+	float lo[3][4], hi[3][4];
+	bool valid[4];
 	for (int k = 0; k < 4; k++)
 	{
-		const uint32_t src = n.src[k];
-		if (src == 0xFFFFFFFFu)
-			continue;
+		const uint32_t src = src4[4u * i + k];
+		valid[k] = src != 0xFFFFFFFFu;
 		for (int a = 0; a < 3; a++)
-			n.lo[a][k] = nodes2[src].bmin[a], n.hi[a][k] = nodes2[src].bmax[a];
+			lo[a][k] = valid[k] ? nodes2[src].bmin[a] : 0.0f, hi[a][k] = valid[k] ? nodes2[src].bmax[a] : 0.0f;
 	}
+	pack_boxes4c(nodes4[i], lo, hi, valid);
 }
 
 // refit, pass 1: rewrite the leaf-ordered triangle vertices from the new mesh vertices
@@ -650,30 +654,35 @@ struct ChunkQueue
 	}
 };
 
-static_assert(BLOCK == STACK_STRIDE, "LDS stack layout is stack[entry][thread of the workgroup]");
-#define RT_STACK_DECL_(DEPTH)                                                                \
-	__shared__ uint32_t s_stack[(DEPTH)*BLOCK];                                             \
+// Workgroup size of the persistent-lane kernels of the incoherent waves (k_trace_stream).  Their LDS = stack + ONE copy of the
+// top-of-tree cache per workgroup: a larger workgroup shares that copy among more waves, so more waves fit a CU
+// (256 threads: 26 KiB -> 6 workgroups = 24 waves per CU; 1024 threads: 62 KiB -> 2 workgroups = 32 waves per CU).
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 256
+#endif
+constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
+#define RT_STACK_DECL_N(DEPTH, NTHREADS)                                                     \
+	__shared__ uint32_t s_stack[(DEPTH) * (NTHREADS)];                                      \
 	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
 	uint32_t spill_[SPILL_STACK];                                                           \
 	Ctx ctx;                                                                                \
 	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
+	ctx.stk.stride = (NTHREADS);                                                            \
 	ctx.stk.spill = spill_;                                                                 \
-	stage_top(p, s_top);                                                                    \
+	stage_top<NTHREADS>(p, s_top);                                                          \
 	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;            \
 	ctx.stk.overflow = &p.wv.counters->stack_overflow;
+#define RT_STACK_DECL_(DEPTH) RT_STACK_DECL_N(DEPTH, BLOCK)
 #define RT_STACK_DECL_CLOSEST RT_STACK_DECL_(LDS_STACK)
 #define RT_STACK_DECL_ANY RT_STACK_DECL_(LDS_STACK_ANY)
 
 // every workgroup copies the top-of-tree rows into its LDS once (the grids are persistent)
-__device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
+template <int NTHREADS> __device__ __forceinline__ void stage_top(const Params &p, f4 *s_top)
 {
 	const f4 *src = (const f4 *)(p.sc.nodes4 + p.lds_first);
 	const uint32_t rows = p.lds_count * TOP_ROWS;
-	for (uint32_t i = threadIdx.x; i < rows; i += BLOCK)
-	{
-		const uint32_t n = i / TOP_ROWS, r = i - n * TOP_ROWS;
-		s_top[i] = src[n * 8u + r];
-	}
+	for (uint32_t i = threadIdx.x; i < rows; i += NTHREADS)
+		s_top[i] = src[i];
 	__syncthreads();
 }
 
@@ -715,14 +724,17 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES RT_TRAVERSAL_WAVES
+#endif
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, ANY ? RT_ANY_WAVES : RT_TRAVERSAL_WAVES) k_trace_stream(const Params p)
+__global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
 {
 	WaveCounters *const wc = p.wv.counters;
 	const uint32_t count = ANY ? connection_count(wc, p.depth) : wc->ext[p.depth];
 	if (count == 0u)
 		return;
-	RT_STACK_DECL_(ANY ? LDS_STACK_ANY : LDS_STACK)
+	RT_STACK_DECL_N(ANY ? LDS_STACK_ANY : LDS_STACK, TRACE_BLOCK)
 	uint32_t *const head = &wc->work[p.queue][0];
 	const uint32_t b = p.depth & 1u;
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
@@ -814,7 +826,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 	__shared__ float s_pot[POT_CACHE * BLOCK];
 	Ctx ctx;
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
-	ctx.stk.overflow = nullptr;
+	ctx.stk.overflow = nullptr, ctx.stk.stride = 0;
 	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
 	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
@@ -994,11 +1006,11 @@ __global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *all_nodes, uint32_t
 	}
 }
 
-__global__ void __launch_bounds__(BLOCK) k_refresh4(Node4 *nodes4, uint32_t count4, const Node *nodes2)
+__global__ void __launch_bounds__(BLOCK) k_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *nodes2)
 {
 	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i < count4)
-		refresh4_item(nodes4, nodes2, i);
+		refresh4_item(nodes4, src4, nodes2, i);
 }
 
 // Grid of the persistent kernels: more workgroups than fit on the chip at once (4-7 per CU).  The queue-driven kernels
@@ -1054,10 +1066,11 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 #define RT_EXT(G, C) hipLaunchKernelGGL((k_extend<G, C>), g, b, 0, st, p, max_items)
 	if (gen == GEN_BUFFER && (p.refill & 1u))
 	{
+		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
 		if (count)
-			hipLaunchKernelGGL((k_trace_stream<false, true>), g, b, 0, st, p);
+			hipLaunchKernelGGL((k_trace_stream<false, true>), gt, bt, 0, st, p);
 		else
-			hipLaunchKernelGGL((k_trace_stream<false, false>), g, b, 0, st, p);
+			hipLaunchKernelGGL((k_trace_stream<false, false>), gt, bt, 0, st, p);
 	}
 	else if (gen == GEN_BUFFER)
 	{
@@ -1109,10 +1122,11 @@ void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
 	const dim3 g(persistent_grid(max_items)), b(BLOCK);
 	if (p.refill & 2u)
 	{
+		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
 		if (count)
-			hipLaunchKernelGGL((k_trace_stream<true, true>), g, b, 0, (hipStream_t)s, p);
+			hipLaunchKernelGGL((k_trace_stream<true, true>), gt, bt, 0, (hipStream_t)s, p);
 		else
-			hipLaunchKernelGGL((k_trace_stream<true, false>), g, b, 0, (hipStream_t)s, p);
+			hipLaunchKernelGGL((k_trace_stream<true, false>), gt, bt, 0, (hipStream_t)s, p);
 	}
 	else if (count)
 		hipLaunchKernelGGL((k_connect<true>), g, b, 0, (hipStream_t)s, p);
@@ -1166,10 +1180,10 @@ void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, con
 		hipLaunchKernelGGL(k_skin_shade, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, shade, verts,
 						   vnormals, indices, tri_count);
 }
-void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t s)
+void launch_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *blas_nodes2, stream_t s)
 {
 	if (count4)
-		hipLaunchKernelGGL(k_refresh4, dim3((count4 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, nodes4, count4, blas_nodes2);
+		hipLaunchKernelGGL(k_refresh4, dim3((count4 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, nodes4, src4, count4, blas_nodes2);
 }
 
 void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
@@ -1267,10 +1281,10 @@ void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, con
 	for (uint32_t i = 0; i < tri_count; i++)
 		skin_shade_item(shade, verts, vnormals, indices, i);
 }
-void launch_refresh4(Node4 *nodes4, uint32_t count4, const Node *blas_nodes2, stream_t)
+void launch_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *blas_nodes2, stream_t)
 {
 	for (uint32_t i = 0; i < count4; i++)
-		refresh4_item(nodes4, blas_nodes2, i);
+		refresh4_item(nodes4, src4, blas_nodes2, i);
 }
 void launch_refit(Node *all_nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
 				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)

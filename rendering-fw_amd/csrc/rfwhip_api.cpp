@@ -350,7 +350,7 @@ struct rfwhip_context
 	bool scene_dirty = true;
 
 	// scene (device side)
-	DevBuf d_nodes, d_nodes4, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
+	DevBuf d_nodes, d_nodes4, d_nodes4_src, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
 	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
 	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
@@ -514,7 +514,7 @@ static void free_all(rfwhip_context *c)
 	}
 	c->d_lbvh_scratch.free_(), c->d_lbvh_nodes.free_(), c->d_lbvh_tri_verts.free_(), c->d_blue_noise.free_();
 	c->have_blue_noise = false;
-	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
+	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
 					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org, &c->d_sh_dir,
@@ -808,8 +808,8 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 						  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 						  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, m.d_flags.as<uint32_t>(),
 						  c->stream);
-		rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(),
-							 c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+		rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
+							 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 		RF_TRY(dm::last_launch_error());
 		if (timed)
 			dm::event_record(eb, c->stream);
@@ -1041,8 +1041,8 @@ extern "C" int rfwhip_pose_mesh(rfwhip_context *c, size_t index, const float *jo
 	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
 					  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
 					  (uint32_t)m.triCount, m.d_flags.as<uint32_t>(), c->stream);
-	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base,
-						 c->stream);
+	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
+						 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 	RF_TRY(dm::last_launch_error());
 	if (timed)
 		dm::event_record(eb, c->stream);
@@ -1063,6 +1063,17 @@ extern "C" int rfwhip_pose_mesh(rfwhip_context *c, size_t index, const float *jo
 	m.posed = true;
 	c->scene_dirty = true; // instance boxes change: the TLAS is rebuilt in update()
 	return RFWHIP_OK;
+}
+
+// float 4-wide node of the collapse -> the compressed node the rays fetch (entries as they are)
+static rt::Node4c compress4(const rt::Node4 &nd)
+{
+	rt::Node4c out;
+	bool valid[4];
+	for (int k = 0; k < 4; k++)
+		valid[k] = nd.entry[k] != rt::ENTRY_EMPTY, out.entry[k] = nd.entry[k];
+	rt::pack_boxes4c(out, nd.lo, nd.hi, valid);
+	return out;
 }
 
 extern "C" int rfwhip_update(rfwhip_context *c)
@@ -1096,7 +1107,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				m.n4_base = (uint32_t)nodes4;
 				nodes += m.bvh.nodes.size(), tris += m.triCount, nodes4 += m.n4.size();
 			}
-		std::vector<rt::Node4> all_nodes4(nodes4);
+		std::vector<rt::Node4c> all_nodes4(nodes4); // what the rays fetch: compressed (rt::pack_boxes4c)
+		std::vector<uint32_t> all_src(4 * nodes4);  // BVH2 node (BLAS-relative) behind each child box, for the refit
 		// resident meshes were refit on the device: save their current device data before the arrays move
 		std::vector<rt::Node> all_nodes(nodes);
 		std::vector<f4> all_verts(3 * tris);
@@ -1130,7 +1142,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 					else
 						nd.entry[j] = e + m.n4_base;
 				}
-				all_nodes4[m.n4_base + k] = nd;
+				all_nodes4[m.n4_base + k] = compress4(nd);
+				memcpy(&all_src[4 * (m.n4_base + k)], nd.src, 16);
 			}
 			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
 			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
@@ -1139,11 +1152,13 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
 		c->blas_nodes4 = all_nodes4.size();
 		c->node4_capacity = all_nodes4.size() + 2 * tlas_reserve + 64;
-		if (c->node4_capacity >= (size_t(1) << 25))
-			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^25 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
+		if (c->node4_capacity >= (size_t(1) << 26))
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^26 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
 		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
-		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4)));
-		RF_TRY(dm::h2d(c->d_nodes4.p, all_nodes4.data(), all_nodes4.size() * sizeof(rt::Node4), c->stream));
+		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4c)));
+		RF_TRY(c->d_nodes4_src.ensure(all_src.size() * sizeof(uint32_t)));
+		RF_TRY(dm::h2d(c->d_nodes4.p, all_nodes4.data(), all_nodes4.size() * sizeof(rt::Node4c), c->stream));
+		RF_TRY(dm::h2d(c->d_nodes4_src.p, all_src.data(), all_src.size() * sizeof(uint32_t), c->stream));
 		RF_TRY(c->d_tri_verts.ensure(all_verts.size() * sizeof(f4)));
 		RF_TRY(c->d_tri_shade.ensure(all_shade.size() * sizeof(rt::TriShade)));
 		RF_TRY(dm::h2d(c->d_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(rt::Node), c->stream));
@@ -1161,8 +1176,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 								  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 								  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount,
 								  m.d_flags.as<uint32_t>(), c->stream);
-				rtk::launch_refresh4(c->d_nodes4.as<rt::Node4>() + m.n4_base, (uint32_t)m.n4.size(),
-									 c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+				rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
+									 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 				if (m.posed) // the host copy of the shading records is the bind pose
 					rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(),
 										   m.d_vnormals.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
@@ -1240,7 +1255,10 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
 	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
 	RF_TRY(dm::h2d(c->d_instances.p, inst.data(), inst.size() * sizeof(rt::Instance), c->stream));
-	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4>() + tlas_base, tl4.data(), tl4.size() * sizeof(rt::Node4), c->stream));
+	std::vector<rt::Node4c> tl4c(tl4.size());
+	for (size_t k = 0; k < tl4.size(); k++)
+		tl4c[k] = compress4(tl4[k]);
+	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4c>() + tlas_base, tl4c.data(), tl4c.size() * sizeof(rt::Node4c), c->stream));
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
@@ -1249,7 +1267,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 									   : rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true);
 
 	rt::SceneView &sv = c->sv;
-	sv.nodes4 = c->d_nodes4.as<rt::Node4>();
+	sv.nodes4 = c->d_nodes4.as<rt::Node4c>();
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
 	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
 	sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();

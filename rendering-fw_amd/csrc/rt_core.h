@@ -268,26 +268,19 @@ struct TStat
 	uint32_t lds; // of `inner`: node visits served by the LDS top-of-tree cache (no vector-L1 traffic)
 };
 
-#if defined(RT_DEVICE_BUILD)
-constexpr int STACK_STRIDE = 256; // = workgroup size: stack[entry][thread], bank = thread % 32, conflict-free
-#else
-constexpr int STACK_STRIDE = 1;
-#endif
+// LDS stack layout: stack[entry][thread of the workgroup] (bank = thread % 32: conflict-free); the stride = the kernel's
+// workgroup size travels in TravStack::stride (a compile-time constant after inlining).  Host emulation: stride 1.
 constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 
-// The top of the largest BLAS, kept in LDS by every traversal workgroup: rows [lo.x lo.y lo.z hi.x hi.y hi.z entry] of
-// Node4 top_first .. top_first + top_count - 1.  A divergent 16-byte load costs the CU's vector L1 one cycle per lane
+// The top of the largest BLAS, kept in LDS by every traversal workgroup: the four rows of the compressed nodes
+// top_first .. top_first + top_count - 1.  A divergent 16-byte load costs the CU's vector L1 one cycle per lane
 // (profiles/micro/gather_micro.hip: 9.6 TB/s chip-wide whatever the table size) and that rate bounds the traversal
 // kernels; the same rows from LDS cost 4 cycles per 64 lanes, and every ray walks through these nodes.
 #ifndef RT_LDS_NODES
 #define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth)
 #endif
 constexpr uint32_t MAX_LDS_NODES = RT_LDS_NODES;
-#if defined(RT_DEVICE_BUILD)
-constexpr uint32_t TOP_ROWS = 7; // the src row stays behind
-#else
-constexpr uint32_t TOP_ROWS = 8; // emulation: `top` aliases the node table itself
-#endif
+constexpr uint32_t TOP_ROWS = 4; // a compressed node is exactly four rows (the emulation's `top` aliases the node table)
 
 struct TravStack
 {
@@ -297,6 +290,7 @@ struct TravStack
 	const f4 *top;	 // staged top-of-tree rows (TOP_ROWS per node)
 	uint32_t top_first, top_count;
 	uint32_t *overflow; // WaveCounters::stack_overflow
+	uint32_t stride;	// entries between two stack levels of one lane (= workgroup size on the device)
 };
 
 // 1/d for the slab test.  A direction component of exactly 0 (it happens: jitter r0 == 1.0f puts a ray on the image's
@@ -330,54 +324,37 @@ RT_FN bool slab(const f4 &a, const f4 &b, f3 id, f3 oid, float t, float &tnear)
 	return tmax > tmin && tmin < t && tmax >= 0.0f;
 }
 
-// The seven 16-byte rows of a Node4 a ray needs: the entries and, per axis, the entry-plane row and the exit-plane row of
-// its four children (which of lo / hi that is depends on the sign of the direction: near_* are row offsets).
-//  * device, global table (PIN): the seven loads are pinned by one empty asm that names every row, so they are issued
-//    back to back (one round trip; none is sunk into the branch that uses it, none is waited for while others are still
-//    to be issued).  The LDS copy of the top of the tree needs no pin.
-//  * The plane distances p * id - oid (24 fma) are computed once, after whichever path loaded the rows: in a wave with
-//    lanes on both paths only the loads run twice.
-struct Node4Rows
+// The four 16-byte rows of a compressed 4-wide node (rt::Node4c).
+//  * device, global table (PIN): the four loads are pinned by one empty asm that names every row, so they are issued back
+//    to back (one round trip; none is sunk into the branch that uses it, none is waited for while others are still to be
+//    issued).  The LDS copy of the top of the tree needs no pin.
+struct Node4cRows
 {
-	f4 en, nx, fx, ny, fy, nz, fz;
+	f4 r0, r1, r2, r3;
 };
-struct Node4Planes
+template <bool PIN> RT_FN Node4cRows load_rows(const char *base, uint32_t nb)
 {
-	f4 ax, ay, az; // distances to the entry planes of children 0..3
-	f4 bx, by, bz; // distances to the exit planes
-};
-template <bool PIN>
-RT_FN Node4Rows load_rows(const char *base, uint32_t nb, uint32_t near_x, uint32_t near_y, uint32_t near_z)
-{
-	Node4Rows r;
+	Node4cRows r;
 #if defined(__HIP_DEVICE_COMPILE__)
 	typedef float v4f __attribute__((ext_vector_type(4)));
-	v4f en = *(const v4f *)(base + (nb + 96u));
-	v4f nx = *(const v4f *)(base + (nb + near_x)), fx = *(const v4f *)(base + (nb + (near_x ^ 48u)));
-	v4f ny = *(const v4f *)(base + (nb + near_y)), fy = *(const v4f *)(base + (nb + (near_y ^ 80u)));
-	v4f nz = *(const v4f *)(base + (nb + near_z)), fz = *(const v4f *)(base + (nb + (near_z ^ 112u)));
+	v4f a = *(const v4f *)(base + nb), b = *(const v4f *)(base + (nb + 16u));
+	v4f c = *(const v4f *)(base + (nb + 32u)), d = *(const v4f *)(base + (nb + 48u));
 	if (PIN)
-		asm volatile("" : "+v"(en), "+v"(nx), "+v"(fx), "+v"(ny), "+v"(fy), "+v"(nz), "+v"(fz));
+		asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 #define RT_F4(V) mk4(V.x, V.y, V.z, V.w)
-	r.en = RT_F4(en), r.nx = RT_F4(nx), r.fx = RT_F4(fx), r.ny = RT_F4(ny), r.fy = RT_F4(fy), r.nz = RT_F4(nz), r.fz = RT_F4(fz);
+	r.r0 = RT_F4(a), r.r1 = RT_F4(b), r.r2 = RT_F4(c), r.r3 = RT_F4(d);
 #undef RT_F4
 #else
-	r.en = *(const f4 *)(base + (nb + 96u));
-	r.nx = *(const f4 *)(base + (nb + near_x)), r.fx = *(const f4 *)(base + (nb + (near_x ^ 48u)));
-	r.ny = *(const f4 *)(base + (nb + near_y)), r.fy = *(const f4 *)(base + (nb + (near_y ^ 80u)));
-	r.nz = *(const f4 *)(base + (nb + near_z)), r.fz = *(const f4 *)(base + (nb + (near_z ^ 112u)));
+	r.r0 = *(const f4 *)(base + nb), r.r1 = *(const f4 *)(base + (nb + 16u));
+	r.r2 = *(const f4 *)(base + (nb + 32u)), r.r3 = *(const f4 *)(base + (nb + 48u));
 #endif
 	return r;
 }
-RT_FN Node4Planes plane_distances(const Node4Rows &q, f3 id, f3 oid)
-{
-	Node4Planes r;
-#define RT_ROW(ROW, I, O) mk4(fmaf(ROW.x, I, -O), fmaf(ROW.y, I, -O), fmaf(ROW.z, I, -O), fmaf(ROW.w, I, -O))
-	r.ax = RT_ROW(q.nx, id.x, oid.x), r.ay = RT_ROW(q.ny, id.y, oid.y), r.az = RT_ROW(q.nz, id.z, oid.z);
-	r.bx = RT_ROW(q.fx, id.x, oid.x), r.by = RT_ROW(q.fy, id.y, oid.y), r.bz = RT_ROW(q.fz, id.z, oid.z);
-#undef RT_ROW
-	return r;
-}
+// byte k of a dword as float: one v_cvt_f32_ubyteK each
+RT_FN float ub0(uint32_t x) { return (float)(x & 255u); }
+RT_FN float ub1(uint32_t x) { return (float)((x >> 8) & 255u); }
+RT_FN float ub2(uint32_t x) { return (float)((x >> 16) & 255u); }
+RT_FN float ub3(uint32_t x) { return (float)(x >> 24); }
 
 // Möller–Trumbore with the reference's rejections: |a| < 1e-6, u outside [0,1], v < 0, u+v > 1, t <= t_min, t >= t.
 RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo)
@@ -421,7 +398,7 @@ struct Traverser
 {
 	f3 O, D;		 // world-space ray
 	f3 o, d, id, oid; // ray in the current space (world, or the object space of cur_inst), 1/d, o/d
-	uint32_t near_x, near_y, near_z; // byte offsets inside a Node4 of the planes this ray enters through, per axis
+	bool neg_x, neg_y, neg_z; // direction signs: which of a child's two planes per axis is the entry plane
 	int cur_inst;
 	int sp;
 	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
@@ -436,9 +413,7 @@ struct Traverser
 		o = o_, d = d_;
 		id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
 		oid = o * id;
-		near_x = id.x < 0.0f ? 48u : 0u;
-		near_y = id.y < 0.0f ? 64u : 16u;
-		near_z = id.z < 0.0f ? 80u : 32u;
+		neg_x = id.x < 0.0f, neg_y = id.y < 0.0f, neg_z = id.z < 0.0f;
 	}
 
 	RT_FN void begin(const SceneView &sc, f3 O_, f3 D_, float t_min_, float t_max)
@@ -455,7 +430,7 @@ struct Traverser
 	RT_FN void push(const TravStack stk, uint32_t e)
 	{
 		if (sp < LDS_DEPTH)
-			stk.lds[sp * STACK_STRIDE] = e;
+			stk.lds[sp * stk.stride] = e;
 		else if (sp < LDS_DEPTH + SPILL_STACK)
 			stk.spill[sp - LDS_DEPTH] = e;
 		else // cannot happen for trees rfwhip_update() accepted; counted so that it can never go unnoticed
@@ -478,7 +453,7 @@ struct Traverser
 			return sp < LDS_DEPTH + SPILL_STACK ? stk.spill[sp - LDS_DEPTH] : ENTRY_DONE; // builders bound the depth
 		}
 		const int s = sp > 0 ? sp - 1 : 0;
-		const uint32_t e = stk.lds[s * STACK_STRIDE];
+		const uint32_t e = stk.lds[s * stk.stride];
 		const uint32_t r = sp > 0 ? e : ENTRY_DONE;
 		sp = s;
 		return r;
@@ -491,9 +466,9 @@ struct Traverser
 		if (sp + 3 <= LDS_DEPTH)
 		{
 			const int na = fa ? 1 : 0, nb = fb ? 1 : 0, nc = fc ? 1 : 0;
-			stk.lds[sp * STACK_STRIDE] = ea;
-			stk.lds[(sp + na) * STACK_STRIDE] = eb;
-			stk.lds[(sp + na + nb) * STACK_STRIDE] = ec;
+			stk.lds[sp * stk.stride] = ea;
+			stk.lds[(sp + na) * stk.stride] = eb;
+			stk.lds[(sp + na + nb) * stk.stride] = ec;
 			sp += na + nb + nc;
 		}
 		else
@@ -514,34 +489,45 @@ struct Traverser
 		{
 			const uint32_t idx = cur & ENTRY_INDEX_MASK;
 			const uint32_t rel = idx - stk.top_first;
-			Node4Rows rows;
+			Node4cRows rows;
 			if (rel < stk.top_count)
 			{
-				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u), near_x, near_y, near_z);
+				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u));
 				if (COUNT)
 					st.lds++;
 			}
-			else // byte offset of the Node4 in the table (tables stay below 4 GiB)
-				rows = load_rows<true>((const char *)sc.nodes4, idx << 7, near_x, near_y, near_z);
-			const Node4Planes n = plane_distances(rows, id, oid);
+			else // byte offset of the node in the table (tables stay below 4 GiB)
+				rows = load_rows<true>((const char *)sc.nodes4, idx << 6);
 			if (COUNT)
 				st.inner++;
-			// slab test of the four children (aabb.cpp:39-77 in fma form, entry/exit planes picked by the direction
-			// sign); a miss (and an empty slot: a point box at 1e34) gets distance +inf
+			// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
+			// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
+			// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
+			const uint32_t ex = fbits(rows.r0.w);
+			const float Ax = ubits((ex & 255u) << 23) * id.x, Ay = ubits(((ex >> 8) & 255u) << 23) * id.y,
+						Az = ubits(((ex >> 16) & 255u) << 23) * id.z;
+			const float Bx = fmaf(rows.r0.x, id.x, -oid.x), By = fmaf(rows.r0.y, id.y, -oid.y), Bz = fmaf(rows.r0.z, id.z, -oid.z);
+			const uint32_t lox = fbits(rows.r2.x), loy = fbits(rows.r2.y), loz = fbits(rows.r2.z);
+			const uint32_t hix = fbits(rows.r2.w), hiy = fbits(rows.r3.x), hiz = fbits(rows.r3.y);
+			const uint32_t nxq = neg_x ? hix : lox, fxq = neg_x ? lox : hix;
+			const uint32_t nyq = neg_y ? hiy : loy, fyq = neg_y ? loy : hiy;
+			const uint32_t nzq = neg_z ? hiz : loz, fzq = neg_z ? loz : hiz;
+			// slab test of the four children (aabb.cpp:39-77 in fma form); a miss (and an empty slot: an inverted box) gets
+			// distance +inf
 			const float INF = 3.0e38f;
 			float t0, t1, t2, t3;
-#define RT_SLAB4(K, OUT)                                                  \
-	{                                                                     \
-		const float tmin = fmaxf(fmaxf(n.ax.K, n.ay.K), n.az.K);          \
-		const float tmax = fminf(fminf(n.bx.K, n.by.K), n.bz.K);          \
-		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF; \
+#define RT_SLAB4(UB, OUT)                                                                                   \
+	{                                                                                                       \
+		const float tmin = fmaxf(fmaxf(fmaf(UB(nxq), Ax, Bx), fmaf(UB(nyq), Ay, By)), fmaf(UB(nzq), Az, Bz)); \
+		const float tmax = fminf(fminf(fmaf(UB(fxq), Ax, Bx), fmaf(UB(fyq), Ay, By)), fmaf(UB(fzq), Az, Bz)); \
+		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                   \
 	}
-			RT_SLAB4(x, t0)
-			RT_SLAB4(y, t1)
-			RT_SLAB4(z, t2)
-			RT_SLAB4(w, t3)
+			RT_SLAB4(ub0, t0)
+			RT_SLAB4(ub1, t1)
+			RT_SLAB4(ub2, t2)
+			RT_SLAB4(ub3, t3)
 #undef RT_SLAB4
-			uint32_t e0 = fbits(rows.en.x), e1 = fbits(rows.en.y), e2 = fbits(rows.en.z), e3 = fbits(rows.en.w);
+			uint32_t e0 = fbits(rows.r1.x), e1 = fbits(rows.r1.y), e2 = fbits(rows.r1.z), e3 = fbits(rows.r1.w);
 			if (!ANY)
 			{
 				// order the four children by entry distance (5-comparator network), nearest first

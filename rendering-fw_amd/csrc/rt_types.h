@@ -10,6 +10,7 @@
 //   * Ray / hit / throughput records are arrays of float4 indexed by the (compacted) path index: one 16-byte
 //     access per lane per attribute, 1 KiB per wave instruction.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__) && !defined(RFWHIP_HOST_EMULATION)
@@ -93,6 +94,73 @@ struct alignas(16) Node4
 };
 static_assert(sizeof(Node4) == 128, "4-wide node");
 
+// What the rays actually fetch: the 4-wide node COMPRESSED to 64 bytes = four 16-byte rows (two nodes per 128-byte line).
+// The traversal kernels are bound by the number of divergent 16-byte lane-loads a CU's vector L1 can serve (one per clock,
+// DESIGN.md §4), so a node costs what its rows cost: 4 instead of the 7 rows a float node needs.  Child boxes are quantised
+// to 8 bits per plane in the frame of the node's own box (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs
+// through compressed wide BVHs", 2017): plane = org + q * 2^e per axis, q rounded OUTWARD, so every compressed box contains
+// the float box it came from — the set of triangles a ray reaches, and therefore every hit, is unchanged.
+//   row 0: org.x org.y org.z | exps (biased exponent bytes ex | ey << 8 | ez << 16)
+//   row 1: entry[4]
+//   row 2: qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (one byte per child, byte k = child k)
+//   row 3: qhi.y[4] qhi.z[4] 0 0
+// An unused slot has an inverted box (qlo = 255, qhi = 0) and ENTRY_EMPTY: never hit.
+struct alignas(16) Node4c
+{
+	float org[3];
+	uint32_t exps;
+	uint32_t entry[4];
+	uint32_t qlo[3];
+	uint32_t qhi[3];
+	uint32_t pad[2];
+};
+static_assert(sizeof(Node4c) == 64, "compressed 4-wide node");
+
+// Quantise the (up to four) child boxes lo[axis][child] .. hi[axis][child] into n (entries untouched).  Shared by the host
+// (upload) and the device (after a refit), so both produce the same bytes.
+RT_FN void pack_boxes4c(Node4c &n, const float lo[3][4], const float hi[3][4], const bool valid[4])
+{
+	n.exps = 0u;
+	for (int a = 0; a < 3; a++)
+	{
+		float mn = 3.0e38f, mx = -3.0e38f;
+		for (int k = 0; k < 4; k++)
+			if (valid[k])
+				mn = lo[a][k] < mn ? lo[a][k] : mn, mx = hi[a][k] > mx ? hi[a][k] : mx;
+		if (!(mx >= mn)) // no valid child
+			mn = 0.0f, mx = 0.0f;
+		const float ext = mx - mn;
+		int e = -100;
+		if (ext > 0.0f)
+		{
+			(void)frexpf(ext * (1.0f / 254.0f), &e); // ext / 254 = m * 2^e with m in [0.5, 1)  =>  254 * 2^e >= ext
+			e = e < -100 ? -100 : (e > 120 ? 120 : e);
+		}
+		const float scale = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+		n.org[a] = mn;
+		n.exps |= (uint32_t)(e + 127) << (8 * a);
+		uint32_t ql4 = 0u, qh4 = 0u;
+		for (int k = 0; k < 4; k++)
+		{
+			uint32_t ql = 255u, qh = 0u; // inverted: never hit
+			if (valid[k])
+			{
+				float fl = floorf((lo[a][k] - mn) * inv), fh = ceilf((hi[a][k] - mn) * inv);
+				fl = fl < 0.0f ? 0.0f : (fl > 255.0f ? 255.0f : fl), fh = fh < 0.0f ? 0.0f : (fh > 255.0f ? 255.0f : fh);
+				// outward, whatever the rounding of the two lines above did
+				while (fl > 0.0f && fmaf(fl, scale, mn) > lo[a][k])
+					fl -= 1.0f;
+				while (fh < 255.0f && fmaf(fh, scale, mn) < hi[a][k])
+					fh += 1.0f;
+				ql = (uint32_t)fl, qh = (uint32_t)fh;
+			}
+			ql4 |= ql << (8 * k), qh4 |= qh << (8 * k);
+		}
+		n.qlo[a] = ql4, n.qhi[a] = qh4;
+	}
+	n.pad[0] = n.pad[1] = 0u;
+}
+
 // Per-instance record (set_instance): inverse transform for rays, normal matrix for shading, BLAS location.
 struct alignas(16) Instance
 {
@@ -170,7 +238,7 @@ struct SceneView
 							 // ready-made stack entry with ABSOLUTE indices (node index into this array, leaf-ordered
 							 // triangle index into tri_verts): a traversal step is base + 32-bit offset, no per-lane
 							 // base pointers
-	const Node4 *nodes4;	 // traversal form: all BLAS 4-wide nodes, then the TLAS 4-wide nodes (absolute entries)
+	const Node4c *nodes4;	 // traversal form: all BLAS 4-wide nodes (compressed), then the TLAS's (absolute entries)
 	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
 	const TriShade *tri_shade;
 	const uint32_t *tlas_prims; // instance index per TLAS leaf slot
