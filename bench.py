@@ -45,6 +45,23 @@ def usable_cores():
     return max(1, n)
 
 
+def probe_embree():
+    """is an Embree the CPU baseline could call discoverable on this box?  (ldconfig cache, the usual library
+    directories, CMake package files.)  Returns a short description or None."""
+    import ctypes.util
+    import glob
+    for name in ("embree3", "embree4", "embree"):
+        found = ctypes.util.find_library(name)
+        if found:
+            return found
+    for pat in ("/usr/lib*/**/libembree*.so*", "/usr/local/lib*/**/libembree*.so*", "/opt/**/libembree*.so*",
+                "/usr/lib*/cmake/embree*", "/usr/local/lib*/cmake/embree*"):
+        hit = glob.glob(pat, recursive=True)
+        if hit:
+            return hit[0]
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,7 +355,11 @@ def main():
             spent += time.perf_counter() - t0
             done += 1
         cpu_value = float(W) * H * done / spent / 1e6
+        embree = probe_embree()
         cpu_baseline = {"value": round(cpu_value, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                        # an Embree harness would be the first choice; none is installed on the box, so the
+                        # oracle port is the only CPU line
+                        "embree": embree if embree else "not found (ldconfig, /usr, /usr/local, /opt searched)",
                         "sample": "%d full %dx%d frame(s) at 1 spp of the same scene/camera/integrator (%s, depth %d), "
                                   "oracle/rfw_oracle.c with OpenMP, %.1f s; oracle BVH build %.1f s not timed"
                                   % (done, W, H, args.integrator, args.max_depth, spent, t_build)}

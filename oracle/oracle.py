@@ -24,6 +24,14 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_ref():
+    """oracle/_ref/libbluenoise.so from the reference's own blue_noise.h (`make ref`); a no-op without /root/reference."""
+    r = subprocess.run(["make", "-C", HERE, "ref"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle/_ref build failed:\n" + r.stdout)
+    return os.path.join(HERE, "_ref", "libbluenoise.so")
+
+
 def load():
     global _lib
     if _lib is None:
@@ -51,6 +59,7 @@ def load():
         L.rfwo_sample_bsdf.restype = None
         L.rfwo_sample_bsdf.argtypes = [fp, fp, u32p, fp, fp, C.c_float, C.c_int, C.c_float, C.c_float, fp, fp, fp]
         L.rfwo_read_local_framebuffer.restype, L.rfwo_read_local_framebuffer.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+        L.rfwo_kat.restype, L.rfwo_kat.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
     return _lib
 
 

@@ -40,11 +40,17 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_TRAVERSAL_WAVES
 #define RT_TRAVERSAL_WAVES 6
 #endif
+// the persistent-lane kernels of the incoherent waves: with the 64-byte nodes their LDS is 20 / 16 KiB per workgroup, so
+// eight workgroups fit a CU; bound to 64 registers they run 8 waves per SIMD instead of 7 (65 registers): +3 % (and every
+// step down in resident waves costs: 6 / 5 / 4 / 3 workgroups per CU -> 2065 / 1899 / 1802 / 1596 Msamples/s)
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 8
+#endif
 #ifndef RT_PRIMARY_WAVES
-#define RT_PRIMARY_WAVES RT_TRAVERSAL_WAVES // k_extend: the kernel that also generates the primary rays
+#define RT_PRIMARY_WAVES 7 // k_extend: the kernel that also generates the primary rays (6 / 7 / 8 -> 6.95 / 6.65 / 7.42 ms per launch)
 #endif
 #ifndef RT_ANY_WAVES
-#define RT_ANY_WAVES RT_TRAVERSAL_WAVES // occlusion kernels (fewer registers, less LDS)
+#define RT_ANY_WAVES 8 // occlusion kernels (fewer registers, less LDS)
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
@@ -724,9 +730,7 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-#ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES RT_TRAVERSAL_WAVES
-#endif
+
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
 {
@@ -741,11 +745,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
 	Traverser<ANY, COUNT> T;
 	T.cur = ENTRY_DONE;
-	bool has_ray = false, exhausted = false;
-	uint32_t ray = 0, slot = 0, nrays = 0;
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
+	uint32_t nrays = 0;
 	const uint32_t lane = __lane_id();
+	bool has_ray = false, exhausted = false;
+	uint32_t ray = 0, slot = 0;
 	for (;;)
 	{
 		const unsigned long long idle_mask = __ballot(!has_ray);
