@@ -87,6 +87,15 @@ RFWHIP_API int rfwhip_set_blue_noise(rfwhip_context *ctx, const uint32_t *table,
 RFWHIP_API int rfwhip_set_mesh_skin(rfwhip_context *ctx, size_t mesh_index, const uint32_t *joints4, const float *weights4,
 									const float *base_normals4, size_t vertex_count);
 RFWHIP_API int rfwhip_pose_mesh(rfwhip_context *ctx, size_t mesh_index, const float *joint_matrices16, size_t joint_count);
+/* ---- device morph targets (extension, same idea: SceneMesh::set_pose(weights), geometry/gltf/mesh.cpp:127-147, runs on the
+ * host in the reference).  set_mesh_morph: for mesh `index` (last rfwhip_set_mesh = base pose) the base vertex normals and
+ * target_count displacement sets, each vertex_count float4 positions and float4 normals (w ignored), target-major.
+ * morph_mesh: vertex = base + sum_j weights[j] * target_j for positions and normals (normals NOT renormalised, as there),
+ * then update_triangles (mesh.cpp:428-485) and the device refit.  rfwhip_update() afterwards. */
+RFWHIP_API int rfwhip_set_mesh_morph(rfwhip_context *ctx, size_t mesh_index, const float *base_normals4,
+									 const float *target_positions4, const float *target_normals4, size_t target_count,
+									 size_t vertex_count);
+RFWHIP_API int rfwhip_morph_mesh(rfwhip_context *ctx, size_t mesh_index, const float *weights, size_t weight_count);
 /* update(): once after a batch of set_* — builds the TLAS, uploads descriptors              context.h:108 */
 RFWHIP_API int rfwhip_update(rfwhip_context *ctx);
 

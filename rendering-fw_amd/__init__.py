@@ -9,9 +9,10 @@ The directory name contains a hyphen (it is the reference repository's name + "_
 """
 from . import _binding, abi, scenes
 from . import gltf
+from . import obj
 from .abi import CONVERGE, RESET
 from .camera import Camera
 from .context import LIB_PATH, RenderContext, load_library
 from .build import build as build_native
 
-__all__ = ["abi", "scenes", "gltf", "Camera", "RenderContext", "load_library", "LIB_PATH", "build_native", "RESET", "CONVERGE"]
+__all__ = ["abi", "scenes", "gltf", "obj", "Camera", "RenderContext", "load_library", "LIB_PATH", "build_native", "RESET", "CONVERGE"]

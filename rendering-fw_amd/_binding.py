@@ -68,6 +68,8 @@ class CoreBinding:
         # device-side presents: only the rendercore (and its emulation build) export these
         for name, (res, args) in {"set_mesh_skin": (i32, [vp, sz, vp, vp, vp, sz]),
                                   "pose_mesh": (i32, [vp, sz, vp, sz]),
+                                  "set_mesh_morph": (i32, [vp, sz, vp, vp, vp, sz, sz]),
+                                  "morph_mesh": (i32, [vp, sz, vp, sz]),
                                   "read_framebuffer_device": (i32, [vp, vp]),
                                   "read_local_framebuffer_stream": (i32, [vp, vp, vp]),
                                   "deinterleave_stream": (i32, [vp, vp, vp, vp]),
@@ -175,6 +177,23 @@ class CoreBinding:
         m = _f32(joint_matrices).reshape(-1, 4, 4)
         cm = np.ascontiguousarray(np.transpose(m, (0, 2, 1)))  # column-major storage
         self._check(self._fn("pose_mesh")(self._ctx, int(index), cm.ctypes.data, len(cm)))
+
+    def set_mesh_morph(self, index, base_normals, target_positions, target_normals):
+        """Device morph targets of mesh `index` (whose last set_mesh vertices are the base pose): base normals (V x 3|4) and
+        per target the position / normal displacements, (T, V, 3|4) each."""
+        def f4(a, lead):
+            a = _f32(a).reshape(lead + (-1,))
+            out = np.zeros(lead + (4,), np.float32)
+            out[..., :3] = a[..., :3]
+            return out
+        tp = _f32(target_positions)
+        t, v = tp.shape[0], tp.shape[1]
+        bn, tp4, tn4 = f4(base_normals, (v,)), f4(tp, (t, v)), f4(target_normals, (t, v))
+        self._check(self._fn("set_mesh_morph")(self._ctx, int(index), bn.ctypes.data, tp4.ctypes.data, tn4.ctypes.data, t, v))
+
+    def morph_mesh(self, index, weights):
+        w = _f32(weights).reshape(-1)
+        self._check(self._fn("morph_mesh")(self._ctx, int(index), w.ctypes.data, len(w)))
 
     def set_blue_noise(self, table):
         """The reference's 5 x 65536-word blue-noise table (createBlueNoiseBuffer()); see scenes.synthetic_blue_noise."""

@@ -78,6 +78,11 @@ int launch_lbvh_build(const rt::f4 *verts, const uint32_t *indices, uint32_t tri
 void launch_skin_vertices(rt::f4 *verts, rt::f4 *vnormals, const rt::f4 *base_verts, const rt::f4 *base_normals,
 						  const uint32_t *joints4, const rt::f4 *weights4, const float *mats, uint32_t joint_count,
 						  uint32_t vertex_count, stream_t s);
+// morph targets on the device (geometry/gltf/mesh.cpp:127-147): verts / vnormals <- base + sum_j weights[j] * target_j;
+// tgt_pos / tgt_nrm: [target][vertex] float4, weights: device array of target_count floats
+void launch_morph_vertices(rt::f4 *verts, rt::f4 *vnormals, const rt::f4 *base_verts, const rt::f4 *base_normals,
+						   const rt::f4 *tgt_pos, const rt::f4 *tgt_nrm, const float *weights, uint32_t target_count,
+						   uint32_t vertex_count, stream_t s);
 // update_triangles() of the same file for the shading records: vertex normals of the three corners + face normal
 void launch_skin_shade(rt::TriShade *shade, const rt::f4 *verts, const rt::f4 *vnormals, const uint32_t *indices,
 					   uint32_t tri_count, stream_t s);

@@ -559,6 +559,22 @@ RT_FN void skin_vertex_item(f4 *verts, f4 *vnormals, const f4 *base_verts, const
 	const f3 rn = r * (1.0f / length(r));
 	vnormals[i] = mk4(rn.x, rn.y, rn.z, 0.0f);
 }
+// SceneMesh::set_pose(weights) (geometry/gltf/mesh.cpp:127-147): base + sum_j w_j * target_j for positions (w stays 1) and
+// normals (not renormalised there either).  targets: [target][vertex] float4 positions, then the same for normals.
+RT_FN void morph_vertex_item(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const f4 *tgt_pos,
+							 const f4 *tgt_nrm, const float *weights, uint32_t target_count, uint32_t vertex_count, uint32_t i)
+{
+	const f4 b = base_verts[i], bn = base_normals[i];
+	f3 p = xyz(b), n = xyz(bn);
+	for (uint32_t j = 0; j < target_count; j++)
+	{
+		const float w = weights[j];
+		p = p + xyz(tgt_pos[(size_t)j * vertex_count + i]) * w;
+		n = n + xyz(tgt_nrm[(size_t)j * vertex_count + i]) * w;
+	}
+	verts[i] = mk4(p.x, p.y, p.z, 1.0f);
+	vnormals[i] = mk4(n.x, n.y, n.z, 0.0f);
+}
 // SceneMesh::update_triangles (mesh.cpp:428-485) on the shading record: vN0..2 and N = normalize(cross(v1-v0, v2-v0))
 RT_FN void skin_shade_item(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t i)
 {
@@ -1165,6 +1181,21 @@ __global__ void __launch_bounds__(BLOCK) k_skin_vertices(f4 *verts, f4 *vnormals
 	if (i < vertex_count)
 		skin_vertex_item(verts, vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, i);
 }
+__global__ void __launch_bounds__(BLOCK) k_morph_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals,
+															  const f4 *tgt_pos, const f4 *tgt_nrm, const float *weights,
+															  uint32_t target_count, uint32_t vertex_count)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < vertex_count)
+		morph_vertex_item(verts, vnormals, base_verts, base_normals, tgt_pos, tgt_nrm, weights, target_count, vertex_count, i);
+}
+void launch_morph_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const f4 *tgt_pos,
+						   const f4 *tgt_nrm, const float *weights, uint32_t target_count, uint32_t vertex_count, stream_t s)
+{
+	if (vertex_count)
+		hipLaunchKernelGGL(k_morph_vertices, dim3((vertex_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, verts,
+						   vnormals, base_verts, base_normals, tgt_pos, tgt_nrm, weights, target_count, vertex_count);
+}
 __global__ void __launch_bounds__(BLOCK) k_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices,
 													  uint32_t tri_count)
 {
@@ -1280,6 +1311,12 @@ void launch_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f
 {
 	for (uint32_t i = 0; i < vertex_count; i++)
 		skin_vertex_item(verts, vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, i);
+}
+void launch_morph_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const f4 *tgt_pos,
+						   const f4 *tgt_nrm, const float *weights, uint32_t target_count, uint32_t vertex_count, stream_t)
+{
+	for (uint32_t i = 0; i < vertex_count; i++)
+		morph_vertex_item(verts, vnormals, base_verts, base_normals, tgt_pos, tgt_nrm, weights, target_count, vertex_count, i);
 }
 void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t tri_count, stream_t)
 {

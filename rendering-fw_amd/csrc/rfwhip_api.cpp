@@ -284,6 +284,10 @@ struct MeshRec
 	bool skinned = false, posed = false;
 	DevBuf d_base_verts, d_base_normals, d_joints, d_weights, d_vnormals, d_joint_mats;
 	uint32_t joint_count = 0;
+	// device morph targets (rfwhip_set_mesh_morph / rfwhip_morph_mesh); shares d_base_verts / d_base_normals / d_vnormals
+	bool morphed = false;
+	DevBuf d_tgt_pos, d_tgt_nrm, d_morph_weights;
+	uint32_t target_count = 0;
 };
 
 struct InstRec
@@ -508,7 +512,7 @@ static void free_all(rfwhip_context *c)
 	for (auto &m : c->meshes)
 	{
 		DevBuf *mb[] = {&m.d_verts, &m.d_indices, &m.d_parents, &m.d_flags, &m.d_base_verts, &m.d_base_normals, &m.d_joints,
-						&m.d_weights, &m.d_vnormals, &m.d_joint_mats};
+						&m.d_weights, &m.d_vnormals, &m.d_joint_mats, &m.d_tgt_pos, &m.d_tgt_nrm, &m.d_morph_weights};
 		for (DevBuf *b : mb)
 			b->free_();
 	}
@@ -773,6 +777,8 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	m.posed = false; // host vertices again; skinning data (if any) stays valid while the counts stay
 	if (m.skinned && !same_topology)
 		m.skinned = false;
+	if (m.morphed && !same_topology)
+		m.morphed = false;
 	fill_shade_records(m, mesh->triangles);
 	// mesh bounds (for the instance boxes of the TLAS)
 	for (int a = 0; a < 3; a++)
@@ -1074,6 +1080,85 @@ static rt::Node4c compress4(const rt::Node4 &nd)
 		valid[k] = nd.entry[k] != rt::ENTRY_EMPTY, out.entry[k] = nd.entry[k];
 	rt::pack_boxes4c(out, nd.lo, nd.hi, valid);
 	return out;
+}
+
+// ---- device morph targets (geometry/gltf/mesh.cpp:127-147 on the device) ---------------------------------------
+extern "C" int rfwhip_set_mesh_morph(rfwhip_context *c, size_t index, const float *base_normals4, const float *target_positions4,
+									 const float *target_normals4, size_t target_count, size_t vertex_count)
+{
+	CTX_ENTER(c);
+	if (index >= c->meshes.size() || !c->meshes[index].used)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_set_mesh_morph: mesh %zu has not been set", index);
+	MeshRec &m = c->meshes[index];
+	if (!base_normals4 || !target_positions4 || !target_normals4 || !target_count || vertex_count != m.vertexCount)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_set_mesh_morph: need base normals and >= 1 target for the mesh's %zu vertices", m.vertexCount);
+	if (m.posed)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_set_mesh_morph: mesh %zu is posed; set_mesh the base pose first", index);
+	RF_TRY(sync_all(c));
+	const size_t n = vertex_count;
+	RF_TRY(m.d_base_verts.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_base_normals.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_vnormals.ensure(n * sizeof(f4)));
+	RF_TRY(m.d_tgt_pos.ensure(target_count * n * sizeof(f4)));
+	RF_TRY(m.d_tgt_nrm.ensure(target_count * n * sizeof(f4)));
+	RF_TRY(m.d_morph_weights.ensure(target_count * sizeof(float)));
+	RF_TRY(dm::d2d(m.d_base_verts.p, m.d_verts.p, n * sizeof(f4), c->stream)); // the vertices of the last set_mesh = base pose
+	RF_TRY(dm::h2d(m.d_base_normals.p, base_normals4, n * sizeof(f4), c->stream));
+	RF_TRY(dm::h2d(m.d_tgt_pos.p, target_positions4, target_count * n * sizeof(f4), c->stream));
+	RF_TRY(dm::h2d(m.d_tgt_nrm.p, target_normals4, target_count * n * sizeof(f4), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	m.morphed = true, m.skinned = false;
+	m.target_count = (uint32_t)target_count;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_morph_mesh(rfwhip_context *c, size_t index, const float *weights, size_t weight_count)
+{
+	CTX_ENTER(c);
+	if (index >= c->meshes.size() || !c->meshes[index].used || !c->meshes[index].morphed)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_morph_mesh: mesh %zu has no morph targets (rfwhip_set_mesh_morph)", index);
+	MeshRec &m = c->meshes[index];
+	if (!weights || weight_count != m.target_count)
+		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_morph_mesh: mesh %zu has %u targets, got %zu weights", index, m.target_count, weight_count);
+	if (!m.resident || m.dirty)
+		return set_error(RFWHIP_ERR_STATE, "rfwhip_morph_mesh: mesh %zu is not resident yet (rfwhip_update first)", index);
+	RF_TRY(sync_all(c));
+	RF_TRY(dm::h2d(m.d_morph_weights.p, weights, weight_count * sizeof(float), c->stream));
+	dm::event_t ea, eb;
+	const bool timed = c->stage_timing != 0;
+	if (timed)
+	{
+		dm::event_create(&ea), dm::event_create(&eb);
+		dm::event_record(ea, c->stream);
+	}
+	rtk::launch_morph_vertices(m.d_verts.as<f4>(), m.d_vnormals.as<f4>(), m.d_base_verts.as<f4>(), m.d_base_normals.as<f4>(),
+							   m.d_tgt_pos.as<f4>(), m.d_tgt_nrm.as<f4>(), m.d_morph_weights.as<float>(), m.target_count,
+							   (uint32_t)m.vertexCount, c->stream);
+	rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(), m.d_vnormals.as<f4>(),
+						   m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, c->stream);
+	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+					  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
+					  (uint32_t)m.triCount, m.d_flags.as<uint32_t>(), c->stream);
+	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
+						 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+	RF_TRY(dm::last_launch_error());
+	if (timed)
+		dm::event_record(eb, c->stream);
+	rt::Node root;
+	RF_TRY(dm::d2h(&root, c->d_nodes.as<rt::Node>() + m.node_base, sizeof(rt::Node), c->stream));
+	RF_TRY(dm::sync(c->stream));
+	for (int a = 0; a < 3; a++)
+		m.bounds_min[a] = root.bmin[a] - 2e-5f, m.bounds_max[a] = root.bmax[a] + 2e-5f;
+	if (timed)
+	{
+		c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
+		c->kernel_launches[KF_REFIT] += 5;
+		c->stats.animationTime = dm::event_ms(ea, eb);
+		dm::event_destroy(ea), dm::event_destroy(eb);
+	}
+	m.posed = true;
+	c->scene_dirty = true; // instance boxes change: the TLAS is rebuilt in update()
+	return RFWHIP_OK;
 }
 
 extern "C" int rfwhip_update(rfwhip_context *c)

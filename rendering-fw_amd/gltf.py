@@ -9,13 +9,19 @@ What it restates from the reference (which parses with tinygltf, a third-party l
   * joint matrices  inverse(meshNode.combined) * joint.combined * inverseBind[j]     (node.cpp:90-98)
   * samplers        LINEAR: lerp for translation / scale, component-wise lerp + normalise for rotations (not slerp),
                     STEP, CUBICSPLINE (animation.cpp:230-320); time wraps with fmod(duration) (animation.cpp:378-390)
-Not covered: morph targets, cameras, KHR extensions, sparse accessors, .glb containers; materials map baseColorFactor /
-metallic / roughness only.  File parsing itself is plain json + base64/external buffers + numpy.
+  * morph targets   pose = base + sum_j w_j * target_j for positions AND normals, normals not renormalised
+                    (mesh.cpp:127-147; poses built at object.cpp:463-497); weights from the mesh / node defaults and from
+                    "weights" animation channels (animation.cpp:201,231-257,365-367: sampleFloat over `count` targets)
+  * containers      .gltf (json + external / data-uri buffers) and binary .glb (12-byte header, JSON chunk, BIN chunk)
+Not covered: cameras, KHR extensions, sparse accessors, image decoding (no image library in this environment: textures are
+referenced by index only); materials map baseColorFactor / metallic / roughness only.  File parsing itself is plain
+json + base64 / external buffers + numpy.
 """
 import base64
 import json
 import math
 import os
+import struct
 
 import numpy as np
 
@@ -36,8 +42,29 @@ def _quat_to_mat(q):
 class Gltf:
     def __init__(self, path):
         self.dir = os.path.dirname(os.path.abspath(path))
-        with open(path, "r") as f:
-            self.doc = json.load(f)
+        self.glb_bin = None
+        with open(path, "rb") as f:
+            raw = f.read()
+        if raw[:4] == b"glTF":
+            # binary container: header (magic, version, length), then chunks (length, type, payload); chunk 0 = JSON,
+            # an optional chunk 1 = BIN, the buffer without a uri
+            magic, version, length = struct.unpack_from("<4sII", raw, 0)
+            if version != 2:
+                raise ValueError("%s: glb version %d (only 2 is defined)" % (path, version))
+            off = 12
+            self.doc = None
+            while off + 8 <= min(length, len(raw)):
+                clen, ctype = struct.unpack_from("<II", raw, off)
+                payload = raw[off + 8:off + 8 + clen]
+                if ctype == 0x4E4F534A:  # "JSON"
+                    self.doc = json.loads(payload.decode("utf-8"))
+                elif ctype == 0x004E4942 and self.glb_bin is None:  # "BIN\0"
+                    self.glb_bin = payload
+                off += 8 + clen + ((4 - clen % 4) % 4)
+            if self.doc is None:
+                raise ValueError("%s: glb without a JSON chunk" % path)
+        else:
+            self.doc = json.loads(raw.decode("utf-8"))
         self.buffers = [self._load_buffer(b) for b in self.doc.get("buffers", [])]
         self.nodes = self.doc.get("nodes", [])
         self.parents = [-1] * len(self.nodes)
@@ -49,10 +76,23 @@ class Gltf:
         self.R = [np.asarray(n.get("rotation", (0, 0, 0, 1)), np.float64) for n in self.nodes]
         self.S = [np.asarray(n.get("scale", (1, 1, 1)), np.float64) for n in self.nodes]
         self.M = [np.asarray(n["matrix"], np.float64).reshape(4, 4).T if "matrix" in n else np.eye(4) for n in self.nodes]
+        # morph-target weights per node: the node's own, else its mesh's defaults, else zeros (node.cpp:44-51)
+        self.W = []
+        for n in self.nodes:
+            w = None
+            if "mesh" in n:
+                mesh = self.doc["meshes"][n["mesh"]]
+                nt = len(mesh["primitives"][0].get("targets", []))
+                w = np.asarray(n.get("weights", mesh.get("weights", [0.0] * nt)), np.float64)
+            self.W.append(w)
         self.animations = [self._load_animation(a) for a in self.doc.get("animations", [])]
 
     # ---- buffers / accessors ---------------------------------------------------------------------------------------
     def _load_buffer(self, b):
+        if "uri" not in b:
+            if self.glb_bin is None:
+                raise ValueError("buffer without a uri outside a .glb container")
+            return self.glb_bin
         uri = b["uri"]
         if uri.startswith("data:"):
             return base64.b64decode(uri.split(",", 1)[1])
@@ -130,7 +170,17 @@ class Gltf:
             return
         a = self.animations[animation]
         for c in a["channels"]:
-            v = self._sample(a["samplers"][c["sampler"]], float(time))
+            smp = a["samplers"][c["sampler"]]
+            if c["path"] == "weights":
+                # one key = `count` consecutive scalars (x3 for CUBICSPLINE): sampleFloat(time, k, i, count)
+                count = len(self.W[c["node"]])
+                per_key = count * (3 if smp["method"] == "CUBICSPLINE" else 1)
+                keyed = dict(smp, keys=smp["keys"].reshape(-1, per_key))
+                if smp["method"] == "CUBICSPLINE":  # (in-tangent, value, out-tangent) per target -> three rows per key
+                    keyed["keys"] = smp["keys"].reshape(-1, count, 3).transpose(0, 2, 1).reshape(-1, count)
+                self.W[c["node"]] = np.asarray(self._sample(keyed, float(time)), np.float64).reshape(-1)[:count]
+                continue
+            v = self._sample(smp, float(time))
             if c["path"] == "translation":
                 self.T[c["node"]] = v[:3]
             elif c["path"] == "scale":
@@ -155,8 +205,24 @@ class Gltf:
             tri = idx if idx is not None else np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
             fn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
             nrm = scenes._accumulate_vertex_normals(len(pos), tri, fn)
+        # morph targets: displacement sets for positions and normals (object.cpp:476-497); a target without NORMAL adds 0
+        targets = []
+        for t in p.get("targets", []):
+            tp = self.accessor(t["POSITION"]).astype(np.float32) if "POSITION" in t else np.zeros_like(pos)
+            tn = self.accessor(t["NORMAL"]).astype(np.float32) if "NORMAL" in t else np.zeros_like(nrm)
+            targets.append((tp, tn))
         return {"positions": pos, "indices": idx, "normals": nrm, "uvs": uv, "joints": joints, "weights": weights,
-                "material": p.get("material", -1)}
+                "material": p.get("material", -1), "targets": targets}
+
+    def morphed(self, node_index, prim=0):
+        """SceneMesh::set_pose(weights) (mesh.cpp:127-147) for the mesh of `node_index` with the node's current weights:
+        positions and normals = base + sum_j w_j * target_j (normals are not renormalised there)."""
+        pr = self.primitive(self.nodes[node_index]["mesh"], prim)
+        pos, nrm = pr["positions"].copy(), pr["normals"].copy()
+        for w, (tp, tn) in zip(self.W[node_index], pr["targets"]):
+            pos += np.float32(w) * tp
+            nrm += np.float32(w) * tn
+        return pos, nrm
 
     def joint_matrices(self, node_index):
         """Joint matrices of the skin attached to mesh node `node_index` in the current pose, (J, 4, 4) row-major."""
