@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=2)
     ap.add_argument("--refill", type=int, default=3, help="persistent-lane traversal on the bounce / shadow waves")
     ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
+    ap.add_argument("--overlap", type=int, default=-1, help="connection waves on a second stream per sub-batch: 0 / 1 / -1 = by launch size")
     ap.add_argument("--lds-nodes", type=int, default=-1,
                     help="top-of-tree 4-wide nodes kept in LDS by the traversal kernels (-1: kernel capacity, 0: off)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -149,6 +150,7 @@ def main():
     ctx.set_setting("refill", args.refill)
     ctx.set_setting("streams", args.streams)
     ctx.set_setting("lds_nodes", args.lds_nodes)
+    ctx.set_setting("overlap", args.overlap)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()

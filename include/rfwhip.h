@@ -149,6 +149,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   lds_nodes    = top-of-tree 4-wide nodes of the largest mesh BVH that every traversal workgroup keeps in LDS
  *                  (-1 = as many as the kernels were built for, the default; 0 disables)
  *   streams      = sub-batches of one render call that run concurrently on their own HIP streams (1..8, default 4)
+ *   overlap      = "1": the connection (shadow) wave of depth d runs on a second stream beside extend / shade of depth d + 1
+ *                  (hides kernel tails when launches are small); "0": in order on the sub-batch's stream; "-1" (default):
+ *                  chosen by the size of the render call
  *   refill       = bit mask, default 3: bit 0 persistent lanes on the extension (bounce) waves, bit 1 on the shadow waves
  *                  (a lane that finishes its ray pulls the next one from the wave's queue)
  * Returns the number of keys; fills up to cap pointers with static strings. */

@@ -292,7 +292,11 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		// depth 0 initialises the slot (no clear pass); later depths accumulate.  One path per slot => no race.
 		if (p.depth == 0)
+		{
 			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, 1.0f);
+			if (p.wv.rad_nee)
+				p.wv.rad_nee[slot] = mk4(0, 0, 0, 0);
+		}
 		else if (out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
 		{
 			f4 r = p.wv.rad[slot];
@@ -330,9 +334,10 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		{
 			const f4 e4 = p.wv.sh_rad[i];
 			const uint32_t slot = fbits(o4.w);
-			f4 r = p.wv.rad[slot];
+			f4 *const dst = p.wv.rad_nee ? p.wv.rad_nee : p.wv.rad;
+			f4 r = dst[slot];
 			r.x += e4.x, r.y += e4.y, r.z += e4.z;
-			p.wv.rad[slot] = r;
+			dst[slot] = r;
 		}
 	}
 	if (COUNT)
@@ -458,6 +463,11 @@ RT_FN void resolve_item(const Params &p, uint32_t li)
 	{
 		const f4 r = p.wv.rad[(unsigned long long)s * p.fr.slots + lp];
 		a.x += r.x, a.y += r.y, a.z += r.z, a.w += r.w;
+		if (p.wv.rad_nee)
+		{
+			const f4 q = p.wv.rad_nee[(unsigned long long)s * p.fr.slots + lp];
+			a.x += q.x, a.y += q.y, a.z += q.z;
+		}
 	}
 	p.wv.acc[li] = a;
 }
@@ -804,9 +814,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 					if (T.hit.prim < 0)
 					{
 						const f4 e4 = p.wv.sh_rad[ray];
-						f4 r = p.wv.rad[slot];
+						f4 *const dst = p.wv.rad_nee ? p.wv.rad_nee : p.wv.rad;
+						f4 r = dst[slot];
 						r.x += e4.x, r.y += e4.y, r.z += e4.z;
-						p.wv.rad[slot] = r;
+						dst[slot] = r;
 					}
 				}
 				else

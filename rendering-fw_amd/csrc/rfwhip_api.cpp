@@ -319,15 +319,25 @@ struct TimedSpan
 struct rfwhip_context
 {
 	int device = 0, rank = 0, world = 1, cus = 256;
-	void *stream = nullptr; // stream 0: prologue, sub-batch 0, resolve, presents
+	void *stream = nullptr; // main stream: scene uploads, refits, prologue, resolve, presents
 	static constexpr int MAX_SUB = 8;
+	// every sub-batch of a render call runs on its own stream, its connection (shadow) waves on a second one beside it
 	void *sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	void *conn_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	DevBuf d_counters_sub[MAX_SUB]; // [0] is d_counters' alias slot (unused), 1.. are the extra sub-batches' counters
-	dm::event_t ev_prologue, ev_resolve, ev_sub_done[MAX_SUB];
+	dm::event_t ev_prologue, ev_sub_done[MAX_SUB];
+	dm::event_t ev_resolve[2];								// resolve of the last call that used radiance buffer set 0 / 1
+	dm::event_t ev_shade[MAX_SUB][rt::MAX_DEPTH_SLOTS];		// shade stage of depth d enqueued (its connections may start)
+	dm::event_t ev_conn[MAX_SUB][rt::MAX_DEPTH_SLOTS];		// connection wave of depth d enqueued
+	dm::event_t ev_conn_last[MAX_SUB];						// everything of the call on the connection stream
+	bool conn_used[MAX_SUB] = {false, false, false, false, false, false, false, false};
+	bool resolve_recorded[2] = {false, false};
+	uint32_t call_parity = 0; // which of the two radiance buffer sets the next render call writes
 	dm::event_t ev_present_in, ev_present_out; // hand-off to / from a caller's stream (rfwhip_*_stream)
 	bool present_pending = false;
 	bool events_ready = false;
-	int subs_last = 1; // sub-batches of the most recent render call
+	size_t last_wave_off = 0; // where the most recent call's first sub-batch keeps its per-path records
+	int subs_last = 1, subs_first = 0; // sub-batch slots of the most recent render call: subs_first .. subs_first + subs_last - 1
 	bool cleaned = false;
 	uint32_t W = 0, H = 0;
 
@@ -346,6 +356,7 @@ struct rfwhip_context
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
 	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
+	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
 	// scene (host side)
 	std::vector<MeshRec> meshes;
@@ -362,8 +373,10 @@ struct rfwhip_context
 	rt::SceneView sv;
 
 	// wave state
-	DevBuf d_org[2], d_dir2[2], d_thr[2], d_hit, d_hit_inst, d_hit0, d_hit0_inst, d_sh_org, d_sh_dir, d_sh_rad, d_rad,
-		d_acc, d_counters, d_packet_rng, d_jump_table, d_present;
+	// shadow-ray buffers: two sets (by depth parity) so that shade(d + 1) can write while connect(d) still reads;
+	// radiance: two sets (by call parity) x {shade, connections}, so that a call can start while the previous one resolves
+	DevBuf d_org[2], d_dir2[2], d_thr[2], d_hit, d_hit_inst, d_hit0, d_hit0_inst, d_sh_org[2], d_sh_dir[2], d_sh_rad[2],
+		d_rad[2], d_rad_nee[2], d_acc, d_counters, d_packet_rng, d_jump_table, d_present;
 	uint32_t samples_done = 0;
 	size_t wave_capacity = 0; // path slots the wave buffers can hold
 	rt::FrameView fr;
@@ -521,8 +534,9 @@ static void free_all(rfwhip_context *c)
 	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
-					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org, &c->d_sh_dir,
-					  &c->d_sh_rad, &c->d_rad, &c->d_acc, &c->d_counters, &c->d_packet_rng, &c->d_jump_table,
+					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org[0], &c->d_sh_org[1],
+					  &c->d_sh_dir[0], &c->d_sh_dir[1], &c->d_sh_rad[0], &c->d_sh_rad[1], &c->d_rad[0], &c->d_rad[1],
+					  &c->d_rad_nee[0], &c->d_rad_nee[1], &c->d_acc, &c->d_counters, &c->d_packet_rng, &c->d_jump_table,
 					  &c->d_present};
 	for (DevBuf *b : bufs)
 		b->free_();
@@ -533,17 +547,23 @@ static void free_all(rfwhip_context *c)
 		c->d_counters_sub[i].free_();
 	if (c->events_ready)
 	{
-		dm::event_destroy(c->ev_prologue), dm::event_destroy(c->ev_resolve);
+		dm::event_destroy(c->ev_prologue), dm::event_destroy(c->ev_resolve[0]), dm::event_destroy(c->ev_resolve[1]);
 		dm::event_destroy(c->ev_present_in), dm::event_destroy(c->ev_present_out);
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
-			dm::event_destroy(c->ev_sub_done[i]);
+		{
+			dm::event_destroy(c->ev_sub_done[i]), dm::event_destroy(c->ev_conn_last[i]);
+			for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+				dm::event_destroy(c->ev_shade[i][d]), dm::event_destroy(c->ev_conn[i][d]);
+		}
 		c->events_ready = false, c->present_pending = false;
 	}
-	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
+	for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
 	{
-		dm::stream_destroy(c->sub_stream[i]);
-		c->sub_stream[i] = nullptr;
+		dm::stream_destroy(c->sub_stream[i]), dm::stream_destroy(c->conn_stream[i]);
+		c->sub_stream[i] = nullptr, c->conn_stream[i] = nullptr;
+		c->conn_used[i] = false;
 	}
+	c->resolve_recorded[0] = c->resolve_recorded[1] = false;
 	c->wave_capacity = 0;
 	c->blas_nodes4 = 0, c->node4_capacity = 0;
 }
@@ -1420,10 +1440,15 @@ static int ensure_wave_buffers(rfwhip_context *c, size_t paths)
 	RF_TRY(c->d_hit_inst.ensure(paths * 4));
 	RF_TRY(c->d_hit0.ensure(b16));
 	RF_TRY(c->d_hit0_inst.ensure(paths * 4));
-	RF_TRY(c->d_sh_org.ensure(b16));
-	RF_TRY(c->d_sh_dir.ensure(b16));
-	RF_TRY(c->d_sh_rad.ensure(b16));
-	RF_TRY(c->d_rad.ensure(b16));
+	for (int k = 0; k < 2; k++)
+	{
+		RF_TRY(c->d_sh_org[k].ensure(b16));
+		RF_TRY(c->d_sh_dir[k].ensure(b16));
+		RF_TRY(c->d_sh_rad[k].ensure(b16));
+		RF_TRY(c->d_rad[k].ensure(b16));
+		RF_TRY(c->d_rad_nee[k].ensure(b16));
+	}
+	c->resolve_recorded[0] = c->resolve_recorded[1] = false; // (everything was synchronised above)
 	c->wave_capacity = paths;
 	return 0;
 }
@@ -1477,8 +1502,8 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 		wv.org[k] = c->d_org[k].as<f4>(), wv.dir[k] = c->d_dir2[k].as<f4>(), wv.thr[k] = c->d_thr[k].as<f4>();
 	wv.hit = c->d_hit.as<f4>(), wv.hit_inst = c->d_hit_inst.as<int>();
 	wv.hit0 = c->d_hit0.as<f4>(), wv.hit0_inst = c->d_hit0_inst.as<int>();
-	wv.sh_org = c->d_sh_org.as<f4>(), wv.sh_dir = c->d_sh_dir.as<f4>(), wv.sh_rad = c->d_sh_rad.as<f4>();
-	wv.rad = c->d_rad.as<f4>(), wv.acc = c->d_acc.as<f4>();
+	wv.sh_org = c->d_sh_org[0].as<f4>(), wv.sh_dir = c->d_sh_dir[0].as<f4>(), wv.sh_rad = c->d_sh_rad[0].as<f4>();
+	wv.rad = c->d_rad[c->call_parity].as<f4>(), wv.rad_nee = nullptr, wv.acc = c->d_acc.as<f4>();
 	wv.packet_rng = c->d_packet_rng.as<uint32_t>();
 	wv.counters = c->d_counters.as<rt::WaveCounters>();
 	p.cam.blue_noise = nullptr;
@@ -1516,10 +1541,14 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 
 static int sync_all(rfwhip_context *c)
 {
-	RF_TRY(dm::sync(c->stream));
-	for (int i = 1; i < rfwhip_context::MAX_SUB; i++)
+	for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
+	{
 		if (c->sub_stream[i])
 			RF_TRY(dm::sync(c->sub_stream[i]));
+		if (c->conn_stream[i])
+			RF_TRY(dm::sync(c->conn_stream[i]));
+	}
+	RF_TRY(dm::sync(c->stream));
 	if (c->present_pending)
 	{
 		// a present enqueued on the CALLER's stream (rfwhip_read_local_framebuffer_stream) still reads the accumulator:
@@ -1535,19 +1564,29 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 	if (!c->events_ready)
 	{
 		RF_TRY(dm::event_create(&c->ev_prologue));
-		RF_TRY(dm::event_create(&c->ev_resolve));
+		RF_TRY(dm::event_create(&c->ev_resolve[0]));
+		RF_TRY(dm::event_create(&c->ev_resolve[1]));
 		RF_TRY(dm::event_create(&c->ev_present_in));
 		RF_TRY(dm::event_create(&c->ev_present_out));
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
+		{
 			RF_TRY(dm::event_create(&c->ev_sub_done[i]));
+			RF_TRY(dm::event_create(&c->ev_conn_last[i]));
+			for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+			{
+				RF_TRY(dm::event_create(&c->ev_shade[i][d]));
+				RF_TRY(dm::event_create(&c->ev_conn[i][d]));
+			}
+		}
 		c->events_ready = true;
 	}
-	c->sub_stream[0] = c->stream;
-	for (int i = 1; i < subs; i++)
+	for (int i = 0; i < subs; i++)
 	{
 		if (!c->sub_stream[i])
 			RF_TRY(dm::stream_create(&c->sub_stream[i]));
-		if (!c->d_counters_sub[i].p)
+		if (!c->conn_stream[i])
+			RF_TRY(dm::stream_create(&c->conn_stream[i]));
+		if (i > 0 && !c->d_counters_sub[i].p)
 		{
 			RF_TRY(c->d_counters_sub[i].ensure(sizeof(rt::WaveCounters)));
 			RF_TRY(dm::zero(c->d_counters_sub[i].p, sizeof(rt::WaveCounters), c->stream));
@@ -1578,11 +1617,15 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
 	if (paths >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "spp batch too large: %zu path slots (limit 2^31)", paths);
-	if (paths > c->wave_capacity)
+	// Sub-batches: up to `streams`, but no launch below ~1.5 M paths (small launches are all tail: an 8-GPU rank's 2 M paths
+	// per step run 1.98 ms as one sub-batch, 2.68 ms as four).  A call that is ONE sub-batch alternates between two sets of
+	// wave buffers / streams / counters from call to call, so that consecutive calls overlap each other's kernel tails.
+	const int subs = std::max(1, std::min(std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp), (int)(paths / 1500000u)));
+	const bool alternate = subs == 1;
+	if ((alternate ? 2 * paths : paths) > c->wave_capacity)
 		RF_TRY(sync_all(c));
-	RF_TRY(ensure_wave_buffers(c, paths));
-	const int subs = std::max(1, std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp));
-	RF_TRY(ensure_sub_batches(c, subs));
+	RF_TRY(ensure_wave_buffers(c, alternate ? 2 * paths : paths));
+	RF_TRY(ensure_sub_batches(c, alternate ? 2 : subs));
 	if (!c->render_pending)
 	{
 		c->render_t0 = std::chrono::steady_clock::now();
@@ -1621,28 +1664,52 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		tg.stop();
 		xor128_jump(c->jump_table, c->rng_state, (unsigned long long)packets * 32ull * (unsigned long long)c->spp);
 	}
-	if (subs > 1)
+	const bool rng_prologue = c->integrator == 0 && c->jitter == 0;
+	if (rng_prologue)
 		RF_TRY(dm::event_record(c->ev_prologue, s0));
 	const bool count = c->count_traversal != 0;
 	const uint32_t row_group = std::max(1u, c->fr.tiles_x / 4u); // primary wave: one row of 8x8 tiles per XCD group
+	const uint32_t par = c->call_parity;						 // radiance buffer set of this call
+	const bool connect = c->integrator == 1 && total_light_count(c) > 0 && c->max_depth > 0;
+	// Connection waves on a second stream hide the kernel tails of a call that is ONE sub-batch (1 spp frames: +21 %); beside
+	// other sub-batches the extra kernels in flight only evict each other's working sets (4 sub-batches, 8 spp: -8 %,
+	// 128 spp: -9 %): by default they are used when the call is a single sub-batch.
+	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1));
 	rtk::Params base;
 	fill_params(c, cam, base);
-	// ---- sub-batches ----
-	for (int i = 0; i < subs; i++)
+	base.wv.rad = c->d_rad[par].as<f4>();
+	// the connections always add into their own buffer, on a side stream or not: the image is then bit-identical whichever way
+	// a call is scheduled (e.g. the ranks of a strip split against the single-rank image)
+	base.wv.rad_nee = connect ? c->d_rad_nee[par].as<f4>() : nullptr;
+	// ---- sub-batches: each on its own stream; nothing here waits for the previous call's resolve ----
+	const int first_slot = alternate ? (int)par : 0;
+	for (int k = 0; k < subs; k++)
 	{
-		void *s = c->sub_stream[i];
-		const uint32_t s_begin = (uint32_t)((long long)c->spp * i / subs), s_end = (uint32_t)((long long)c->spp * (i + 1) / subs);
+		const int i = first_slot + k; // which set of streams / counters / buffer slices
+		void *s = c->sub_stream[i], *sc = side ? c->conn_stream[i] : c->sub_stream[i];
+		const uint32_t s_begin = (uint32_t)((long long)c->spp * k / subs), s_end = (uint32_t)((long long)c->spp * (k + 1) / subs);
 		const uint32_t spp_i = s_end - s_begin;
 		if (!spp_i)
 			continue;
-		if (i > 0)
-			RF_TRY(dm::stream_wait_event(s, c->ev_prologue)); // also orders it behind the previous call's resolve
+		if (rng_prologue)
+			RF_TRY(dm::stream_wait_event(s, c->ev_prologue));
+		if (c->resolve_recorded[par]) // the resolve of the call before the previous one read this radiance set
+			RF_TRY(dm::stream_wait_event(s, c->ev_resolve[par]));
+		// Several sub-batches start together, behind the previous call's resolve: they render the same pixels, and while they
+		// run in step their kernels share BVH nodes in the L2s (letting them drift apart costs 2-4 %)
+		if (subs > 1 && c->resolve_recorded[par ^ 1u])
+			RF_TRY(dm::stream_wait_event(s, c->ev_resolve[par ^ 1u]));
+		if (c->conn_used[i]) // the previous call's connection waves still use this sub-batch's counters and shadow buffers
+			RF_TRY(dm::stream_wait_event(s, c->ev_conn_last[i]));
 		rtk::Params p = base;
-		const size_t off = (size_t)c->fr.slots * s_begin; // this sub-batch's slice of every per-path buffer
-		for (int k = 0; k < 2; k++)
-			p.wv.org[k] += off, p.wv.dir[k] += off, p.wv.thr[k] += off;
+		const size_t off_rad = (size_t)c->fr.slots * s_begin; // this sub-batch's slice of the radiance buffers of the call
+		const size_t off = alternate ? paths * par : off_rad;	// and of every other per-path buffer
+		for (int q = 0; q < 2; q++)
+			p.wv.org[q] += off, p.wv.dir[q] += off, p.wv.thr[q] += off;
 		p.wv.hit += off, p.wv.hit_inst += off, p.wv.hit0 += off, p.wv.hit0_inst += off;
-		p.wv.sh_org += off, p.wv.sh_dir += off, p.wv.sh_rad += off, p.wv.rad += off;
+		p.wv.rad += off_rad;
+		if (p.wv.rad_nee)
+			p.wv.rad_nee += off_rad;
 		if (p.wv.packet_rng)
 			p.wv.packet_rng += (size_t)s_begin * packets * 4;
 		if (i > 0)
@@ -1652,6 +1719,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		const uint32_t n = c->fr.slots * spp_i;
 		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
+		bool conn_now = false;
 		if (c->integrator == 0)
 		{
 			p.depth = 0, p.group = row_group, p.queue = queue++;
@@ -1670,36 +1738,62 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				p.depth = (uint32_t)d;
 				p.group = d == 0 ? row_group : 16u;
 				p.queue = queue++;
+				// shadow-ray buffers of this depth's parity: shade(d) writes them, connect(d) reads them
+				p.wv.sh_org = c->d_sh_org[d & 1].as<f4>() + off, p.wv.sh_dir = c->d_sh_dir[d & 1].as<f4>() + off;
+				p.wv.sh_rad = c->d_sh_rad[d & 1].as<f4>() + off;
 				StageTimer te(c, KF_EXTEND, d, s);
 				rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
 				te.stop();
+				if (side && d >= 2 && d < c->max_depth) // connect(d - 2) read the buffers shade(d) is about to write
+					RF_TRY(dm::stream_wait_event(s, c->ev_conn[i][d - 2]));
 				StageTimer ts(c, KF_SHADE, -1, s);
 				rtk::launch_shade_pt(p, n, s);
 				ts.stop();
-				// the connections of the last shade call are never traced (CUDART/src/Context.cpp:109-120): the shade
-				// kernel does not emit them, and no wave is launched for them
-				if (total_light_count(c) && d < c->max_depth)
+				// The connection wave of depth d runs beside extend / shade of depth d + 1 on its own stream (it adds into
+				// rad_nee, they into rad).  The connections of the last shade call are never traced
+				// (CUDART/src/Context.cpp:109-120): the shade kernel does not emit them, and no wave is launched for them.
+				if (connect && d < c->max_depth)
 				{
+					if (side)
+					{
+						RF_TRY(dm::event_record(c->ev_shade[i][d], s));
+						RF_TRY(dm::stream_wait_event(sc, c->ev_shade[i][d]));
+					}
 					p.group = 16u, p.queue = queue++;
-					StageTimer tc(c, KF_CONNECT, -1, s);
-					rtk::launch_connect(p, count, n, s);
+					StageTimer tc(c, KF_CONNECT, -1, sc);
+					rtk::launch_connect(p, count, n, sc);
 					tc.stop();
+					if (side)
+					{
+						RF_TRY(dm::event_record(c->ev_conn[i][d], sc));
+						conn_now = true;
+					}
 				}
 			}
 		}
-		if (i > 0)
-			RF_TRY(dm::event_record(c->ev_sub_done[i], s));
+		RF_TRY(dm::event_record(c->ev_sub_done[i], s));
+		if (conn_now)
+			RF_TRY(dm::event_record(c->ev_conn_last[i], sc));
+		c->conn_used[i] = conn_now;
 	}
-	// ---- epilogue on stream 0: one resolve over every sample of the call ----
-	for (int i = 1; i < subs; i++)
+	// ---- epilogue on the main stream: one resolve over every sample of the call ----
+	for (int i = first_slot; i < first_slot + subs; i++)
+	{
 		RF_TRY(dm::stream_wait_event(s0, c->ev_sub_done[i]));
+		if (c->conn_used[i])
+			RF_TRY(dm::stream_wait_event(s0, c->ev_conn_last[i]));
+	}
 	{
 		StageTimer tf(c, KF_FINALIZE, -1);
 		rtk::launch_resolve(base, s0);
 		tf.stop();
 	}
+	RF_TRY(dm::event_record(c->ev_resolve[par], s0));
+	c->resolve_recorded[par] = true;
+	c->call_parity ^= 1u;
 	RF_TRY(dm::last_launch_error());
-	c->subs_last = subs;
+	c->subs_last = subs, c->subs_first = first_slot;
+	c->last_wave_off = alternate ? paths * par : 0;
 	c->samples_done += (uint32_t)c->spp;
 	c->totals.samples += (uint64_t)c->W * c->H * (uint64_t)c->spp / (uint64_t)c->world;
 	return RFWHIP_OK;
@@ -1712,12 +1806,12 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	// wave counters of the last frame, summed over its sub-batches.  A sub-batch's connection wave of depth d ran only
 	// if its depth d + 1 had extension rays (k_connect / k_trace_stream: connection_count)
 	rt::WaveCounters wc;
-	RF_TRY(dm::d2h(&wc, c->d_counters.p, sizeof(wc), c->stream));
+	RF_TRY(dm::d2h(&wc, c->subs_first == 0 ? c->d_counters.p : c->d_counters_sub[c->subs_first].p, sizeof(wc), c->stream));
 	uint32_t stack_overflow = wc.stack_overflow;
 	for (int d = 0; d + 1 < rt::MAX_DEPTH_SLOTS; d++)
 		if (!wc.ext[d + 1])
 			wc.shadow[d] = 0;
-	for (int i = 1; i < c->subs_last; i++)
+	for (int i = c->subs_first + 1; i < c->subs_first + c->subs_last; i++)
 	{
 		rt::WaveCounters w2;
 		RF_TRY(dm::d2h(&w2, c->d_counters_sub[i].p, sizeof(w2), c->stream));
@@ -1741,7 +1835,7 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		// ext[0] counts path slots (8x8 tiles, padded at the image border); primary RAYS exist for real pixels only
 		uint32_t owned_rows = 0;
 		for (uint32_t y = 0; y < c->H; y++)
-			owned_rows += ((y / 8u) % (uint32_t)c->world) == (uint32_t)c->rank;
+			owned_rows += ((y / rt::STRIP_ROWS) % (uint32_t)c->world) == (uint32_t)c->rank;
 		const uint32_t samples = c->fr.slots ? wc.ext[0] / c->fr.slots : 0u;
 		st.primaryCount = owned_rows * c->W * samples;
 	}
@@ -1914,7 +2008,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -1980,6 +2074,13 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
 		c->refill = atoi(value) & 3; // bit 0: extension waves, bit 1: shadow waves
+	else if (k == "overlap")
+	{
+		const int n = atoi(value);
+		if (n < -1 || n > 1)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "overlap must be -1 (by launch size), 0 or 1");
+		c->overlap = n;
+	}
 	else if (k == "streams")
 	{
 		const int n = atoi(value);
@@ -2020,6 +2121,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->refill);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
+	else if (k == "overlap")
+		snprintf(value, cap, "%d", c->overlap);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
@@ -2090,8 +2193,8 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	const size_t slots = c->fr.slots;
 	std::vector<f4> h(slots);
 	std::vector<int> hi(slots);
-	RF_TRY(dm::d2h(h.data(), c->d_hit0.p, slots * sizeof(f4), c->stream));
-	RF_TRY(dm::d2h(hi.data(), c->d_hit0_inst.p, slots * 4, c->stream));
+	RF_TRY(dm::d2h(h.data(), c->d_hit0.as<f4>() + c->last_wave_off, slots * sizeof(f4), c->stream));
+	RF_TRY(dm::d2h(hi.data(), c->d_hit0_inst.as<int>() + c->last_wave_off, slots * 4, c->stream));
 	const size_t n = (size_t)c->W * c->H;
 	for (size_t i = 0; i < n; i++)
 	{

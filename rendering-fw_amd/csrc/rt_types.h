@@ -33,7 +33,10 @@ struct f3
 	float x, y, z;
 };
 
-constexpr uint32_t STRIP_ROWS = 8;	  // rows per ownership strip
+#ifndef RT_STRIP_ROWS
+#define RT_STRIP_ROWS 8
+#endif
+constexpr uint32_t STRIP_ROWS = RT_STRIP_ROWS; // rows per ownership strip, a multiple of the 8-row tiles
 constexpr uint32_t TILE = 8;		  // 8x8 pixel tile = one wave64
 constexpr uint32_t ENTRY_LEAF = 0x80000000u;
 constexpr uint32_t ENTRY_TLAS = 0x40000000u;
@@ -313,7 +316,9 @@ struct WaveView
 	f4 *sh_org;	 // shadow ray origin.xyz, bits(slot)
 	f4 *sh_dir;	 // direction.xyz, tmax
 	f4 *sh_rad;	 // contribution.rgb
-	f4 *rad;	 // per-slot radiance of the batch (rgb, alpha)
+	f4 *rad;	 // per-slot radiance of the batch (rgb, alpha): written by the shade stages
+	f4 *rad_nee; // per-slot radiance added by the connection waves (they overlap the next depth's extend / shade stages, so
+				 // they must not read-modify-write the same words); null: connections add into `rad`
 	f4 *acc;	 // per local pixel accumulator (row-major local_rows x W)
 	const uint32_t *packet_rng; // parity integrator: xor128 state per (sample, packet), 4 x u32
 	WaveCounters *counters;

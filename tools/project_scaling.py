@@ -46,10 +46,31 @@ def run(rank, world, steps=10, warm=3):
     ctx.destroy()
     return dt
 
+import json, subprocess
+if len(sys.argv) > 5 and sys.argv[5] == "--one":
+    # child: one rank, one process
+    r, w = int(sys.argv[6]), int(sys.argv[7])
+    print("RANKMS %.6f" % run(r, w), flush=True)
+    sys.exit(0)
+
+def run(rank, world):  # noqa: F811 — every rank in its own process
+    out = subprocess.run([sys.executable, __file__, str(spp), str(streams), str(pipeline), "0", "--one", str(rank), str(world)],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+    return float([l for l in out.splitlines() if l.startswith("RANKMS")][0].split()[1])
+
 t1 = run(0, 1)
 print("spp", spp, "streams", streams, "pipeline", pipeline, "world 1: %.3f ms/step" % t1, flush=True)
 worlds = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 4, 8]
+rec = {"what": "single-GPU PROJECTION of the strip split (every rank of world N run alone on one MI355X with bench.py's per-step "
+               "chain, a stream-ordered copy standing in for the RCCL gather; each rank in a FRESH process like a real launch: a second "
+               "context in one process runs ~10 % slower than the first) — not a measurement of an N-GPU run",
+       "workload": scene.name, "spp_per_step": spp, "streams": streams, "pipeline": pipeline, "ms_per_step_world1": round(t1, 4),
+       "msamples_per_s_world1": round(W * H * spp / t1 / 1e3, 1), "worlds": {}}
 for world in worlds:
     ts = [run(r, world) for r in range(world)]
     tn = max(ts)
     print("world %d: slowest rank %.3f ms/step (min %.3f)  projected efficiency %.3f  ranks %s" % (world, tn, min(ts), t1 / (world * tn), " ".join("%.2f" % t for t in ts)), flush=True)
+    rec["worlds"][str(world)] = {"slowest_rank_ms": round(tn, 4), "fastest_rank_ms": round(min(ts), 4),
+                                 "projected_efficiency": round(t1 / (world * tn), 4),
+                                 "projected_msamples_per_s": round(W * H * spp / tn / 1e3, 1)}
+print("JSON " + json.dumps(rec), flush=True)
