@@ -55,6 +55,10 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
+#ifndef RT_SHADE_WAVES_PLAIN
+#define RT_SHADE_WAVES_PLAIN 5 // the shade kernel of scenes without textures: 111 registers unbounded; 4 / 5 / 6 waves ->
+								// 10.96 / 10.59 / 10.82 ms per launch (96 registers + 3 spilled dwords at 5)
+#endif
 
 // ================================================================================================================
 // per-thread context: traversal stack + compaction + statistics.  Device and host-emulation flavours.
@@ -242,7 +246,7 @@ RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	}
 }
 
-RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 {
 	const uint32_t b = p.depth & 1u, nb = b ^ 1u;
 	ShadeOut out;
@@ -284,7 +288,7 @@ RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 				WaveCounters *c = p.wv.counters;
 				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
 			}
-			pt_shade(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
+			pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
 			write_rad = true;
 		}
 	}
@@ -852,7 +856,7 @@ __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(cons
 	}
 }
 
-__global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params p)
+template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVES : RT_SHADE_WAVES_PLAIN) k_shade_pt(const Params p)
 {
 	static_assert(BLOCK == POT_STRIDE, "potential cache layout is pot[light][thread]");
 	__shared__ float s_pot[POT_CACHE * BLOCK];
@@ -905,7 +909,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 				if (wave * 64u >= nhits)
 					break; // wave-uniform: nothing left for this wave
 			}
-			shade_pt_item(p, idx, act, ctx);
+			shade_pt_item<TEX>(p, idx, act, ctx);
 		}
 		__syncthreads(); // s_list / s_wave_hits are rewritten by the next chunk
 	}
@@ -913,7 +917,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SHADE_WAVES) k_shade_pt(const Params
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
 	{
 		const uint32_t i = c * BLOCK + threadIdx.x;
-		shade_pt_item(p, i, i < count, ctx);
+		shade_pt_item<TEX>(p, i, i < count, ctx);
 	}
 #endif
 }
@@ -1146,7 +1150,10 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 {
-	hipLaunchKernelGGL(k_shade_pt, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
+	if (p.textured)
+		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
+	else
+		hipLaunchKernelGGL(k_shade_pt<false>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
 }
 
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
@@ -1287,7 +1294,7 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 	Ctx ctx;
 	const uint32_t n = p.wv.counters->ext[p.depth];
 	for (uint32_t i = 0; i < n; i++)
-		shade_pt_item(p, i, true, ctx);
+		p.textured ? shade_pt_item<true>(p, i, true, ctx) : shade_pt_item<false>(p, i, true, ctx);
 }
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)
 {

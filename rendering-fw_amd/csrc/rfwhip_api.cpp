@@ -369,6 +369,7 @@ struct rfwhip_context
 	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
 	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
+	bool textured = false; // some material carries a map
 	uint32_t tlas_root_entry = 0, instance_count = 0;
 	rt::SceneView sv;
 
@@ -718,6 +719,10 @@ extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *ma
 	RF_TRY(dm::h2d(c->d_materials.p, mats.data(), count * sizeof(rfwhip_material), c->stream));
 	RF_TRY(dm::sync(c->stream));
 	c->material_count = (uint32_t)count;
+	// does any material use a map?  (bits 2..5, 7..10: diffuse / normal / specularity / roughness maps and their extra layers)
+	c->textured = false;
+	for (size_t i = 0; i < count; i++)
+		c->textured = c->textured || (mats[i].flags & 0x7BCu) != 0;
 	c->scene_dirty = true;
 	return RFWHIP_OK;
 }
@@ -1537,6 +1542,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, (uint32_t)big->n4.size());
 	}
 	p.refill = (uint32_t)c->refill;
+	p.textured = c->textured ? 1u : 0u;
 }
 
 static int sync_all(rfwhip_context *c)

@@ -1358,6 +1358,9 @@ struct ShadeOut
 	f4 eo, ed, et; // extension ray: origin|slot<<1|flags, dir|packedN, throughput|pdf
 };
 
+// TEX = false: the scene has no material with a texture or normal map (the host knows: rfwhip_set_materials) — the texture
+// layers, their descriptors and the level-of-detail arithmetic are compiled out, which frees a fifth of the registers.
+template <bool TEX>
 RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
 					ShadeOut &out, float *pot_cache)
 {
@@ -1394,7 +1397,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	f3 Tg, Bt;
 	create_tangent_space(iN, Tg, Bt);
 	bool alpha_skip = false;
-	if (mat_flag(mflags, MF_DIFFUSE_MAP) && mat.map[0].addr < sc.texture_count)
+	if (TEX && mat_flag(mflags, MF_DIFFUSE_MAP) && mat.map[0].addr < sc.texture_count)
 	{
 		const float tu = bw0 * tu4.x + bw1 * tu4.y + bw2 * tu4.z;
 		const float tv = bw0 * tv4.x + bw1 * tv4.y + bw2 * tv4.z;
