@@ -65,15 +65,24 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 // after a refit of the BVH2 boxes: re-quantise the child boxes of the compressed 4-wide nodes of the same BLAS; src4 = four
 // BLAS-relative BVH2 node indices per 4-wide node (Node4::src of the host's collapse)
 void launch_refresh4(rt::Node4c *nodes4, const uint32_t *src4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
-// BVH construction on the device (lbvh.hip): BVH2 in device form over chunks of four Morton-consecutive triangles, boxes
-// fitted, leaf-ordered vertices written; mesh-local arrays (node_base = tri_base = 0).  nodes: 2 * ceil(n / LBVH_CHUNK) entries,
-// parents / flags the same, tri_verts 3 n.  Returns 0, or 1 when the mesh is a single leaf (build it on the host).
-#ifndef LBVH_CHUNK
-#define LBVH_CHUNK 4
-#endif
-size_t lbvh_scratch_bytes(uint32_t tri_count);
-int launch_lbvh_build(const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, void *scratch, size_t scratch_bytes,
-					  rt::Node *nodes, int *parents, rt::f4 *tri_verts, uint32_t *flags, float bounds_out_device[6], stream_t s);
+// BVH construction on the device (lbvh.hip), end to end in mesh-local arrays (node_base = tri_base = n4_base = 0):
+//   nodes / parents / flags   2 n entries   BVH2 in the reference's layout, device entries, one triangle per leaf
+//   nodes4 / src4             <= n / 4 n    the compressed 4-wide nodes the rays fetch, breadth-first, + their BVH2 sources
+//   tri_verts                 3 n           triangles in leaf (depth-first) order, w of vertex 0 = primitive id
+// Only the result record comes back (the call synchronises the stream).  Returns 0, or 1 when the mesh has fewer than two
+// triangles (build it on the host), > 1 on an error.
+struct DeviceBuildResult
+{
+	uint32_t node_count, node4_count, stack_need;
+	float bmin[3], bmax[3];
+};
+size_t device_build_scratch_bytes(uint32_t tri_count);
+int launch_device_build(const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, void *scratch, size_t scratch_bytes,
+						rt::Node *nodes, int *parents, uint32_t *flags, rt::Node4c *nodes4, uint32_t *src4, rt::f4 *tri_verts,
+						DeviceBuildResult *out, stream_t s);
+// mesh-local entries -> scene-wide indices, in place (rfwhip_update places a device-built mesh with two copies and this)
+void launch_rebase(rt::Node *nodes, uint32_t node_count, uint32_t node_base, rt::Node4c *nodes4, uint32_t n4_count, uint32_t n4_base,
+				   uint32_t tri_base, stream_t s);
 // linear-blend skinning on the device (geometry/gltf/mesh.cpp:31-45): verts/vnormals <- base * sum(w_k * M[j_k]);
 // mats: joint_count column-major 4x4
 void launch_skin_vertices(rt::f4 *verts, rt::f4 *vnormals, const rt::f4 *base_verts, const rt::f4 *base_normals,

@@ -275,6 +275,11 @@ struct MeshRec
 	DevBuf d_verts, d_indices;		   // raw vertices / indices (kept for refit)
 	DevBuf d_parents, d_flags;		   // refit helpers
 	uint32_t node_base = 0, tri_base = 0, shade_base = 0;
+	// built on the device (builder=device): no host copy of the tree; the mesh-local device arrays below are what
+	// rfwhip_update() places (device-to-device copies + an entry rebase)
+	bool device_built = false;
+	DevBuf d_b_nodes, d_b_nodes4, d_b_src, d_b_tri_verts;
+	uint32_t node_count2 = 0, n4_count = 0; // BVH2 nodes / 4-wide nodes of the mesh, whoever built them
 	int stack_need = 0;		   // worst-case traversal-stack entries of the 4-wide tree (bvh::stack_need4)
 	uint32_t max_material = 0; // largest material id any triangle refers to
 	bool resident = false; // placed in the global arrays by the last update()
@@ -349,7 +354,7 @@ struct rfwhip_context
 	int stage_timing = 0;
 	int count_traversal = 0;
 	int builder = 0;	// 0 host (binned SAH), 1 device (Morton / Karras, lbvh.hip)
-	DevBuf d_lbvh_scratch, d_lbvh_nodes, d_lbvh_tri_verts;
+	DevBuf d_lbvh_scratch;
 	int sampler = 0;	// 0 hash RNG, 1 blue noise
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
@@ -526,11 +531,12 @@ static void free_all(rfwhip_context *c)
 	for (auto &m : c->meshes)
 	{
 		DevBuf *mb[] = {&m.d_verts, &m.d_indices, &m.d_parents, &m.d_flags, &m.d_base_verts, &m.d_base_normals, &m.d_joints,
-						&m.d_weights, &m.d_vnormals, &m.d_joint_mats, &m.d_tgt_pos, &m.d_tgt_nrm, &m.d_morph_weights};
+						&m.d_weights, &m.d_vnormals, &m.d_joint_mats, &m.d_tgt_pos, &m.d_tgt_nrm, &m.d_morph_weights,
+						&m.d_b_nodes, &m.d_b_nodes4, &m.d_b_src, &m.d_b_tri_verts};
 		for (DevBuf *b : mb)
 			b->free_();
 	}
-	c->d_lbvh_scratch.free_(), c->d_lbvh_nodes.free_(), c->d_lbvh_tri_verts.free_(), c->d_blue_noise.free_();
+	c->d_lbvh_scratch.free_(), c->d_blue_noise.free_();
 	c->have_blue_noise = false;
 	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
@@ -835,12 +841,12 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 			dm::event_create(&ea), dm::event_create(&eb);
 			dm::event_record(ea, c->stream);
 		}
-		rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+		rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), m.node_count2,
 						  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 						  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, m.d_flags.as<uint32_t>(),
 						  c->stream);
 		rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
-							 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+							 m.n4_count, c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 		RF_TRY(dm::last_launch_error());
 		if (timed)
 			dm::event_record(eb, c->stream);
@@ -861,76 +867,48 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	c->scene_dirty = true;
 	const size_t n = mesh->triangleCount;
 	bool device_built = false;
-	if (c->builder == 1 && n > LBVH_CHUNK)
+	if (c->builder == 1 && n > (size_t)BLAS_MAX_LEAF)
 	{
-		// construction on the device (lbvh.hip) in mesh-local arrays; topology, boxes and leaf-ordered vertices come back
-		// and take the same road as a host-built tree (4-wide collapse, placement in update())
-		const uint32_t m2 = 2u * (uint32_t)((n + LBVH_CHUNK - 1) / LBVH_CHUNK);
-		RF_TRY(c->d_lbvh_scratch.ensure(rtk::lbvh_scratch_bytes((uint32_t)n)));
-		RF_TRY(c->d_lbvh_nodes.ensure((size_t)m2 * sizeof(rt::Node)));
-		RF_TRY(c->d_lbvh_tri_verts.ensure(3 * n * sizeof(f4)));
-		RF_TRY(m.d_parents.ensure((size_t)m2 * sizeof(int)));
-		RF_TRY(m.d_flags.ensure((size_t)m2 * sizeof(uint32_t)));
-		dm::event_t ea, eb;
-		const bool timed = c->stage_timing != 0;
-		if (timed)
-		{
-			dm::event_create(&ea), dm::event_create(&eb);
-			dm::event_record(ea, c->stream);
-		}
-		const int rc = rtk::launch_lbvh_build(m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)n,
-											  c->d_lbvh_scratch.p, c->d_lbvh_scratch.cap, c->d_lbvh_nodes.as<rt::Node>(),
-											  m.d_parents.as<int>(), c->d_lbvh_tri_verts.as<f4>(), m.d_flags.as<uint32_t>(),
-											  nullptr, c->stream);
-		if (rc != 0)
+		// Construction on the device, end to end (lbvh.hip): Morton order, locally-ordered clustering, 4-wide collapse with
+		// quantisation, depth-first triangle order — all into this mesh's own device arrays.  Only the counts, the stack
+		// need and the root box come back; rfwhip_update() places the mesh with device-to-device copies.
+		const size_t n2 = 2 * n;
+		RF_TRY(c->d_lbvh_scratch.ensure(rtk::device_build_scratch_bytes((uint32_t)n)));
+		RF_TRY(m.d_b_nodes.ensure(n2 * sizeof(rt::Node)));
+		RF_TRY(m.d_parents.ensure(n2 * sizeof(int)));
+		RF_TRY(m.d_flags.ensure(n2 * sizeof(uint32_t)));
+		RF_TRY(m.d_b_nodes4.ensure(n * sizeof(rt::Node4c)));
+		RF_TRY(m.d_b_src.ensure(4 * n * sizeof(uint32_t)));
+		RF_TRY(m.d_b_tri_verts.ensure(3 * n * sizeof(f4)));
+		const auto t0 = std::chrono::steady_clock::now();
+		rtk::DeviceBuildResult res;
+		const int rc = rtk::launch_device_build(m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)n,
+												c->d_lbvh_scratch.p, c->d_lbvh_scratch.cap, m.d_b_nodes.as<rt::Node>(),
+												m.d_parents.as<int>(), m.d_flags.as<uint32_t>(), m.d_b_nodes4.as<rt::Node4c>(),
+												m.d_b_src.as<uint32_t>(), m.d_b_tri_verts.as<f4>(), &res, c->stream);
+		if (rc > 1)
 			return set_error(RFWHIP_ERR_HIP, "rfwhip_set_mesh: device BVH build failed (%d)", rc);
 		RF_TRY(dm::last_launch_error());
-		if (timed)
-			dm::event_record(eb, c->stream);
-		m.bvh.nodes.resize(m2), m.bvh.parents.resize(m2), m.bvh.order.resize(n), m.leaf_verts.resize(3 * n);
-		RF_TRY(dm::d2h(m.bvh.nodes.data(), c->d_lbvh_nodes.p, (size_t)m2 * sizeof(rt::Node), c->stream));
-		RF_TRY(dm::d2h(m.bvh.parents.data(), m.d_parents.p, (size_t)m2 * sizeof(int), c->stream));
-		RF_TRY(dm::d2h(m.leaf_verts.data(), c->d_lbvh_tri_verts.p, 3 * n * sizeof(f4), c->stream));
-		RF_TRY(dm::sync(c->stream));
-		if (timed)
+		if (c->stage_timing)
 		{
-			c->kernel_ms[KF_REFIT] += dm::event_ms(ea, eb);
-			c->kernel_launches[KF_REFIT] += 8;
-			dm::event_destroy(ea), dm::event_destroy(eb);
+			c->kernel_ms[KF_REFIT] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			c->kernel_launches[KF_REFIT] += 1;
 		}
-		// device form -> the reference's host form (left_first = first primitive / left child, bvh_node.h:23-28)
-		for (uint32_t k = 0; k < m2; k++)
-		{
-			rt::Node &nd = m.bvh.nodes[k];
-			if (nd.count > 0)
-				nd.left_first = (int)((uint32_t)nd.left_first & rt::ENTRY_FIRST_MASK);
-			else if (nd.count < 0)
-				nd.left_first = (int)((uint32_t)nd.left_first & rt::ENTRY_INDEX_MASK);
-		}
-		for (size_t s = 0; s < n; s++)
-			memcpy(&m.bvh.order[s], &m.leaf_verts[3 * s].w, 4);
-		// depth of the Morton tree (iterative walk): the traversal stacks are sized for BLAS_DEPTH_LIMIT
-		{
-			std::vector<std::pair<int, int>> st;
-			st.push_back({0, 1});
-			int deepest = 0;
-			while (!st.empty())
-			{
-				const auto [node, depth] = st.back();
-				st.pop_back();
-				deepest = std::max(deepest, depth);
-				if (m.bvh.nodes[node].count < 0)
-					st.push_back({m.bvh.nodes[node].left_first, depth + 1}), st.push_back({m.bvh.nodes[node].left_first + 1, depth + 1});
-			}
-			m.bvh.max_depth = deepest;
-		}
-		// a Morton tree too deep for the traversal stack falls back to the host builder
-		device_built = m.bvh.max_depth <= 42;
+		// a tree too deep for the traversal stack falls back to the host builder
+		device_built = rc == 0 && (int)res.stack_need <= BLAS_STACK_BUDGET;
 		if (device_built)
 		{
-			bvh::collapse4(m.bvh, false, m.n4);
-			device_built = bvh::stack_need4(m.n4) <= BLAS_STACK_BUDGET;
+			m.node_count2 = res.node_count, m.n4_count = res.node4_count, m.stack_need = (int)res.stack_need;
+			for (int a = 0; a < 3; a++)
+				m.bounds_min[a] = res.bmin[a], m.bounds_max[a] = res.bmax[a];
+			m.bvh = bvh::Result(), m.n4.clear(), m.leaf_verts.clear();
 		}
+	}
+	m.device_built = device_built;
+	if (device_built)
+	{
+		RF_TRY(dm::sync(c->stream));
+		return RFWHIP_OK;
 	}
 	if (!device_built)
 	{
@@ -949,14 +927,14 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	}
 	for (int a = 0; a < 3; a++)
 		m.bounds_min[a] = m.bvh.nodes[0].bmin[a], m.bounds_max[a] = m.bvh.nodes[0].bmax[a];
-	if (!device_built) // (the device-built tree was collapsed when its stack need was checked)
-		bvh::collapse4(m.bvh, false, m.n4);
+	bvh::collapse4(m.bvh, false, m.n4);
+	m.node_count2 = (uint32_t)m.bvh.nodes.size(), m.n4_count = (uint32_t)m.n4.size();
 	m.stack_need = bvh::stack_need4(m.n4);
 	if (m.stack_need > BLAS_STACK_BUDGET)
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_set_mesh: the BVH of mesh %zu needs %d traversal-stack entries (budget %d)",
 						 index, m.stack_need, BLAS_STACK_BUDGET);
 	m.leaf_verts.resize(3 * n);
-	for (size_t s = 0; s < n && !device_built; s++)
+	for (size_t s = 0; s < n; s++)
 	{
 		const uint32_t prim = m.bvh.order[s];
 		uint32_t ia, ib, ic;
@@ -1069,11 +1047,11 @@ extern "C" int rfwhip_pose_mesh(rfwhip_context *c, size_t index, const float *jo
 							  (uint32_t)m.vertexCount, c->stream);
 	rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(), m.d_vnormals.as<f4>(),
 						   m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, c->stream);
-	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), m.node_count2,
 					  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
 					  (uint32_t)m.triCount, m.d_flags.as<uint32_t>(), c->stream);
 	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
-						 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+						 m.n4_count, c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 	RF_TRY(dm::last_launch_error());
 	if (timed)
 		dm::event_record(eb, c->stream);
@@ -1161,11 +1139,11 @@ extern "C" int rfwhip_morph_mesh(rfwhip_context *c, size_t index, const float *w
 							   (uint32_t)m.vertexCount, c->stream);
 	rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(), m.d_vnormals.as<f4>(),
 						   m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount, c->stream);
-	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+	rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), m.node_count2,
 					  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
 					  (uint32_t)m.triCount, m.d_flags.as<uint32_t>(), c->stream);
 	rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
-						 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+						 m.n4_count, c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 	RF_TRY(dm::last_launch_error());
 	if (timed)
 		dm::event_record(eb, c->stream);
@@ -1215,65 +1193,77 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			{
 				m.node_base = (uint32_t)nodes, m.tri_base = (uint32_t)tris, m.shade_base = (uint32_t)tris;
 				m.n4_base = (uint32_t)nodes4;
-				nodes += m.bvh.nodes.size(), tris += m.triCount, nodes4 += m.n4.size();
+				nodes += m.node_count2, tris += m.triCount, nodes4 += m.n4_count;
 			}
-		std::vector<rt::Node4c> all_nodes4(nodes4); // what the rays fetch: compressed (rt::pack_boxes4c)
-		std::vector<uint32_t> all_src(4 * nodes4);  // BVH2 node (BLAS-relative) behind each child box, for the refit
-		// resident meshes were refit on the device: save their current device data before the arrays move
-		std::vector<rt::Node> all_nodes(nodes);
-		std::vector<f4> all_verts(3 * tris);
-		std::vector<rt::TriShade> all_shade(tris);
+		if (tris > rt::ENTRY_FIRST_MASK)
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
+		c->blas_nodes4 = nodes4;
+		c->node4_capacity = nodes4 + 2 * tlas_reserve + 64;
+		if (c->node4_capacity >= (size_t(1) << 26))
+			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^26 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
+		RF_TRY(c->d_nodes.ensure(nodes * sizeof(rt::Node)));
+		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4c)));
+		RF_TRY(c->d_nodes4_src.ensure(4 * nodes4 * sizeof(uint32_t)));
+		RF_TRY(c->d_tri_verts.ensure(3 * tris * sizeof(f4)));
+		RF_TRY(c->d_tri_shade.ensure(tris * sizeof(rt::TriShade)));
+		// One mesh at a time.  Device form everywhere: left_first / entries carry ready-made stack entries (rt::make_entry)
+		// with ABSOLUTE indices — node index into the scene-wide arrays, leaf-ordered triangle index into tri_verts.
+		std::vector<rt::Node> nodes2;
+		std::vector<rt::Node4c> nodes4c;
+		std::vector<uint32_t> src;
 		for (auto &m : c->meshes)
 		{
 			if (!m.used)
 				continue;
-			memcpy(&all_nodes[m.node_base], m.bvh.nodes.data(), m.bvh.nodes.size() * sizeof(rt::Node));
-			// device form: left_first carries the ready-made stack entry (rt::make_entry) with ABSOLUTE indices —
-			// node index into the scene-wide node array / leaf-ordered triangle index into tri_verts; count is kept
-			for (size_t k = 0; k < m.bvh.nodes.size(); k++)
+			rt::Node *dn = c->d_nodes.as<rt::Node>() + m.node_base;
+			rt::Node4c *dn4 = c->d_nodes4.as<rt::Node4c>() + m.n4_base;
+			uint32_t *dsrc = c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base;
+			f4 *dtv = c->d_tri_verts.as<f4>() + 3ull * m.tri_base;
+			if (m.device_built)
 			{
-				rt::Node &nd = all_nodes[m.node_base + k];
-				if (nd.count > 0)
-					nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.tri_base, nd.count, false);
-				else if (nd.count < 0)
-					nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.node_base, nd.count, false);
+				// built on the device in mesh-local arrays: copy and rebase there, nothing touches the host
+				RF_TRY(dm::d2d(dn, m.d_b_nodes.p, (size_t)m.node_count2 * sizeof(rt::Node), c->stream));
+				RF_TRY(dm::d2d(dn4, m.d_b_nodes4.p, (size_t)m.n4_count * sizeof(rt::Node4c), c->stream));
+				RF_TRY(dm::d2d(dsrc, m.d_b_src.p, 4ull * m.n4_count * sizeof(uint32_t), c->stream));
+				RF_TRY(dm::d2d(dtv, m.d_b_tri_verts.p, 3ull * m.triCount * sizeof(f4), c->stream));
+				rtk::launch_rebase(dn, m.node_count2, m.node_base, dn4, m.n4_count, m.n4_base, m.tri_base, c->stream);
+				RF_TRY(dm::last_launch_error());
 			}
-			// 4-wide traversal nodes: entries become absolute (node index into nodes4 / triangle index into tri_verts)
-			for (size_t k = 0; k < m.n4.size(); k++)
+			else
 			{
-				rt::Node4 nd = m.n4[k];
-				for (int j = 0; j < 4; j++)
+				nodes2 = m.bvh.nodes;
+				for (rt::Node &nd : nodes2)
 				{
-					const uint32_t e = nd.entry[j];
-					if (e == rt::ENTRY_EMPTY)
-						continue;
-					if (e & rt::ENTRY_LEAF)
-						nd.entry[j] = (e & ~rt::ENTRY_FIRST_MASK) | (((e & rt::ENTRY_FIRST_MASK) + m.tri_base) & rt::ENTRY_FIRST_MASK);
-					else
-						nd.entry[j] = e + m.n4_base;
+					if (nd.count > 0)
+						nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.tri_base, nd.count, false);
+					else if (nd.count < 0)
+						nd.left_first = (int)rt::make_entry(nd.left_first + (int)m.node_base, nd.count, false);
 				}
-				all_nodes4[m.n4_base + k] = compress4(nd);
-				memcpy(&all_src[4 * (m.n4_base + k)], nd.src, 16);
+				nodes4c.resize(m.n4.size()), src.resize(4 * m.n4.size());
+				for (size_t k = 0; k < m.n4.size(); k++)
+				{
+					rt::Node4 nd = m.n4[k];
+					for (int j = 0; j < 4; j++)
+					{
+						const uint32_t e = nd.entry[j];
+						if (e == rt::ENTRY_EMPTY)
+							continue;
+						if (e & rt::ENTRY_LEAF)
+							nd.entry[j] = (e & ~rt::ENTRY_FIRST_MASK) | (((e & rt::ENTRY_FIRST_MASK) + m.tri_base) & rt::ENTRY_FIRST_MASK);
+						else
+							nd.entry[j] = e + m.n4_base;
+					}
+					nodes4c[k] = compress4(nd); // what the rays fetch: compressed (rt::pack_boxes4c)
+					memcpy(&src[4 * k], nd.src, 16); // BVH2 node (BLAS-relative) behind each child box, for the refit
+				}
+				RF_TRY(dm::h2d(dn, nodes2.data(), nodes2.size() * sizeof(rt::Node), c->stream));
+				RF_TRY(dm::h2d(dn4, nodes4c.data(), nodes4c.size() * sizeof(rt::Node4c), c->stream));
+				RF_TRY(dm::h2d(dsrc, src.data(), src.size() * sizeof(uint32_t), c->stream));
+				RF_TRY(dm::h2d(dtv, m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4), c->stream));
+				RF_TRY(dm::sync(c->stream)); // the staging vectors are reused by the next mesh
 			}
-			memcpy(&all_verts[3ull * m.tri_base], m.leaf_verts.data(), m.leaf_verts.size() * sizeof(f4));
-			memcpy(&all_shade[m.shade_base], m.shade.data(), m.shade.size() * sizeof(rt::TriShade));
+			RF_TRY(dm::h2d(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.shade.data(), m.shade.size() * sizeof(rt::TriShade), c->stream));
 		}
-		if (tris > rt::ENTRY_FIRST_MASK)
-			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
-		c->blas_nodes4 = all_nodes4.size();
-		c->node4_capacity = all_nodes4.size() + 2 * tlas_reserve + 64;
-		if (c->node4_capacity >= (size_t(1) << 26))
-			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^26 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
-		RF_TRY(c->d_nodes.ensure(all_nodes.size() * sizeof(rt::Node)));
-		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4c)));
-		RF_TRY(c->d_nodes4_src.ensure(all_src.size() * sizeof(uint32_t)));
-		RF_TRY(dm::h2d(c->d_nodes4.p, all_nodes4.data(), all_nodes4.size() * sizeof(rt::Node4c), c->stream));
-		RF_TRY(dm::h2d(c->d_nodes4_src.p, all_src.data(), all_src.size() * sizeof(uint32_t), c->stream));
-		RF_TRY(c->d_tri_verts.ensure(all_verts.size() * sizeof(f4)));
-		RF_TRY(c->d_tri_shade.ensure(all_shade.size() * sizeof(rt::TriShade)));
-		RF_TRY(dm::h2d(c->d_nodes.p, all_nodes.data(), all_nodes.size() * sizeof(rt::Node), c->stream));
-		RF_TRY(dm::h2d(c->d_tri_verts.p, all_verts.data(), all_verts.size() * sizeof(f4), c->stream));
-		RF_TRY(dm::h2d(c->d_tri_shade.p, all_shade.data(), all_shade.size() * sizeof(rt::TriShade), c->stream));
 		RF_TRY(dm::sync(c->stream));
 		// meshes that had been refit since their build are re-refit from their device vertices after the move
 		for (auto &m : c->meshes)
@@ -1282,12 +1272,12 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				continue;
 			if (m.resident && !m.dirty)
 			{
-				rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), (uint32_t)m.bvh.nodes.size(),
+				rtk::launch_refit(c->d_nodes.as<rt::Node>(), m.node_base, m.d_parents.as<int>(), m.node_count2,
 								  c->d_tri_verts.as<f4>(), m.tri_base, m.d_verts.as<f4>(),
 								  m.indexed ? m.d_indices.as<uint32_t>() : nullptr, (uint32_t)m.triCount,
 								  m.d_flags.as<uint32_t>(), c->stream);
 				rtk::launch_refresh4(c->d_nodes4.as<rt::Node4c>() + m.n4_base, c->d_nodes4_src.as<uint32_t>() + 4ull * m.n4_base,
-									 (uint32_t)m.n4.size(), c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
+									 m.n4_count, c->d_nodes.as<rt::Node>() + m.node_base, c->stream);
 				if (m.posed) // the host copy of the shading records is the bind pose
 					rtk::launch_skin_shade(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.d_verts.as<f4>(),
 										   m.d_vnormals.as<f4>(), m.indexed ? m.d_indices.as<uint32_t>() : nullptr,
@@ -1319,8 +1309,9 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			for (int r = 0; r < 3; r++)
 				d.nrm[4 * col + r] = in.normal[3 * col + r];
 		d.node_base = m.node_base, d.tri_base = m.tri_base, d.shade_base = m.shade_base;
-		d.root_entry = m.bvh.nodes[0].count < 0 ? rt::make_entry((int)m.n4_base, -1, false)
-												: rt::make_entry(m.bvh.nodes[0].left_first + (int)m.tri_base, m.bvh.nodes[0].count, false);
+		d.root_entry = (m.device_built || m.bvh.nodes[0].count < 0)
+						   ? rt::make_entry((int)m.n4_base, -1, false)
+						   : rt::make_entry(m.bvh.nodes[0].left_first + (int)m.tri_base, m.bvh.nodes[0].count, false);
 		float lo[3] = {1e34f, 1e34f, 1e34f}, hi[3] = {-1e34f, -1e34f, -1e34f};
 		for (int k = 0; k < 8; k++)
 		{
@@ -1534,12 +1525,12 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	{
 		const MeshRec *big = nullptr;
 		for (const auto &m : c->meshes)
-			if (m.used && !m.n4.empty() && (!big || m.n4.size() > big->n4.size()))
+			if (m.used && m.n4_count && (!big || m.n4_count > big->n4_count))
 				big = &m;
 		const uint32_t cap = rtk::max_lds_nodes();
 		const uint32_t want = c->lds_nodes < 0 ? cap : std::min<uint32_t>((uint32_t)c->lds_nodes, cap);
 		if (big && want)
-			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, (uint32_t)big->n4.size());
+			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, big->n4_count);
 	}
 	p.refill = (uint32_t)c->refill;
 	p.textured = c->textured ? 1u : 0u;
@@ -2348,6 +2339,38 @@ extern "C" int rfwhip_get_bvh(rfwhip_context *c, size_t mesh_index, rfwhip_bvh_n
 	if (mesh_index >= c->meshes.size() || !c->meshes[mesh_index].used)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_get_bvh: no mesh %zu", mesh_index);
 	MeshRec &m = c->meshes[mesh_index];
+	if (m.device_built)
+	{
+		// no host copy exists: fetched on demand (this is a debugging / test hook, not part of the build path)
+		if (node_count)
+			*node_count = m.node_count2;
+		if (prim_count)
+			*prim_count = m.triCount;
+		RF_TRY(sync_all(c));
+		const uint32_t nb = m.resident ? m.node_base : 0u, tb = m.resident ? m.tri_base : 0u;
+		if (nodes && node_cap)
+		{
+			const size_t n = std::min<size_t>(node_cap, m.node_count2);
+			const rt::Node *src = m.resident ? c->d_nodes.as<rt::Node>() + m.node_base : m.d_b_nodes.as<rt::Node>();
+			RF_TRY(dm::d2h(nodes, src, n * sizeof(rt::Node), c->stream));
+			for (size_t k = 0; k < n; k++) // device entries -> the reference layout (bvh_node.h:23-28), mesh-local
+			{
+				if (nodes[k].count > 0)
+					nodes[k].left_first = (int32_t)(((uint32_t)nodes[k].left_first & rt::ENTRY_FIRST_MASK) - tb);
+				else if (nodes[k].count < 0)
+					nodes[k].left_first = (int32_t)(((uint32_t)nodes[k].left_first & rt::ENTRY_INDEX_MASK) - nb);
+			}
+		}
+		if (prim_indices && prim_cap)
+		{
+			std::vector<f4> tv(3 * m.triCount);
+			const f4 *src = m.resident ? c->d_tri_verts.as<f4>() + 3ull * m.tri_base : m.d_b_tri_verts.as<f4>();
+			RF_TRY(dm::d2h(tv.data(), src, tv.size() * sizeof(f4), c->stream));
+			for (size_t k = 0; k < std::min<size_t>(prim_cap, m.triCount); k++)
+				memcpy(&prim_indices[k], &tv[3 * k].w, 4);
+		}
+		return RFWHIP_OK;
+	}
 	if (node_count)
 		*node_count = m.bvh.nodes.size();
 	if (prim_count)
