@@ -12,7 +12,7 @@ Inputs (scene, BVH, path buffers) are resident in HBM before the timed region st
 
 The JSON line carries, besides the driver contract fields:
   roofline      dominant kernel (extend = closest-hit traversal): algorithmic bytes per SURVEY §8(d)
-                (ray 32 B in [+32 B out for generated primaries], 112 B per popped 4-wide node, 52 B per triangle test,
+                (ray 32 B in [+32 B out for generated primaries], 64 B per popped inner node, 52 B per triangle test,
                 16 B hit record out) from an instrumented replay of the same frames, divided by the kernel's mean
                 duration measured with hipEvents on the render stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle's restatement of the same integrator ("port") on the host cores, bounded sample.
@@ -31,6 +31,9 @@ L2_PEAK_GBS = 34500.0  # same guide, §L2: 8 XCDs x 4 MiB, ~34.5 TB/s aggregate
 # a CU's vector L1 serves ONE divergent 16-byte lane-load per clock (profiles/micro/gather_micro.hip: 75 G 128-byte
 # records/s with 8 loads each, whatever the table size) — the ceiling the traversal kernels actually run into
 LANE_LOADS_PEAK = 600.0e9
+# the traversal node: rt::Node4c, 64 bytes = four 16-byte rows (csrc/rt_types.h) — also SURVEY §8(d)'s "64 B per popped inner node"
+NODE_BYTES = 64.0
+NODE_ROWS = 4.0
 
 
 def usable_cores():
@@ -78,7 +81,7 @@ def parse():
                          "triangles) under the same protocol, e.g. for its 8-GPU strip split")
     ap.add_argument("--integrator", default="pt", choices=["pt", "parity"])
     ap.add_argument("--max-depth", type=int, default=2)
-    ap.add_argument("--refill", type=int, default=3, help="persistent-lane traversal on the bounce / shadow waves")
+    ap.add_argument("--refill", type=int, default=7, help="persistent-lane traversal: bit 0 bounce waves, bit 1 shadow waves, bit 2 primary wave")
     ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
     ap.add_argument("--overlap", type=int, default=-1, help="connection waves on a second stream per sub-batch: 0 / 1 / -1 = by launch size")
     ap.add_argument("--lds-nodes", type=int, default=-1,
@@ -239,7 +242,7 @@ def main():
         cnt = ctx.get_counters(reset=True)
         ctx.set_setting("count_traversal", 0)
         primaries = float(W) * H * args.spp * replay / world
-        algo_bytes = (cnt["rays_extend"] * (32 + 16) + primaries * 32 + 112.0 * cnt["inner_extend"] + 52.0 * cnt["tris_extend"])
+        algo_bytes = (cnt["rays_extend"] * (32 + 16) + primaries * 32 + NODE_BYTES * cnt["inner_extend"] + 52.0 * cnt["tris_extend"])
         # one render call launches the extend kernel (max_depth + 1) x sub-batches times; the sub-batches run on their
         # own HIP streams, so launches of different sub-batches overlap and each launch's duration is stretched by the
         # share of the chip it gets.  Reported: bytes and duration of the average launch as it ran (what rocprofv3
@@ -265,9 +268,9 @@ def main():
         ser_ms_per_launch = ser_ms / max(1, ser_launches)
         ctx.set_setting("streams", args.streams)
         ctx.set_setting("spp", args.spp)
-        # vector-L1 lane-loads of the extend stage: 7 rows per 4-wide node fetched from global memory (visits served by the
-        # LDS top-of-tree cache cost none), 3 per triangle test, 2 to read the ray
-        lane_loads = (7.0 * (cnt["inner_extend"] - cnt.get("lds_extend", 0)) + 3.0 * cnt["tris_extend"] + 2.0 * cnt["rays_extend"])
+        # vector-L1 lane-loads of the extend stage: 4 rows per 64-byte 4-wide node fetched from global memory (visits served
+        # by the LDS top-of-tree cache cost none), 3 per triangle test, 2 to read the ray
+        lane_loads = (NODE_ROWS * (cnt["inner_extend"] - cnt.get("lds_extend", 0)) + 3.0 * cnt["tris_extend"] + 2.0 * cnt["rays_extend"])
         lane_loads_per_launch = lane_loads / replay / max(1.0, launches_per_step)
         pm = {}
         if os.path.exists(args.traffic_json):

@@ -149,6 +149,44 @@ def main():
         "split_ms": {"pose_mesh_update": round(t_pose / n * 1e3, 3), "render_1spp": round(t_render / n * 1e3, 3)},
         "kernel_ms_per_frame": {k: round(v_[0] / n, 4) for k, v_ in kt.items()}, "frames": n}))
 
+    # ---- config 5 on the asset it names: CesiumMan (assets/models/CesiumMan), from the committed fixture (bind pose, rig, three
+    # poses' joint matrices: tests/golden/asset_cesiumman.npz) — skin on the device, the host sends 19 joint matrices per frame ------
+    import os
+    fx_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "asset_cesiumman.npz")
+    if os.path.exists(fx_path):
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        from test_assets import _rig_scene
+        fx = np.load(fx_path)
+        scene = _rig_scene(pkg, fx["positions"], fx["normals"], fx["indices"], fx["node_transform"], W, H)
+        ctx = pkg.RenderContext(device=0)
+        ctx.init(W, H)
+        scene.upload(ctx)
+        for k, v_ in {"integrator": "pt", "spp": 1, "max_depth": 2, "stage_timing": 1}.items():
+            ctx.set_setting(k, v_)
+        ctx.set_mesh_skin(0, fx["joints"], fx["weights"], fx["normals"])
+        ctx.render_frame(scene.camera, pkg.RESET)
+        for name in ctx.KERNELS:
+            ctx.get_kernel_time(name, reset=True)
+        t_pose = t_render = 0.0
+        t_all = time.perf_counter()
+        for f in range(args.frames):
+            t0 = time.perf_counter()
+            ctx.pose_mesh(0, fx["joint_matrices"][f % len(fx["joint_matrices"])])
+            ctx.update()
+            t1 = time.perf_counter()
+            ctx.render_frame(scene.camera, pkg.RESET)
+            t2 = time.perf_counter()
+            t_pose += t1 - t0
+            t_render += t2 - t1
+        total = time.perf_counter() - t_all
+        kt = {name: ctx.get_kernel_time(name) for name in ctx.KERNELS}
+        print(json.dumps({"config": "5 (CesiumMan, device skinning)",
+            "workload": "CesiumMan (3273 vertices, 4672 triangles, 19 joints) on a floor, 1920x1080, 1 spp pt depth 2 per frame",
+            "metric": "ms/frame (wall, everything)", "value": round(total / n * 1e3, 3), "fps": round(n / total, 1),
+            "split_ms": {"pose_mesh_update": round(t_pose / n * 1e3, 3), "render_1spp": round(t_render / n * 1e3, 3)},
+            "kernel_ms_per_frame": {k: round(v_[0] / n, 4) for k, v_ in kt.items()}, "frames": n}))
+
 
 if __name__ == "__main__":
     main()

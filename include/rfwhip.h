@@ -152,8 +152,11 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   overlap      = "1": the connection (shadow) wave of depth d runs on a second stream beside extend / shade of depth d + 1
  *                  (hides kernel tails when launches are small); "0": in order on the sub-batch's stream; "-1" (default):
  *                  chosen by the size of the render call
- *   refill       = bit mask, default 3: bit 0 persistent lanes on the extension (bounce) waves, bit 1 on the shadow waves
- *                  (a lane that finishes its ray pulls the next one from the wave's queue)
+ *   sub_batch_paths = a render call's spp are cut into concurrent sub-batches only if each gets at least this many path
+ *                  slots (default 12000000)
+ *   refill       = bit mask, default 7: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,
+ *                  bit 2 the pt integrator's primary wave (a lane that finishes its ray pulls the next one from the
+ *                  wave's run of the launch's queue; the primary wave generates it)
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

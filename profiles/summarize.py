@@ -36,14 +36,14 @@ def pmc(path):
 def traffic(spp, streams, workload, tag, *paths):
     """profiles/traffic_extend.json from the PMC passes of one evidence run (FETCH_SIZE, WRITE_SIZE and TCC_REQ_sum, each in
     its own rocprofv3 --pmc pass of the same bench command): per launch of the extend stage = the primary kernel
-    k_extend<1, false> + the bounce kernel k_trace_stream<false, false>."""
+    k_primary_stream<false> (k_extend<1, false> before round 2g) + the bounce kernel k_trace_stream<false, false>."""
     import json
     tot, disp = {}, {}
     for path in paths:
         c = sqlite3.connect(path).cursor()
         for name, counter, n, total in c.execute(
                 "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
-            if "k_extend<1, false>" in name or "k_trace_stream<false, false>" in name:
+            if "k_extend<1, false>" in name or "k_primary_stream<false>" in name or "k_trace_stream<false, false>" in name:
                 tot[counter] = tot.get(counter, 0.0) + total
                 disp[counter] = disp.get(counter, 0) + n
     out = {"workload": workload, "spp": int(spp), "streams": int(streams)}
@@ -59,7 +59,7 @@ def traffic(spp, streams, workload, tag, *paths):
             out[k.lower() + "_per_extend_launch"] = int(tot[k] / disp[k])
     out["dispatches"] = disp
     out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-                         "--no-roofline` (tools/evidence.sh); extend stage = k_extend<1,false> + k_trace_stream<false,false> dispatches; "
+                         "--no-roofline` (tools/evidence.sh); extend stage = k_primary_stream<false> + k_trace_stream<false,false> dispatches; "
                          "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch, l2 bytes = TCC_REQ_sum x 128" % tag)
     print(json.dumps(out, indent=1))
 

@@ -747,12 +747,47 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #ifndef RT_SHADE_COMPACT
 #define RT_SHADE_COMPACT 1
 #endif
+// Three knobs, swept together on the MI355X (terrain_1002k, 128 spp per step; Msamples/s):
+//   refill threshold (idle lanes)   leaf vote   run length      result
+//   52 / 56                         64          per refill      2208   (round 1: every refill = one atomic on the queue head)
+//   32                              64          per refill      2153   (eager refills alone lose: the queue atomic stalls the wave)
+//   52 / 56                         32          per refill      2367
+//   32                              32          512             2514
+//   24 / 40 / 48                    32          512             2520 / 2451 / 2425
+//   32                              24 / 48     512             2503 / 2266
+//   32                              32          1024 / 2048     2512 / 2493
 #ifndef RT_REFILL_IDLE_EXT
-#define RT_REFILL_IDLE_EXT 52 // extension rays: refill once 52 of 64 lanes are idle (swept on MI355X: eager refills cost
-							  // more than they save: 1 -> -45 %; 32 / 40 / 48 / 52 / 56 / 60 / 64 -> 1900 / 1919 / 1935 / 1934 / 1934 / 1922 / 1898)
+#define RT_REFILL_IDLE_EXT 32 // extension rays: idle lanes pull new rays once 32 of the wave's 64 lanes are idle
 #endif
 #ifndef RT_REFILL_IDLE_ANY
-#define RT_REFILL_IDLE_ANY 56 // shadow rays are short: only nearly-empty waves are worth refilling (+3 %)
+#define RT_REFILL_IDLE_ANY 32 // shadow rays
+#endif
+
+// the node phase of a wave ends early once this many of its lanes hold a leaf (64: only when none is on an inner node)
+#ifndef RT_LEAF_VOTE_EXT
+#define RT_LEAF_VOTE_EXT 32
+#endif
+#ifndef RT_LEAF_VOTE_PRIMARY
+#define RT_LEAF_VOTE_PRIMARY 32
+#endif
+#ifndef RT_REFILL_IDLE_PRIMARY
+#define RT_REFILL_IDLE_PRIMARY 40 // (24 / 32 / 40: 2548 / 2548 / 2554 Msamples/s; the one-ray-per-lane primary kernel: 2494)
+#endif
+// the primary wave takes the persistent-lane form only when the launch is large (1080p: >= 8 spp per sub-batch): measured on
+// the MI355X, 32 spp per launch 6.68 -> 6.05 ms, 1 spp per launch 0.42 -> 0.61 ms (a wave then sees only ~4 tiles, and the
+// tile-row-to-XCD dealing of the one-ray-per-lane kernel is worth more than the refills)
+#ifndef RT_PRIMARY_STREAM_MIN
+#define RT_PRIMARY_STREAM_MIN (16u << 20)
+#endif
+#ifndef RT_PRIMARY_STREAM_WAVES
+#define RT_PRIMARY_STREAM_WAVES 7
+#endif
+// rays a wave takes from the launch's queue per atomic (0: one atomic per refill, exactly the idle lanes)
+#ifndef RT_STREAM_CHUNK
+#define RT_STREAM_CHUNK 512
+#endif
+#ifndef RT_LEAF_VOTE_ANY
+#define RT_LEAF_VOTE_ANY 32
 #endif
 
 __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
@@ -761,14 +796,19 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
 }
 
 
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
+// MODE: where a lane's next ray comes from — the extension-ray buffers of this depth, the shadow-ray buffers, or the
+// pt integrator's primary-ray generator (item = path slot; the ray is also stored for the shade kernel)
+enum
 {
+	STREAM_EXT = 0,
+	STREAM_ANY = 1,
+	STREAM_PRIMARY_PT = 2
+};
+
+template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(const Params &p, const uint32_t count, Ctx &ctx)
+{
+	constexpr bool ANY = MODE == STREAM_ANY;
 	WaveCounters *const wc = p.wv.counters;
-	const uint32_t count = ANY ? connection_count(wc, p.depth) : wc->ext[p.depth];
-	if (count == 0u)
-		return;
-	RT_STACK_DECL_N(ANY ? LDS_STACK_ANY : LDS_STACK, TRACE_BLOCK)
 	uint32_t *const head = &wc->work[p.queue][0];
 	const uint32_t b = p.depth & 1u;
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
@@ -781,33 +821,83 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 	const uint32_t lane = __lane_id();
 	bool has_ray = false, exhausted = false;
 	uint32_t ray = 0, slot = 0;
+#if RT_STREAM_CHUNK
+	uint32_t q_next = 0, q_end = 0; // wave-uniform: the rest of the run this wave owns
+	// run length: RT_STREAM_CHUNK for big launches, down to 64 when the launch has fewer than ~4 runs per wave
+	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
+	run = run > RT_STREAM_CHUNK ? (uint32_t)RT_STREAM_CHUNK : (run < 64u ? 64u : run);
+#endif
+	constexpr uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : (MODE == STREAM_EXT ? RT_REFILL_IDLE_EXT : RT_REFILL_IDLE_PRIMARY);
+	constexpr int VOTE = MODE == STREAM_ANY ? RT_LEAF_VOTE_ANY : (MODE == STREAM_EXT ? RT_LEAF_VOTE_EXT : RT_LEAF_VOTE_PRIMARY);
 	for (;;)
 	{
 		const unsigned long long idle_mask = __ballot(!has_ray);
 		const uint32_t nidle = (uint32_t)__popcll(idle_mask);
-		if (!exhausted && nidle >= (ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE_EXT))
+		if (!exhausted && nidle >= REFILL)
 		{
+#if RT_STREAM_CHUNK
+			// the wave owns a run of consecutive rays at a time: one queue atomic per run, refills in between are wave-local
+			if (q_next == q_end)
+			{
+				uint32_t g = 0;
+				if (lane == 0)
+					g = atomicAdd(head, run);
+				g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+				q_next = g < count ? g : count;
+				q_end = g + run < count ? g + run : count;
+			}
+			const uint32_t base = q_next;
+			const uint32_t take = nidle < q_end - q_next ? nidle : q_end - q_next;
+			q_next += take;
+			const uint32_t limit = base + take;
+#else
 			const uint32_t leader = (uint32_t)__ffsll((long long)idle_mask) - 1u;
 			uint32_t base = 0;
 			if (lane == leader)
 				base = atomicAdd(head, nidle);
 			base = __shfl(base, (int)leader);
+			const uint32_t limit = count;
+#endif
 			if (!has_ray)
 			{
 				const uint32_t idx = base + wave_prefix(idle_mask);
-				if (idx < count)
+				if (idx < limit)
 				{
-					const f4 o4 = ray_o[idx], d4 = ray_d[idx];
-					// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
-					T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
-					has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+					if (MODE == STREAM_PRIMARY_PT)
+					{
+						const PixelRef pr = slot_to_pixel(p.fr, idx);
+						if (pr.valid)
+						{
+							f3 O, D;
+							pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
+							p.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
+							p.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+							T.begin(p.sc, O, D, 1e-5f, 1e34f);
+							has_ray = true, ray = idx, nrays++;
+						}
+					}
+					else
+					{
+						const f4 o4 = ray_o[idx], d4 = ray_d[idx];
+						// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
+						T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
+						has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+					}
 				}
 			}
+#if RT_STREAM_CHUNK
+			exhausted = q_next >= count;
+#else
 			exhausted = base + nidle >= count;
+#endif
 		}
 		if (__ballot(has_ray) == 0ull)
-			break;
-		T.descend(p.sc, ctx.stk, st);
+		{
+			if (exhausted)
+				break;
+			continue; // (primary slots outside the image leave their lanes idle: take the next ones)
+		}
+		T.template descend<VOTE>(p.sc, ctx.stk, st);
 		if (has_ray)
 		{
 			T.visit(p.sc, ctx.stk, st);
@@ -826,8 +916,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 				}
 				else
 				{
-					p.wv.hit[ray] = mk4(T.hit.t, T.hit.u, T.hit.v, ubits((uint32_t)T.hit.prim));
-					p.wv.hit_inst[ray] = T.hit.inst;
+					f4 *const hb = MODE == STREAM_PRIMARY_PT ? p.wv.hit0 : p.wv.hit;
+					int *const ib = MODE == STREAM_PRIMARY_PT ? p.wv.hit0_inst : p.wv.hit_inst;
+					hb[ray] = mk4(T.hit.t, T.hit.u, T.hit.v, ubits((uint32_t)T.hit.prim));
+					ib[ray] = T.hit.inst;
 				}
 				has_ray = false;
 			}
@@ -840,6 +932,24 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 		ctx.add64(ANY ? &wc->lds_shadow : &wc->lds_extend, st.lds);
 		ctx.add64(ANY ? &wc->rays_shadow : &wc->rays_extend, nrays);
 	}
+}
+
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
+{
+	const uint32_t count = ANY ? connection_count(p.wv.counters, p.depth) : p.wv.counters->ext[p.depth];
+	if (count == 0u)
+		return;
+	RT_STACK_DECL_N(ANY ? LDS_STACK_ANY : LDS_STACK, TRACE_BLOCK)
+	stream_rays<ANY ? STREAM_ANY : STREAM_EXT, COUNT>(p, count, ctx);
+}
+
+// the pt integrator's primary wave in the same persistent-lane form: a lane generates its next primary ray itself
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primary_stream(const Params p, const uint32_t count)
+{
+	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
+	stream_rays<STREAM_PRIMARY_PT, COUNT>(p, count, ctx);
 }
 
 template <bool COUNT>
@@ -1121,6 +1231,14 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 			RT_EXT(GEN_RANGED, true);
 		else
 			RT_EXT(GEN_RANGED, false);
+	}
+	else if (gen == GEN_PT && (p.refill & 4u) && max_items >= RT_PRIMARY_STREAM_MIN)
+	{
+		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
+		if (count)
+			hipLaunchKernelGGL((k_primary_stream<true>), gt, bt, 0, st, p, max_items);
+		else
+			hipLaunchKernelGGL((k_primary_stream<false>), gt, bt, 0, st, p, max_items);
 	}
 	else if (gen == GEN_PT)
 	{

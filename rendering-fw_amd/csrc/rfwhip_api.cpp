@@ -359,8 +359,9 @@ struct rfwhip_context
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
-	int refill = 3; // bit 0: extension waves, bit 1: shadow waves
+	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
+	long long sub_batch_paths = 12000000; // a render call is cut into sub-batches only if each gets at least this many path slots
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
 	// scene (host side)
@@ -1614,10 +1615,16 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
 	if (paths >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "spp batch too large: %zu path slots (limit 2^31)", paths);
-	// Sub-batches: up to `streams`, but no launch below ~1.5 M paths (small launches are all tail: an 8-GPU rank's 2 M paths
-	// per step run 1.98 ms as one sub-batch, 2.68 ms as four).  A call that is ONE sub-batch alternates between two sets of
-	// wave buffers / streams / counters from call to call, so that consecutive calls overlap each other's kernel tails.
-	const int subs = std::max(1, std::min(std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp), (int)(paths / 1500000u)));
+	// Sub-batches: a call is cut into up to `streams` concurrent sub-batches only when that leaves every one at least
+	// `sub_batch_paths` path slots and there are four of them: since the bounce / shadow / primary kernels keep their lanes
+	// filled themselves, ONE sub-batch whose calls alternate between two sets of wave buffers / streams / counters (so that
+	// consecutive calls overlap each other's kernel tails, connection waves on a side stream) is as fast or faster up to
+	// ~40 M path slots (MI355X, 1080p terrain, Msamples/s for 1 / 2 / 4 sub-batches — 4 spp: 2029 / 1733 / 1732, 16 spp:
+	// 2399 / 2219 / 2319, 32 spp: 2329 / 2408 / 2419, 64 spp: 2555 / 2279 / 2592).
+	const long long want = (long long)paths / c->sub_batch_paths;
+	int subs = (int)std::min<long long>(std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp), want);
+	if (subs < std::min(4, c->streams))
+		subs = 1;
 	const bool alternate = subs == 1;
 	if ((alternate ? 2 * paths : paths) > c->wave_capacity)
 		RF_TRY(sync_all(c));
@@ -2005,7 +2012,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2070,7 +2077,14 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	else if (k == "lds_nodes")
 		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
-		c->refill = atoi(value) & 3; // bit 0: extension waves, bit 1: shadow waves
+		c->refill = atoi(value) & 7;
+	else if (k == "sub_batch_paths")
+	{
+		const long long n = atoll(value);
+		if (n < 1)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "sub_batch_paths must be >= 1");
+		c->sub_batch_paths = n;
+	}
 	else if (k == "overlap")
 	{
 		const int n = atoi(value);
@@ -2118,6 +2132,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->refill);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
+	else if (k == "sub_batch_paths")
+		snprintf(value, cap, "%lld", c->sub_batch_paths);
 	else if (k == "overlap")
 		snprintf(value, cap, "%d", c->overlap);
 	else

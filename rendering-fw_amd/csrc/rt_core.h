@@ -483,8 +483,13 @@ struct Traverser
 	}
 
 	// phase 1: walk 4-wide inner nodes until this lane holds a leaf entry (or ENTRY_DONE / ENTRY_SENTINEL)
-	RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
+	// VOTE < 64 (wave kernels only): the wave leaves the node phase as soon as VOTE of its lanes hold a leaf, so that
+	// those lanes do not sit idle while the others finish a long descent (lanes still on an inner node skip visit()).
+	template <int VOTE = 64> RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		const int nwork = VOTE < 64 ? __popcll(__ballot(cur != ENTRY_DONE)) : 0;
+#endif
 		while (!(cur & ENTRY_LEAF))
 		{
 			const uint32_t idx = cur & ENTRY_INDEX_MASK;
@@ -564,13 +569,23 @@ struct Traverser
 					push3(stk, e1, h1 && h0, e2, h2 && (h0 || h1), e3, h3 && (h0 || h1 || h2));
 				cur = have ? next : pop(stk);
 			}
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (VOTE < 64)
+			{
+				// only the lanes still inside this loop execute the ballot: the lanes with work that are NOT counted here
+				// are the ones already waiting with a leaf (or with a finished ray to retire)
+				const int inner = __popcll(__ballot(!(cur & ENTRY_LEAF)));
+				if (nwork - inner >= VOTE)
+					break;
+			}
+#endif
 		}
 	}
 
 	// phase 2: the leaf in hand — enter an instance (top-level leaf) or test the triangles, then fetch the next entry
 	RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st)
 	{
-		if (cur == ENTRY_DONE)
+		if (cur == ENTRY_DONE || !(cur & ENTRY_LEAF)) // (an inner node in hand: the wave left descend<VOTE>() early)
 			return;
 		if (cur == ENTRY_SENTINEL)
 		{

@@ -49,7 +49,7 @@ def test_traversal_1m_triangles(pkg, make_hip, make_oracle, terrain):
 
 
 def test_accumulation_and_subbatch_independence(pkg, make_hip, terrain):
-    a = _ctx(pkg, make_hip, terrain, spp=16, streams=4)
+    a = _ctx(pkg, make_hip, terrain, spp=16, streams=4, sub_batch_paths=1000000)
     a.render_frame(terrain.camera, pkg.RESET)
     img16 = a.framebuffer()
     b = _ctx(pkg, make_hip, terrain, spp=8, streams=1)
@@ -57,7 +57,7 @@ def test_accumulation_and_subbatch_independence(pkg, make_hip, terrain):
     b.render_frame(terrain.camera, pkg.CONVERGE)
     img8x2 = b.framebuffer()
     assert np.abs(img16 - img8x2).max() <= 1e-4 * max(1.0, float(img16.max()))
-    c = _ctx(pkg, make_hip, terrain, spp=16, streams=3)
+    c = _ctx(pkg, make_hip, terrain, spp=16, streams=3, sub_batch_paths=1000000)
     c.render_frame(terrain.camera, pkg.RESET)
     assert np.array_equal(c.framebuffer(), img16)           # 16 spp cut 4/4/4/4 or 5/5/6: same samples, same order
     st = a.get_stats()

@@ -210,7 +210,7 @@ def test_hip_golden_image_is_independent_of_the_launch_shape(pkg, make_hip):
     scene = golden_scenes.cornell_pt(pkg, 96, 64)
     ctx.init(96, 64)
     scene.upload(ctx)
-    for k, v in (("integrator", "pt"), ("spp", 4), ("max_depth", 2), ("streams", 4)):
+    for k, v in (("integrator", "pt"), ("spp", 4), ("max_depth", 2), ("streams", 4), ("sub_batch_paths", 1)):
         ctx.set_setting(k, v)
     ctx.render_frame(scene.camera, pkg.RESET)
     img = ctx.framebuffer()[..., :3]

@@ -29,3 +29,10 @@ for lds in (-1, 0):
         print("  ray", i, "gpu", a["prim"][i], a["t"][i], "oracle", b["prim"][i], b["t"][i], "u,v", (b["u"][i], b["v"][i]) if hb[i] else (a["u"][i], a["v"][i]), "tri size", np.ptp(verts.reshape(-1,3,3)[p], axis=0).max())
     both = ha & hb
     print("  prim mismatch among both-hit:", int((a["prim"][both] != b["prim"][both]).sum()), "max |dt|/t", float((np.abs(a["t"][both]-b["t"][both])/np.abs(b["t"][both])).max()))
+    scale = float(np.abs(verts).max())
+    same = both & (a["prim"] == b["prim"])
+    err = np.abs(a["t"] - b["t"]) - (1e-6 * scale + 2e-5 * np.abs(b["t"]))
+    bad = np.nonzero(same & (err > 0))[0]
+    print("  t-tolerance violations among same-prim hits:", len(bad), "scale", scale)
+    for i in bad[:10]:
+        print("   ray", i, "prim", a["prim"][i], "t gpu", a["t"][i], "t oracle", b["t"][i], "uv gpu", a["u"][i], a["v"][i], "uv oracle", b["u"][i], b["v"][i])
