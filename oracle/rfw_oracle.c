@@ -969,7 +969,12 @@ int rfwo_wait(rfwo_context *c)
 	(void)c;
 	return 0;
 }
-static int owns_row(const rfwo_context *c, uint32_t y) { return (int)((y / STRIP) % (uint32_t)c->world) == c->rank; }
+/* strips are dealt to the ranks forwards in even periods of `world` strips and backwards in odd ones (product: rt::strip_owner) */
+static int owns_row(const rfwo_context *c, uint32_t y)
+{
+	const uint32_t strip = y / STRIP, w = (uint32_t)c->world, k = strip / w, pos = strip % w;
+	return (int)((k & 1u) ? w - 1u - pos : pos) == c->rank;
+}
 uint32_t rfwo_local_rows(const rfwo_context *c)
 {
 	const uint32_t strips = (c->H + STRIP - 1) / STRIP;

@@ -497,7 +497,7 @@ RT_FN void deinterleave_item(const f4 *gathered, f4 *out, uint32_t W, uint32_t H
 	const uint32_t x = gi % W, y = gi / W;
 	if (y >= H)
 		return;
-	const uint32_t strip = y / STRIP_ROWS, rank = strip % world;
+	const uint32_t strip = y / STRIP_ROWS, rank = strip_owner(strip, world);
 	const uint32_t yl = (strip / world) * STRIP_ROWS + y % STRIP_ROWS;
 	out[gi] = gathered[((unsigned long long)rank * local_rows + yl) * W + x];
 }

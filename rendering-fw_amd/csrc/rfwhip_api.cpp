@@ -326,18 +326,22 @@ struct rfwhip_context
 	int device = 0, rank = 0, world = 1, cus = 256;
 	void *stream = nullptr; // main stream: scene uploads, refits, prologue, resolve, presents
 	static constexpr int MAX_SUB = 8;
+	static constexpr int MAX_RING = 4;
 	// every sub-batch of a render call runs on its own stream, its connection (shadow) waves on a second one beside it
 	void *sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	void *conn_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	DevBuf d_counters_sub[MAX_SUB]; // [0] is d_counters' alias slot (unused), 1.. are the extra sub-batches' counters
 	dm::event_t ev_prologue, ev_sub_done[MAX_SUB];
-	dm::event_t ev_resolve[2];								// resolve of the last call that used radiance buffer set 0 / 1
+	dm::event_t ev_resolve[MAX_RING];								// resolve of the last call that used radiance buffer set 0 / 1
 	dm::event_t ev_shade[MAX_SUB][rt::MAX_DEPTH_SLOTS];		// shade stage of depth d enqueued (its connections may start)
 	dm::event_t ev_conn[MAX_SUB][rt::MAX_DEPTH_SLOTS];		// connection wave of depth d enqueued
 	dm::event_t ev_conn_last[MAX_SUB];						// everything of the call on the connection stream
 	bool conn_used[MAX_SUB] = {false, false, false, false, false, false, false, false};
-	bool resolve_recorded[2] = {false, false};
-	uint32_t call_parity = 0; // which of the two radiance buffer sets the next render call writes
+	bool resolve_recorded[MAX_RING] = {false, false, false, false};
+	uint32_t call_slot = 0;	  // which set of the ring the next render call uses
+	int ring = 4;			  // single-sub-batch calls rotate through this many sets of wave buffers / streams / counters
+	int ring_active = 0;	  // ring size of the calls in flight (2 for calls cut into sub-batches: radiance double-buffered)
+	size_t paths_active = 0;  // path slots per call of the calls in flight
 	dm::event_t ev_present_in, ev_present_out; // hand-off to / from a caller's stream (rfwhip_*_stream)
 	bool present_pending = false;
 	bool events_ready = false;
@@ -555,7 +559,9 @@ static void free_all(rfwhip_context *c)
 		c->d_counters_sub[i].free_();
 	if (c->events_ready)
 	{
-		dm::event_destroy(c->ev_prologue), dm::event_destroy(c->ev_resolve[0]), dm::event_destroy(c->ev_resolve[1]);
+		dm::event_destroy(c->ev_prologue);
+		for (int r = 0; r < rfwhip_context::MAX_RING; r++)
+			dm::event_destroy(c->ev_resolve[r]);
 		dm::event_destroy(c->ev_present_in), dm::event_destroy(c->ev_present_out);
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
 		{
@@ -571,7 +577,9 @@ static void free_all(rfwhip_context *c)
 		c->sub_stream[i] = nullptr, c->conn_stream[i] = nullptr;
 		c->conn_used[i] = false;
 	}
-	c->resolve_recorded[0] = c->resolve_recorded[1] = false;
+	for (int r = 0; r < rfwhip_context::MAX_RING; r++)
+		c->resolve_recorded[r] = false;
+	c->ring_active = 0, c->call_slot = 0;
 	c->wave_capacity = 0;
 	c->blas_nodes4 = 0, c->node4_capacity = 0;
 }
@@ -1445,7 +1453,8 @@ static int ensure_wave_buffers(rfwhip_context *c, size_t paths)
 		RF_TRY(c->d_rad[k].ensure(b16));
 		RF_TRY(c->d_rad_nee[k].ensure(b16));
 	}
-	c->resolve_recorded[0] = c->resolve_recorded[1] = false; // (everything was synchronised above)
+	for (int r = 0; r < rfwhip_context::MAX_RING; r++) // (everything was synchronised above)
+		c->resolve_recorded[r] = false;
 	c->wave_capacity = paths;
 	return 0;
 }
@@ -1500,7 +1509,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	wv.hit = c->d_hit.as<f4>(), wv.hit_inst = c->d_hit_inst.as<int>();
 	wv.hit0 = c->d_hit0.as<f4>(), wv.hit0_inst = c->d_hit0_inst.as<int>();
 	wv.sh_org = c->d_sh_org[0].as<f4>(), wv.sh_dir = c->d_sh_dir[0].as<f4>(), wv.sh_rad = c->d_sh_rad[0].as<f4>();
-	wv.rad = c->d_rad[c->call_parity].as<f4>(), wv.rad_nee = nullptr, wv.acc = c->d_acc.as<f4>();
+	wv.rad = c->d_rad[0].as<f4>(), wv.rad_nee = nullptr, wv.acc = c->d_acc.as<f4>();
 	wv.packet_rng = c->d_packet_rng.as<uint32_t>();
 	wv.counters = c->d_counters.as<rt::WaveCounters>();
 	p.cam.blue_noise = nullptr;
@@ -1562,8 +1571,8 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 	if (!c->events_ready)
 	{
 		RF_TRY(dm::event_create(&c->ev_prologue));
-		RF_TRY(dm::event_create(&c->ev_resolve[0]));
-		RF_TRY(dm::event_create(&c->ev_resolve[1]));
+		for (int r = 0; r < rfwhip_context::MAX_RING; r++)
+			RF_TRY(dm::event_create(&c->ev_resolve[r]));
 		RF_TRY(dm::event_create(&c->ev_present_in));
 		RF_TRY(dm::event_create(&c->ev_present_out));
 		for (int i = 0; i < rfwhip_context::MAX_SUB; i++)
@@ -1626,10 +1635,20 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	if (subs < std::min(4, c->streams))
 		subs = 1;
 	const bool alternate = subs == 1;
-	if ((alternate ? 2 * paths : paths) > c->wave_capacity)
+	// ring of buffer sets: a single-sub-batch call uses set (call number mod ring) of everything — up to `ring` calls are
+	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only
+	const int ring = alternate ? c->ring : 2;
+	if ((alternate ? (size_t)ring * paths : paths) > c->wave_capacity || ring != c->ring_active || paths != c->paths_active)
+	{
+		// the calls in flight lay their records out for another ring / batch size
 		RF_TRY(sync_all(c));
-	RF_TRY(ensure_wave_buffers(c, alternate ? 2 * paths : paths));
-	RF_TRY(ensure_sub_batches(c, alternate ? 2 : subs));
+		for (int r = 0; r < rfwhip_context::MAX_RING; r++)
+			c->resolve_recorded[r] = false;
+		c->ring_active = ring, c->paths_active = paths, c->call_slot = 0;
+	}
+	RF_TRY(ensure_wave_buffers(c, alternate ? (size_t)ring * paths : paths));
+	RF_TRY(ensure_sub_batches(c, alternate ? ring : subs));
+	const bool pipelined = c->render_pending; // the caller enqueues calls without waiting for them in between
 	if (!c->render_pending)
 	{
 		c->render_t0 = std::chrono::steady_clock::now();
@@ -1673,18 +1692,20 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		RF_TRY(dm::event_record(c->ev_prologue, s0));
 	const bool count = c->count_traversal != 0;
 	const uint32_t row_group = std::max(1u, c->fr.tiles_x / 4u); // primary wave: one row of 8x8 tiles per XCD group
-	const uint32_t par = c->call_parity;						 // radiance buffer set of this call
+	const uint32_t par = c->call_slot;							 // buffer set of this call
+	const uint32_t prev = (par + (uint32_t)ring - 1u) % (uint32_t)ring; // ... and of the previous one
 	const bool connect = c->integrator == 1 && total_light_count(c) > 0 && c->max_depth > 0;
-	// Connection waves on a second stream hide the kernel tails of a call that is ONE sub-batch (1 spp frames: +21 %); beside
-	// other sub-batches the extra kernels in flight only evict each other's working sets (4 sub-batches, 8 spp: -8 %,
-	// 128 spp: -9 %): by default they are used when the call is a single sub-batch.
-	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1));
+	// Connection waves on a second stream hide the kernel tails of a call that runs alone (1 spp frames, wait after every
+	// call: 1.56 -> 1.43 ms).  When the caller pipelines its calls, the ring of buffer sets already keeps up to four launch
+	// chains in flight and the extra kernels only evict each other's working sets (1 spp: 1.17 ms without, 1.38 ms with the
+	// side stream; 16 spp: 13.2 / 14.1 ms), and the same holds beside other sub-batches (4 sub-batches, 128 spp: -9 %).
+	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1 && !pipelined));
 	rtk::Params base;
 	fill_params(c, cam, base);
-	base.wv.rad = c->d_rad[par].as<f4>();
+	base.wv.rad = alternate ? c->d_rad[0].as<f4>() + paths * par : c->d_rad[par].as<f4>();
 	// the connections always add into their own buffer, on a side stream or not: the image is then bit-identical whichever way
 	// a call is scheduled (e.g. the ranks of a strip split against the single-rank image)
-	base.wv.rad_nee = connect ? c->d_rad_nee[par].as<f4>() : nullptr;
+	base.wv.rad_nee = !connect ? nullptr : (alternate ? c->d_rad_nee[0].as<f4>() + paths * par : c->d_rad_nee[par].as<f4>());
 	// ---- sub-batches: each on its own stream; nothing here waits for the previous call's resolve ----
 	const int first_slot = alternate ? (int)par : 0;
 	for (int k = 0; k < subs; k++)
@@ -1697,12 +1718,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			continue;
 		if (rng_prologue)
 			RF_TRY(dm::stream_wait_event(s, c->ev_prologue));
-		if (c->resolve_recorded[par]) // the resolve of the call before the previous one read this radiance set
+		if (c->resolve_recorded[par]) // the resolve of the call `ring` calls ago read this radiance set
 			RF_TRY(dm::stream_wait_event(s, c->ev_resolve[par]));
 		// Several sub-batches start together, behind the previous call's resolve: they render the same pixels, and while they
 		// run in step their kernels share BVH nodes in the L2s (letting them drift apart costs 2-4 %)
-		if (subs > 1 && c->resolve_recorded[par ^ 1u])
-			RF_TRY(dm::stream_wait_event(s, c->ev_resolve[par ^ 1u]));
+		if (subs > 1 && c->resolve_recorded[prev])
+			RF_TRY(dm::stream_wait_event(s, c->ev_resolve[prev]));
 		if (c->conn_used[i]) // the previous call's connection waves still use this sub-batch's counters and shadow buffers
 			RF_TRY(dm::stream_wait_event(s, c->ev_conn_last[i]));
 		rtk::Params p = base;
@@ -1794,7 +1815,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	}
 	RF_TRY(dm::event_record(c->ev_resolve[par], s0));
 	c->resolve_recorded[par] = true;
-	c->call_parity ^= 1u;
+	c->call_slot = (par + 1u) % (uint32_t)ring;
 	RF_TRY(dm::last_launch_error());
 	c->subs_last = subs, c->subs_first = first_slot;
 	c->last_wave_off = alternate ? paths * par : 0;
@@ -1839,7 +1860,7 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		// ext[0] counts path slots (8x8 tiles, padded at the image border); primary RAYS exist for real pixels only
 		uint32_t owned_rows = 0;
 		for (uint32_t y = 0; y < c->H; y++)
-			owned_rows += ((y / rt::STRIP_ROWS) % (uint32_t)c->world) == (uint32_t)c->rank;
+			owned_rows += rt::strip_owner(y / rt::STRIP_ROWS, (uint32_t)c->world) == (uint32_t)c->rank;
 		const uint32_t samples = c->fr.slots ? wc.ext[0] / c->fr.slots : 0u;
 		st.primaryCount = owned_rows * c->W * samples;
 	}
@@ -2012,7 +2033,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2085,6 +2106,13 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "sub_batch_paths must be >= 1");
 		c->sub_batch_paths = n;
 	}
+	else if (k == "ring")
+	{
+		const int n = atoi(value);
+		if (n < 1 || n > rfwhip_context::MAX_RING)
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "ring must be in [1, %d]", (int)rfwhip_context::MAX_RING);
+		c->ring = n;
+	}
 	else if (k == "overlap")
 	{
 		const int n = atoi(value);
@@ -2134,6 +2162,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "sub_batch_paths")
 		snprintf(value, cap, "%lld", c->sub_batch_paths);
+	else if (k == "ring")
+		snprintf(value, cap, "%d", c->ring);
 	else if (k == "overlap")
 		snprintf(value, cap, "%d", c->overlap);
 	else
@@ -2225,7 +2255,7 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	const bool parity = c->integrator == 0;
 	for (uint32_t yl = 0; yl < c->fr.local_rows; yl++)
 	{
-		const uint32_t y = ((yl / rt::STRIP_ROWS) * c->world + c->rank) * rt::STRIP_ROWS + yl % rt::STRIP_ROWS;
+		const uint32_t y = rt::strip_of_local(yl / rt::STRIP_ROWS, (uint32_t)c->rank, (uint32_t)c->world) * rt::STRIP_ROWS + yl % rt::STRIP_ROWS;
 		if (y >= c->H)
 			continue;
 		for (uint32_t x = 0; x < c->W; x++)

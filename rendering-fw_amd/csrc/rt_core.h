@@ -151,7 +151,7 @@ struct PixelRef
 };
 RT_FN uint32_t local_to_global_row(const FrameView &fr, uint32_t yl)
 {
-	return ((yl / STRIP_ROWS) * fr.world + fr.rank) * STRIP_ROWS + (yl % STRIP_ROWS);
+	return strip_of_local(yl / STRIP_ROWS, fr.rank, fr.world) * STRIP_ROWS + (yl % STRIP_ROWS);
 }
 RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
 {

@@ -37,6 +37,19 @@ struct f3
 #define RT_STRIP_ROWS 8
 #endif
 constexpr uint32_t STRIP_ROWS = RT_STRIP_ROWS; // rows per ownership strip, a multiple of the 8-row tiles
+// Strip ownership: strips are dealt to the ranks in periods of `world`, forwards in even periods and backwards in odd
+// ones (0 1 .. w-1 | w-1 .. 1 0 | 0 1 ..): with the plain round-robin every strip of rank r lies 8 r rows below rank 0's,
+// and where the cost of a row grows down the image (terrain under sky) the ranks' times were in rank order, 6 % apart
+// at 8 ranks; the serpentine cancels that gradient.
+RT_FN uint32_t strip_owner(uint32_t strip, uint32_t world)
+{
+	const uint32_t k = strip / world, pos = strip % world;
+	return (k & 1u) ? world - 1u - pos : pos;
+}
+RT_FN uint32_t strip_of_local(uint32_t local_strip, uint32_t rank, uint32_t world)
+{
+	return local_strip * world + ((local_strip & 1u) ? world - 1u - rank : rank);
+}
 constexpr uint32_t TILE = 8;		  // 8x8 pixel tile = one wave64
 constexpr uint32_t ENTRY_LEAF = 0x80000000u;
 constexpr uint32_t ENTRY_TLAS = 0x40000000u;

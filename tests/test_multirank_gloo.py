@@ -81,7 +81,8 @@ def test_strip_ownership_covers_every_row_once(pkg, make_emu):
             rows = c.local_rows()
             assert rows % 8 == 0 and rows == -(-(-(-1080 // 8)) // world) * 8
             for yl in range(rows):
-                y = ((yl // 8) * world + rank) * 8 + yl % 8
+                k = yl // 8                                   # local strip k: forwards in even periods, backwards in odd ones
+                y = (k * world + (world - 1 - rank if k & 1 else rank)) * 8 + yl % 8
                 if y < 1080:
                     assert owners[y] == -1
                     owners[y] = rank

@@ -22,13 +22,20 @@ def run(rank, world, steps=10, warm=3):
     local = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0")
     flat = torch.empty((world, rows, W, 4), dtype=torch.float32, device="cuda:0")
     full = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    side = None if os.environ.get("NULL_STREAM") else torch.cuda.Stream()   # (bench.py: the chain has its own stream)
+    if side is not None:
+        torch.cuda.set_stream(side)
     ts = torch.cuda.current_stream().cuda_stream
+    mode = os.environ.get("CHAIN", "full")
     def step(first):
         ctx.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
-        if world > 1 and pipeline:
+        if os.environ.get("NO_CHAIN"):
+            pass
+        elif world > 1 and pipeline:
             ctx.read_local_framebuffer_stream(local.data_ptr(), ts)
-            flat[rank].copy_(local, non_blocking=True)   # stands in for the gather's landing copy
-            if rank == 0:
+            if mode != "present":
+                flat[rank].copy_(local, non_blocking=True)   # stands in for the gather's landing copy
+            if rank == 0 and mode == "full":
                 ctx.deinterleave_stream(flat.data_ptr(), full.data_ptr(), ts)
         elif world > 1:
             ctx.wait()
