@@ -3,6 +3,7 @@
 // half-empty wave issues faster decides whether packing the live lanes into one half of the wave is worth anything.
 // Every wave runs ITER x 32 independent v_fma_f32 (or another op) under an EXEC mask chosen by `mode`:
 //   0: all 64 lanes   1: lanes 0..31   2: lanes 0..15   3: every 4th lane (16 scattered)   4: lanes 32..63   5: lane 0 only
+//   6: lanes 0..7   7: lanes 0..3   8: lanes 0..1   9: lanes 0, 16, 32, 48
 // Reported: wave-instructions per shader clock per SIMD (s_memtime around the loop, 8 waves per SIMD resident).
 // build: hipcc --offload-arch=gfx950 -O3 valu_micro.hip -o valu_micro ; run: ./valu_micro
 #include <hip/hip_runtime.h>
@@ -32,7 +33,11 @@ __device__ __forceinline__ bool lane_on(int mode, uint32_t lane)
 	case 2: return lane < 16;
 	case 3: return (lane & 3) == 0;
 	case 4: return lane >= 32;
-	default: return lane == 0;
+	case 5: return lane == 0;
+	case 6: return lane < 8;
+	case 7: return lane < 4;
+	case 8: return lane < 2;
+	default: return (lane & 15) == 0;
 	}
 }
 
@@ -44,6 +49,9 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 	const uint32_t lane = threadIdx.x & 63;
 	float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 	const float m = 1.0000001f, c = 1e-9f;
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+	const v2f pm = {m, m}, pc = {c, c};
 	uint64_t t0 = 0, t1 = 0;
 	if (lane_on(mode, lane))
 	{
@@ -74,6 +82,13 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 							 : "v"(m), "v"(c)
 							 : "vcc");
 			}
+			else if (OP == 5)
+			{
+				// 32 packed instructions = 64 fmas per lane
+				asm volatile(REP8("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n")
+							 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+							 : "v"(pm), "v"(pc));
+			}
 			else
 			{
 				asm volatile(REP8("v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %6\n v_mov_b32 %3, %7\n")
@@ -82,13 +97,13 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 		}
 		t1 = __builtin_readcyclecounter();
 	}
-	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 	if (lane == (mode == 4 ? 32 : 0)) cyc[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
 }
 
 template <int OP> static void run(const char *name, float *out, uint64_t *cyc, uint64_t *h, int blocks)
 {
-	for (int mode = 0; mode < 6; mode++)
+	for (int mode = 0; mode < 10; mode++)
 	{
 		hipEvent_t a, b;
 		CHECK(hipEventCreate(&a));
@@ -126,5 +141,6 @@ int main()
 	run<2>("v_cvt_ub", out, cyc, h, blocks);
 	run<3>("v_cndmask", out, cyc, h, blocks);
 	run<4>("v_mov", out, cyc, h, blocks);
+	run<5>("v_pk_fma", out, cyc, h, blocks);
 	return 0;
 }

@@ -1163,11 +1163,14 @@ __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4c *nodes4, const uint32
 // do not care much (late workgroups find their queue empty), the shade kernel walks its chunks with a static stride
 // and balances better the finer that stride is.  Swept on MI355X: 8 / 16 / 32 / 64 / 128 per CU -> 1820 / 1835 /
 // 1857 / 1829 / 1780 Msamples/s (beyond 32 every extra workgroup still stages the LDS node cache and polls a queue).
+// Persistent grids: workgroups per CU, upper bound.  Re-swept after the traversal kernels took the persistent-lane form (a
+// CU holds 8 of their workgroups; more only queue up behind them): traversal 8 / 12 / 16 / 24 / 32 / 48 per CU -> 2673 /
+// 2675 / 2659 / 2640 / 2626 / 2615 Msamples/s, shade kernel 8 / 12 / 16 / 24 / 32 / 64 -> 2592 / 2612 / 2633 / 2668 / 2589 / 2584.
 #ifndef RT_GRID_BLOCKS_PER_CU
-#define RT_GRID_BLOCKS_PER_CU 32u
+#define RT_GRID_BLOCKS_PER_CU 12u
 #endif
 #ifndef RT_SHADE_BLOCKS_PER_CU
-#define RT_SHADE_BLOCKS_PER_CU RT_GRID_BLOCKS_PER_CU
+#define RT_SHADE_BLOCKS_PER_CU 16u
 #endif
 #ifndef RT_GRID_CHUNKS_PER_BLOCK
 #define RT_GRID_CHUNKS_PER_BLOCK 32u // a workgroup should find about this many 256-item chunks to be worth launching

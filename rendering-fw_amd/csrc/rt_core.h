@@ -508,9 +508,7 @@ struct Traverser
 			// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
 			// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
 			// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
-			const uint32_t ex = fbits(rows.r0.w);
-			const float Ax = ubits((ex & 255u) << 23) * id.x, Ay = ubits(((ex >> 8) & 255u) << 23) * id.y,
-						Az = ubits(((ex >> 16) & 255u) << 23) * id.z;
+			const float Ax = rows.r0.w * id.x, Ay = rows.r3.z * id.y, Az = rows.r3.w * id.z;
 			const float Bx = fmaf(rows.r0.x, id.x, -oid.x), By = fmaf(rows.r0.y, id.y, -oid.y), Bz = fmaf(rows.r0.z, id.z, -oid.z);
 			const uint32_t lox = fbits(rows.r2.x), loy = fbits(rows.r2.y), loz = fbits(rows.r2.z);
 			const uint32_t hix = fbits(rows.r2.w), hiy = fbits(rows.r3.x), hiz = fbits(rows.r3.y);

@@ -116,19 +116,19 @@ static_assert(sizeof(Node4) == 128, "4-wide node");
 // to 8 bits per plane in the frame of the node's own box (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs
 // through compressed wide BVHs", 2017): plane = org + q * 2^e per axis, q rounded OUTWARD, so every compressed box contains
 // the float box it came from — the set of triangles a ray reaches, and therefore every hit, is unchanged.
-//   row 0: org.x org.y org.z | exps (biased exponent bytes ex | ey << 8 | ez << 16)
+//   row 0: org.x org.y org.z | scale.x            (scale = 2^e as a float: no decode in the loop)
 //   row 1: entry[4]
 //   row 2: qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (one byte per child, byte k = child k)
-//   row 3: qhi.y[4] qhi.z[4] 0 0
+//   row 3: qhi.y[4] qhi.z[4] | scale.y scale.z
 // An unused slot has an inverted box (qlo = 255, qhi = 0) and ENTRY_EMPTY: never hit.
 struct alignas(16) Node4c
 {
 	float org[3];
-	uint32_t exps;
+	float scale_x;
 	uint32_t entry[4];
 	uint32_t qlo[3];
 	uint32_t qhi[3];
-	uint32_t pad[2];
+	float scale_y, scale_z;
 };
 static_assert(sizeof(Node4c) == 64, "compressed 4-wide node");
 
@@ -136,7 +136,6 @@ static_assert(sizeof(Node4c) == 64, "compressed 4-wide node");
 // (upload) and the device (after a refit), so both produce the same bytes.
 RT_FN void pack_boxes4c(Node4c &n, const float lo[3][4], const float hi[3][4], const bool valid[4])
 {
-	n.exps = 0u;
 	for (int a = 0; a < 3; a++)
 	{
 		float mn = 3.0e38f, mx = -3.0e38f;
@@ -154,7 +153,7 @@ RT_FN void pack_boxes4c(Node4c &n, const float lo[3][4], const float hi[3][4], c
 		}
 		const float scale = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
 		n.org[a] = mn;
-		n.exps |= (uint32_t)(e + 127) << (8 * a);
+		(a == 0 ? n.scale_x : (a == 1 ? n.scale_y : n.scale_z)) = scale;
 		uint32_t ql4 = 0u, qh4 = 0u;
 		for (int k = 0; k < 4; k++)
 		{
@@ -174,7 +173,6 @@ RT_FN void pack_boxes4c(Node4c &n, const float lo[3][4], const float hi[3][4], c
 		}
 		n.qlo[a] = ql4, n.qhi[a] = qh4;
 	}
-	n.pad[0] = n.pad[1] = 0u;
 }
 
 // Per-instance record (set_instance): inverse transform for rays, normal matrix for shading, BLAS location.
