@@ -32,6 +32,7 @@ L2_PEAK_GBS = 34500.0  # same guide, §L2: 8 XCDs x 4 MiB, ~34.5 TB/s aggregate
 # records/s with 8 loads each, whatever the table size) — the ceiling the traversal kernels actually run into
 LANE_LOADS_PEAK = 600.0e9
 # the traversal node: rt::Node4c, 64 bytes = four 16-byte rows (csrc/rt_types.h) — also SURVEY §8(d)'s "64 B per popped inner node"
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave64 instructions per second, chip: 256 CUs x 4 SIMDs, one 4-clock instruction at a time
 NODE_BYTES = 64.0
 NODE_ROWS = 4.0
 
@@ -217,6 +218,7 @@ def main():
     fence()
     for name in ctx.KERNELS:
         ctx.get_kernel_time(name, reset=True)
+    ctx.get_counters(reset=True)  # also re-arms the device-side clock of the extend stage
     del gather_ms[:]
     t_start = time.perf_counter()
     for k in range(args.steps):
@@ -230,6 +232,7 @@ def main():
     if world == 1:
         ctx.read_framebuffer_device(full_fb.data_ptr())
     kernel_times = {name: ctx.get_kernel_time(name) for name in ctx.KERNELS}
+    clock = ctx.get_counters(reset=False)  # extend stage on the device's own clock: first workgroup in .. last workgroup out
     stats = ctx.get_stats().as_dict()
 
     samples = float(W) * H * args.spp * args.steps
@@ -256,7 +259,13 @@ def main():
         # shows), and the mean number of kernels in flight (sum of all kernel durations / wall time) beside it.
         launches_per_step = ext_launches / max(1, args.steps)
         bytes_per_launch = algo_bytes / replay / max(1.0, launches_per_step)
-        ms_per_launch = ext_ms / max(1, ext_launches)
+        # Duration of the average extend launch.  Two clocks: HIP events recorded on the launch's stream around it (they
+        # include the time a launch waits for CU slots while other streams' persistent kernels hold them), and the kernels'
+        # own first-workgroup-in / last-workgroup-out timestamps (100 MHz device counter) — the quantity a rocprofv3 kernel
+        # trace reports, and the one `achieved` is computed from; both are in the line.
+        ms_events = ext_ms / max(1, ext_launches)
+        ms_device = clock["extend_ticks"] * 1e-5 / max(1, clock["extend_launches_timed"])
+        ms_per_launch = ms_device if clock["extend_launches_timed"] else ms_events
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
         concurrency = busy_ms / (elapsed * 1e3) if elapsed > 0 else 1.0
@@ -289,12 +298,15 @@ def main():
                 pm = {}
         traffic = pm.get("hbm_bytes_per_extend_launch")
         l2_bytes = pm.get("l2_bytes_per_extend_launch")
+        valu_insts = pm.get("sq_insts_valu_per_extend_launch")
         ser_s = ser_ms_per_launch * 1e-3
         roofline = {
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": ms_per_launch,
-            "launches_timed": ext_launches, "launches_per_step": launches_per_step,
+            "ms_per_launch_clock": "device (first workgroup in .. last workgroup out)" if clock["extend_launches_timed"] else "hip events",
+            "ms_per_launch_hip_events": ms_events, "achieved_hip_events": round(bytes_per_launch / (ms_events * 1e-3) / 1e9, 2) if ms_events > 0 else None,
+            "launches_timed": ext_launches, "launches_timed_device_clock": clock["extend_launches_timed"], "launches_per_step": launches_per_step,
             "kernels_in_flight": round(concurrency, 3),
             "achieved_x_kernels_in_flight": round(achieved * max(1.0, concurrency), 2),
             "per_ray": {"inner_nodes": cnt["inner_extend"] / max(1, cnt["rays_extend"]),
@@ -321,7 +333,14 @@ def main():
                 "l1_lane_load_rate": round(lane_loads_per_launch / ser_s / 1e9, 2) if ser_s > 0 else None,
                 "l1_lane_load_peak": LANE_LOADS_PEAK / 1e9, "l1_lane_load_unit": "G lane-loads/s",
                 "l1_lane_load_frac": round(lane_loads_per_launch / ser_s / LANE_LOADS_PEAK, 5) if ser_s > 0 else None,
-                "binding_ceiling": "vector-L1 lane-load rate (with VALU issue at 15-31 of 64 lanes active: profiles/r02*_pmc_sq*.md)",
+                # VALU issue (PMC: SQ_INSTS_VALU per launch, profiles/) against one 4-clock wave64 instruction per SIMD and clock
+                # group (1024 SIMDs x 2.4 GHz / 4; 2-clock instructions such as v_mov issue faster: profiles/micro/valu_micro.hip)
+                "valu_wave_insts_per_launch": valu_insts,
+                "valu_issue_rate": round(valu_insts / ser_s / 1e9, 2) if (valu_insts and ser_s > 0) else None,
+                "valu_issue_peak": VALU_ISSUE_PEAK / 1e9, "valu_issue_unit": "G wave-instructions/s",
+                "valu_issue_frac": round(valu_insts / ser_s / VALU_ISSUE_PEAK, 5) if (valu_insts and ser_s > 0) else None,
+                "valu_lanes_active_of_64": pm.get("valu_lanes_active_extend"),
+                "binding_ceiling": "VALU issue at the lane utilisation above (divergent traversal); the vector-L1 lane-load rate is the second ceiling",
             },
             "hbm_traffic_gbs": round(traffic / (ms_per_launch * 1e-3) / 1e9, 2) if (traffic and ms_per_launch > 0) else None,
         }

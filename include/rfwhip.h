@@ -177,6 +177,8 @@ typedef struct rfwhip_counters
 	uint64_t samples;		 /* pixel samples started */
 	uint64_t lds_extend;	 /* of inner_extend: visits served by the LDS top-of-tree cache (no vector-L1 lane-loads) */
 	uint64_t lds_shadow;	 /* of inner_shadow: the same */
+	uint64_t extend_ticks;	 /* extend-stage kernels, first workgroup in to last workgroup out, summed: ticks of the 100 MHz device clock */
+	uint64_t extend_launches_timed; /* launches in extend_ticks */
 } rfwhip_counters;
 RFWHIP_API int rfwhip_get_counters(rfwhip_context *ctx, rfwhip_counters *out, int reset);
 

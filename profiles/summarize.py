@@ -54,9 +54,14 @@ def traffic(spp, streams, workload, tag, *paths):
     if "TCC_REQ_sum" in tot:
         out["l2_requests_per_extend_launch"] = int(tot["TCC_REQ_sum"] / disp["TCC_REQ_sum"])
         out["l2_bytes_per_extend_launch"] = int(tot["TCC_REQ_sum"] / disp["TCC_REQ_sum"] * 128)  # 128-byte lines
-    for k in ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"):
+    for k in ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"):
         if k in tot:
             out[k.lower() + "_per_extend_launch"] = int(tot[k] / disp[k])
+    if "SQ_THREAD_CYCLES_VALU" in tot and "SQ_ACTIVE_INST_VALU" in tot:
+        # lanes active per VALU instruction (thread-cycles over instruction-cycles, both in 4-clock units)
+        out["valu_lanes_active_extend"] = round(tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_ACTIVE_INST_VALU"], 2)
+    if "SQ_WAIT_ANY" in tot and "SQ_WAVE_CYCLES" in tot:
+        out["wave_cycles_waiting_frac_extend"] = round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 4)
     out["dispatches"] = disp
     out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                          "--no-roofline` (tools/evidence.sh); extend stage = k_primary_stream<false> + k_trace_stream<false,false> dispatches; "

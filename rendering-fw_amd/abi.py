@@ -126,7 +126,8 @@ class Counters(C.Structure):
                 ("tris_extend", C.c_uint64), ("inner_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
                 ("shaded", C.c_uint64), ("samples", C.c_uint64),
                 # rendercore only (the oracle fills the first eight): node visits served by the LDS top-of-tree cache
-                ("lds_extend", C.c_uint64), ("lds_shadow", C.c_uint64)]
+                ("lds_extend", C.c_uint64), ("lds_shadow", C.c_uint64),
+                ("extend_ticks", C.c_uint64), ("extend_launches_timed", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

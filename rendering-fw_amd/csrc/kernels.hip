@@ -448,6 +448,12 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
 	c->ext[0] = primary_count;
 	c->probe_valid = 0u;
 	c->stack_overflow = 0u;
+	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
+	{
+		if (c->t_last[d] > c->t_first[d])
+			c->ext_ticks += c->t_last[d] - c->t_first[d], c->ext_timed++;
+		c->t_first[d] = ~0ull, c->t_last[d] = 0ull;
+	}
 }
 
 RT_FN uint32_t local_pixel_to_slot(const FrameView &fr, uint32_t x, uint32_t yl)
@@ -722,9 +728,22 @@ template <int NTHREADS> __device__ __forceinline__ void stage_top(const Params &
 	__syncthreads();
 }
 
+// first workgroup in / last workgroup out of an extend-stage launch (WaveCounters::t_first / t_last)
+__device__ __forceinline__ void clock_in(WaveCounters *wc, uint32_t depth)
+{
+	if (threadIdx.x == 0)
+		atomicMin(&wc->t_first[depth], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void clock_out(WaveCounters *wc, uint32_t depth)
+{
+	if (threadIdx.x == 0)
+		atomicMax(&wc->t_last[depth], (unsigned long long)wall_clock64());
+}
+
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
+	clock_in(p.wv.counters, p.depth);
 	RT_STACK_DECL_CLOSEST
 	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext[p.depth] : fixed_count;
 	ChunkQueue w(p, count);
@@ -735,6 +754,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 		if (c < w.nchunks)
 			extend_item<GEN, COUNT>(p, i, i < count, ctx);
 	}
+	clock_out(p.wv.counters, p.depth);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -940,16 +960,22 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 	const uint32_t count = ANY ? connection_count(p.wv.counters, p.depth) : p.wv.counters->ext[p.depth];
 	if (count == 0u)
 		return;
+	if (!ANY)
+		clock_in(p.wv.counters, p.depth);
 	RT_STACK_DECL_N(ANY ? LDS_STACK_ANY : LDS_STACK, TRACE_BLOCK)
 	stream_rays<ANY ? STREAM_ANY : STREAM_EXT, COUNT>(p, count, ctx);
+	if (!ANY)
+		clock_out(p.wv.counters, p.depth);
 }
 
 // the pt integrator's primary wave in the same persistent-lane form: a lane generates its next primary ray itself
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primary_stream(const Params p, const uint32_t count)
 {
+	clock_in(p.wv.counters, 0);
 	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
 	stream_rays<STREAM_PRIMARY_PT, COUNT>(p, count, ctx);
+	clock_out(p.wv.counters, 0);
 }
 
 template <bool COUNT>

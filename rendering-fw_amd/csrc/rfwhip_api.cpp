@@ -2199,10 +2199,18 @@ extern "C" int rfwhip_get_counters(rfwhip_context *c, rfwhip_counters *out, int 
 		out->inner_shadow += wc.inner_shadow, out->tris_shadow += wc.tris_shadow;
 		out->shaded += wc.shaded;
 		out->lds_extend += wc.lds_extend, out->lds_shadow += wc.lds_shadow;
+		// the device-side clock of the extend stage: launches already folded + the ones of the most recent call
+		out->extend_ticks += wc.ext_ticks, out->extend_launches_timed += wc.ext_timed;
+		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+			if (wc.t_last[d] > wc.t_first[d])
+				out->extend_ticks += wc.t_last[d] - wc.t_first[d], out->extend_launches_timed++;
 		if (reset)
 		{
 			wc.rays_extend = wc.rays_shadow = wc.inner_extend = wc.tris_extend = wc.inner_shadow = wc.tris_shadow = wc.shaded = 0;
 			wc.lds_extend = wc.lds_shadow = 0;
+			wc.ext_ticks = 0, wc.ext_timed = 0;
+			for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+				wc.t_first[d] = ~0ull, wc.t_last[d] = 0ull;
 			RF_TRY(dm::h2d(buf, &wc, sizeof(wc), c->stream));
 			RF_TRY(dm::sync(c->stream));
 		}

@@ -7,13 +7,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
 mkdir -p $R/gpurun_out
-cd $R && timeout 900 python bench.py --stage-rates > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-tail -c 1500 gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
-d=$R/gpurun_out/${tag}_stats; rm -rf $d
-(cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $d -- python bench.py > $d.log 2>&1)
-(cd $R && python profiles/summarize.py stats $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_kernel_stats.md; head -12 gpurun_out/${tag}_kernel_stats.md)
-dbs=""
 pass() { # name counters...
   name=$1; shift
   d=$R/gpurun_out/${tag}_pmc_$name; rm -rf $d
@@ -22,10 +16,16 @@ pass() { # name counters...
   (cd $R && python profiles/summarize.py pmc $db > gpurun_out/${tag}_pmc_$name.md; head -6 gpurun_out/${tag}_pmc_$name.md)
   echo $db
 }
+# counter passes first: bench.py reads the traffic figures derived from them (same code, same box)
 f=$(pass fetch FETCH_SIZE | tail -1)
 w=$(pass write WRITE_SIZE | tail -1)
 t=$(pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum | tail -1)
 p=$(pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum | tail -1)
-pass sq_issue SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY > /dev/null
-pass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE > /dev/null
-(cd $R && python profiles/summarize.py traffic 128 4 terrain_1002k "$tag" $f $w $t $p > gpurun_out/${tag}_traffic_extend.json; cat gpurun_out/${tag}_traffic_extend.json)
+q=$(pass sq_issue SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY | tail -1)
+l=$(pass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE | tail -1)
+(cd $R && python profiles/summarize.py traffic 128 4 terrain_1002k "$tag" $f $w $t $p $q $l > gpurun_out/${tag}_traffic_extend.json; cat gpurun_out/${tag}_traffic_extend.json; cp gpurun_out/${tag}_traffic_extend.json profiles/traffic_extend.json)
+cd $R && timeout 900 python bench.py --stage-rates > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -c 1500 gpurun_out/${tag}_bench.json
+d=$R/gpurun_out/${tag}_stats; rm -rf $d
+(cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $d -- python bench.py > $d.log 2>&1)
+(cd $R && python profiles/summarize.py stats $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_kernel_stats.md; head -12 gpurun_out/${tag}_kernel_stats.md)
