@@ -1,5 +1,6 @@
 /*
- * rfw_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  PARITY UNPINNED — see rfw_oracle.h.
+ * rfw_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  PARITY UNPINNED against the reference's binaries —
+ * what pins it instead: rfw_oracle.h.
  *
  * Restates, in plain C, what the reference computes on the north-star path:
  *   camera view              RFW/system/context/rfw/context/Camera.cpp:74-115

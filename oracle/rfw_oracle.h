@@ -5,12 +5,17 @@
  * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under rendering-fw_amd/
  * may include, link or call it.
  *
- * PARITY UNPINNED: the reference ships no tests, golden images or known-answer vectors, and neither its Embree
- * rendercore (needs Embree 3, TBB, glm, GLEW, a GL context) nor its in-tree BVH (needs a Rust crate fetched from
- * the network) can be compiled in this image.  What pins this restatement instead:
+ * PARITY UNPINNED against the reference's own binaries: the reference ships no tests, golden images or known-answer
+ * vectors, and neither its Embree rendercore (Embree 3, TBB, glm, GLEW, a GL context), its CUDA rendercore, its BSDF
+ * headers (glm) nor its in-tree BVH (a Rust crate fetched from the network) can be compiled in this image
+ * (SURVEY.md §0.3, §8c).  What pins this restatement within that limit:
+ *   - the one reference file that does compile here: blue_noise.h, built by `make -C oracle ref` into
+ *     oracle/_ref/libbluenoise.so — the sampler is checked against the REAL tables (crc32s of SURVEY §2) and sampler
+ *     outputs / a render using them are committed under tests/golden/,
+ *   - an independent numpy float32 restatement of BOTH integrators written from the reference text
+ *     (tests/golden/make_golden.py, make_golden_pt.py): known-answer tables for the BSDF / light-sampling / packing
+ *     functions and brute-force renders with per-depth wave counts, committed under tests/golden/,
  *   - known answers derived by hand from the reference's integer arithmetic (xor128.h:20-27, tools.h:218-235),
- *   - an independent numpy float32 brute-force renderer (tests/golden/make_golden.py) whose outputs are committed
- *     under tests/golden/,
  *   - its own brute-force (no-BVH) mode.
  *
  * The interface mirrors include/rfwhip.h one-to-one (prefix rfwo_ instead of rfwhip_), so the parity tests drive
