@@ -438,22 +438,29 @@ RT_FN uint32_t connection_count(const WaveCounters *c, uint32_t depth)
 	return c->ext[depth + 1] ? c->shadow[depth] : 0u;
 }
 
-RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count)
+// Re-arms the per-call part of the counters; thread t of nt takes a strided share (one thread doing the ~500 dependent
+// stores alone took 0.6-1.4 ms on a busy chip — at the head of every launch chain).
+RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t t, uint32_t nt)
 {
-	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
-		c->ext[d] = 0u, c->shadow[d] = 0u;
-	for (int q = 0; q < WORK_QUEUES; q++)
-		for (int x = 0; x < 8; x++)
-			c->work[q][x] = 0u;
-	c->ext[0] = primary_count;
-	c->probe_valid = 0u;
-	c->stack_overflow = 0u;
-	for (int d = 0; d < MAX_DEPTH_SLOTS; d++)
+	for (uint32_t d = t; d < (uint32_t)MAX_DEPTH_SLOTS; d += nt)
 	{
-		if (c->t_last[d] > c->t_first[d])
+		c->ext[d] = d == 0u ? primary_count : 0u, c->shadow[d] = 0u;
+		if (c->t_last[d] > c->t_first[d]) // fold the previous call's extend-stage clock
+		{
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicAdd(&c->ext_ticks, c->t_last[d] - c->t_first[d]);
+			atomicAdd(&c->ext_timed, 1u);
+#else
 			c->ext_ticks += c->t_last[d] - c->t_first[d], c->ext_timed++;
+#endif
+		}
 		c->t_first[d] = ~0ull, c->t_last[d] = 0ull;
 	}
+	uint32_t *const work = &c->work[0][0];
+	for (uint32_t q = t; q < (uint32_t)WORK_QUEUES * 8u; q += nt)
+		work[q] = 0u;
+	if (t == 0u)
+		c->probe_valid = 0u, c->stack_overflow = 0u;
 }
 
 RT_FN uint32_t local_pixel_to_slot(const FrameView &fr, uint32_t x, uint32_t yl)
@@ -1112,8 +1119,8 @@ void launch_kat(const Params &p, int function, const float *in, float *out, uint
 
 __global__ void k_init_counters(WaveCounters *c, uint32_t primary_count)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0)
-		init_counters_item(c, primary_count);
+	if (blockIdx.x == 0)
+		init_counters_item(c, primary_count, threadIdx.x, blockDim.x);
 }
 __global__ void k_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count)
 {
@@ -1215,7 +1222,7 @@ static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID
 
 void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t s)
 {
-	hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, (hipStream_t)s, c, primary_count);
+	hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(256), 0, (hipStream_t)s, c, primary_count);
 }
 
 void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t s)
@@ -1404,7 +1411,7 @@ void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t 
 
 void set_device_cus(int) {}
 uint32_t max_lds_nodes() { return MAX_LDS_NODES; }
-void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count); }
+void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count, 0u, 1u); }
 void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = count; }
 
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
