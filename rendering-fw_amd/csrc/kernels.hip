@@ -735,6 +735,11 @@ template <int NTHREADS> __device__ __forceinline__ void stage_top(const Params &
 	__syncthreads();
 }
 
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // first workgroup in / last workgroup out of an extend-stage launch (WaveCounters::t_first / t_last)
 __device__ __forceinline__ void clock_in(WaveCounters *wc, uint32_t depth)
 {
@@ -771,9 +776,6 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 // stay busy although rays of one wave need very different numbers of steps (measured lane utilisation of the
 // one-ray-per-lane form on the bounce waves: 18-30 %).
 // ----------------------------------------------------------------------------------------------------------------
-#ifndef RT_SHADE_COMPACT
-#define RT_SHADE_COMPACT 1
-#endif
 // Three knobs, swept together on the MI355X (terrain_1002k, 128 spp per step; Msamples/s):
 //   refill threshold (idle lanes)   leaf vote   run length      result
 //   52 / 56                         64          per refill      2208   (round 1: every refill = one atomic on the queue head)
@@ -817,10 +819,6 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #define RT_LEAF_VOTE_ANY 32
 #endif
 
-__device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask)
-{
-	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 
 // MODE: where a lane's next ray comes from — the extension-ray buffers of this depth, the shadow-ray buffers, or the
@@ -1008,61 +1006,57 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ctx.stk.overflow = nullptr, ctx.stk.stride = 0;
 	ctx.pot = s_pot + threadIdx.x;
 	const uint32_t count = p.wv.counters->ext[p.depth];
-	const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
-#if RT_SHADE_COMPACT
-	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by
-	// lane on the bounce waves (PMC: 34 of 64 lanes active per VALU instruction).  Per chunk of 256 paths: pass 0 shades
-	// the misses in place, pass 1 the hits through a workgroup-compacted index list — the first waves are full of hits,
-	// the rest of the workgroup skips the pass.  Which lane shades a path does not affect its result.
-	__shared__ uint32_t s_list[BLOCK];
-	__shared__ uint32_t s_wave_hits[BLOCK / 64];
+	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by lane
+	// on the bounce waves.  Every WAVE keeps its own queue of hit paths in LDS: it walks 64-path chunks, shades a chunk's
+	// misses in place and appends its hits to the queue; whenever 64 hits are queued it shades them as one full wave.
+	// No workgroup barrier anywhere (round 1's per-256 compaction parked the waves without hits at a barrier, holding
+	// their SIMD slots, while the others shaded), and the expensive path always runs with all lanes.  Which lane shades a
+	// path does not affect its result.
+	__shared__ uint32_t s_hits[BLOCK / 64][128];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
-	{
-		const uint32_t i = c * BLOCK + threadIdx.x;
-		bool valid = i < count;
-		if (p.depth == 0 && valid)
-			valid = slot_to_pixel(p.fr, i).valid;
-		bool is_hit = false;
-		if (valid)
-			is_hit = (int)fbits((p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i].w) >= 0;
-		const unsigned long long m = __ballot(is_hit);
-		if (lane == 0)
-			s_wave_hits[wave] = (uint32_t)__popcll(m);
-		__syncthreads();
-		uint32_t base = 0, nhits = 0;
-		for (uint32_t w = 0; w < BLOCK / 64; w++)
-		{
-			const uint32_t n = s_wave_hits[w];
-			base += w < wave ? n : 0u;
-			nhits += n;
-		}
-		if (is_hit)
-			s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
-		__syncthreads();
+	uint32_t *const q = s_hits[wave];
+	const f4 *const hits = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
+	const uint32_t nchunks = (count + 63u) / 64u;
+	const uint32_t nwaves = gridDim.x * (BLOCK / 64u);
+	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
+	uint32_t nq = 0;								// queued hits (wave-uniform)
 #pragma nounroll
-		for (int pass = 0; pass < 2; pass++)
-		{
-			uint32_t idx = i;
-			bool act = valid && !is_hit;
-			if (pass == 1)
-			{
-				act = threadIdx.x < nhits;
-				idx = act ? s_list[threadIdx.x] : 0u;
-				if (wave * 64u >= nhits)
-					break; // wave-uniform: nothing left for this wave
-			}
-			shade_pt_item<TEX>(p, idx, act, ctx);
-		}
-		__syncthreads(); // s_list / s_wave_hits are rewritten by the next chunk
-	}
-#else
-	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+	for (;;)
 	{
-		const uint32_t i = c * BLOCK + threadIdx.x;
-		shade_pt_item<TEX>(p, i, i < count, ctx);
+		uint32_t idx = 0;
+		bool act = false;
+		if (nq >= 64u || (c >= nchunks && nq > 0u))
+		{
+			// one wave of queued hits; the rest of the queue moves down
+			const uint32_t n = nq < 64u ? nq : 64u, rest = nq - n;
+			act = lane < n;
+			idx = act ? q[lane] : 0u;
+			const uint32_t moved = lane < rest ? q[64u + lane] : 0u;
+			if (lane < rest)
+				q[lane] = moved;
+			nq = rest;
+		}
+		else if (c < nchunks)
+		{
+			idx = c * 64u + lane;
+			c += nwaves;
+			bool valid = idx < count;
+			if (p.depth == 0 && valid)
+				valid = slot_to_pixel(p.fr, idx).valid;
+			const bool is_hit = valid && (int)fbits(hits[idx].w) >= 0;
+			const unsigned long long m = __ballot(is_hit);
+			if (is_hit)
+				q[nq + wave_prefix(m)] = idx;
+			nq += (uint32_t)__popcll(m);
+			act = valid && !is_hit;
+			if (__ballot(act) == 0ull)
+				continue;
+		}
+		else
+			break;
+		__builtin_amdgcn_wave_barrier();
+		shade_pt_item<TEX>(p, idx, act, ctx);
 	}
-#endif
 }
 
 template <bool COUNT>

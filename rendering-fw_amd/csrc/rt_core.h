@@ -498,13 +498,19 @@ struct Traverser
 			if (rel < stk.top_count)
 			{
 				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u));
+#if !defined(RT_DIAG_PHASES)
 				if (COUNT)
 					st.lds++;
+#endif
 			}
 			else // byte offset of the node in the table (tables stay below 4 GiB)
 				rows = load_rows<true>((const char *)sc.nodes4, idx << 6);
 			if (COUNT)
 				st.inner++;
+#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+			if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
+				st.lds++; // wave-level iterations of the node loop (leader lane)
+#endif
 			// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
 			// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
 			// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
@@ -615,8 +621,13 @@ struct Traverser
 		{
 			const f4 *tv = sc.tri_verts + 3u * (first + i);
 			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+			if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
+				st.tris++; // wave-level iterations of the triangle loop (leader lane)
+#else
 			if (COUNT)
 				st.tris++;
+#endif
 			if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
 			{
 				hit.prim = (int)fbits(v0.w);
