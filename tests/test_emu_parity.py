@@ -293,3 +293,49 @@ def test_device_skinning_equals_host_skinning(pkg, make_emu, make_oracle, orc):
     live.render_frame(scene.camera, pkg.RESET)
     frac, rmse, _ = image_stats(live.framebuffer(), before, 1e-4)
     assert frac <= 1e-3, (frac, rmse)
+
+
+def _pipelined(pkg, ctx, scene, w, h, settings, calls, wait_every):
+    ctx.init(w, h)
+    scene.upload(ctx)
+    for k, v in settings.items():
+        ctx.set_setting(k, v)
+    for f in range(calls):
+        ctx.render_async(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+        if wait_every and (f + 1) % wait_every == 0:
+            ctx.wait()
+    ctx.wait()
+    return ctx.framebuffer()
+
+
+@pytest.mark.parametrize("integrator", ["pt", "parity"])
+def test_image_is_independent_of_how_calls_are_scheduled(pkg, make_emu, integrator):
+    """Ring of buffer sets (1, 2, 4), pipelined or waited-for calls, one sub-batch or four per call, connection waves on
+    a side stream or not: the same samples in the same order, bit for bit."""
+    scene = pkg.scenes.cornell(64, 48)
+    base = {"integrator": integrator, "spp": 4, "max_depth": 2}
+    ref = _pipelined(pkg, make_emu(), scene, 64, 48, dict(base, ring=1, streams=1), 6, 1)
+    for extra, wait_every in (({"ring": 2}, 0), ({"ring": 4}, 0), ({"ring": 4}, 3), ({"ring": 4, "overlap": 1}, 0),
+                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2)):
+        img = _pipelined(pkg, make_emu(), scene, 64, 48, dict(base, **extra), 6, wait_every)
+        assert np.array_equal(img, ref), (extra, wait_every)
+
+
+def test_changing_the_batch_size_between_pipelined_calls(pkg, make_emu):
+    """spp changes while calls are in flight: the ring is re-laid out behind a synchronisation; 2 + 4 + 2 samples in three
+    calls == 8 samples one by one."""
+    scene = pkg.scenes.cornell(64, 48)
+    a = make_emu()
+    a.init(64, 48)
+    scene.upload(a)
+    a.set_setting("integrator", "pt")
+    for k, spp in enumerate((2, 4, 2)):
+        a.set_setting("spp", spp)
+        a.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+    a.wait()
+    b = _pipelined(pkg, make_emu(), scene, 64, 48, {"integrator": "pt", "spp": 1, "ring": 1}, 8, 1)
+    assert np.abs(a.framebuffer() - b).max() <= 1e-5
+    with pytest.raises(RuntimeError):
+        a.set_setting("ring", 5)
+    with pytest.raises(RuntimeError):
+        a.set_setting("sub_batch_paths", 0)

@@ -429,3 +429,17 @@ def test_bench_workload_path_traced_image_vs_oracle(pkg, make_hip, make_oracle):
     for name in ("primaryCount", "secondaryCount", "deepCount", "shadowCount"):
         x, y = getattr(sa, name), getattr(sb, name)
         assert abs(x - y) <= 2e-4 * y, (name, x, y)
+
+
+@pytest.mark.parametrize("integrator", ["pt", "parity"])
+def test_image_is_independent_of_how_calls_are_scheduled_gpu(pkg, make_hip, integrator):
+    """The same on the real streams: ring of 1 / 2 / 4 buffer sets with eight calls in flight, calls cut into sub-batches,
+    connection waves on a side stream, a wait every third call — bit-identical images."""
+    from test_emu_parity import _pipelined
+    scene = pkg.scenes.cornell(480, 272)
+    base = {"integrator": integrator, "spp": 4, "max_depth": 2}
+    ref = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, ring=1, streams=1), 8, 1)
+    for extra, wait_every in (({"ring": 2}, 0), ({"ring": 4}, 0), ({"ring": 4}, 3), ({"ring": 4, "overlap": 1}, 0),
+                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2)):
+        img = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, **extra), 8, wait_every)
+        assert np.array_equal(img, ref), (extra, wait_every)
