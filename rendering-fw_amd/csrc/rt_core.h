@@ -82,6 +82,11 @@ RT_FN float ubits(uint32_t u)
 
 RT_FN float half_to_float(uint16_t h)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	// v_cvt_f32_f16 (exact, f16 denormals are enabled in the kernels' mode register).  The branchy form below put every
+	// half field of a material into its own basic block: six dependent load-wait round trips per shaded hit.
+	return (float)__builtin_bit_cast(_Float16, h);
+#endif
 	const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
 	const uint32_t exp = (h >> 10) & 0x1Fu;
 	uint32_t man = h & 0x3FFu;
