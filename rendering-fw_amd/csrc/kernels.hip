@@ -70,20 +70,35 @@ struct Ctx
 	TravStack stk;
 	float *pot = nullptr; // this lane's column of the light-potential cache (shade kernel)
 
-	// wave-aggregated slot allocation: returns the compacted index for lanes with flag set
-	__device__ __forceinline__ uint32_t compact(bool flag, uint32_t *counter)
+	// Block-wise slot allocation of the shade kernel's two output queues (rt_types.h: QUEUE_BLOCK).  Wave-uniform state.
+	struct OutQueue
+	{
+		uint32_t pos = 0, end = 0, rays = 0;
+	};
+	OutQueue q_ext, q_shadow;
+	uint32_t q_block = QUEUE_BLOCK;
+	__device__ __forceinline__ uint32_t alloc(OutQueue &q, bool flag, uint32_t *queue_len)
 	{
 		const unsigned long long mask = __ballot(flag);
-		if (mask == 0ull)
+		const uint32_t n = (uint32_t)__popcll(mask);
+		if (n == 0u)
 			return 0u;
-		const uint32_t lane = __lane_id();
-		const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-		uint32_t base = 0;
-		if (lane == leader)
-			base = atomicAdd(counter, (uint32_t)__popcll(mask));
-		base = __shfl(base, (int)leader);
+		const uint32_t room = q.end - q.pos; // (q_block == 0: exact mode — pos == end always, every call reserves its n slots)
+		uint32_t fresh = 0;
+		if (n > room) // (wave-uniform) the outputs that do not fit the rest of this block start a new one
+		{
+			if (__lane_id() == 0u)
+				fresh = atomicAdd(queue_len, q_block ? q_block : n);
+			fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)fresh);
+		}
 		const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-		return base + prefix;
+		const uint32_t slot = prefix < room ? q.pos + prefix : fresh + (prefix - room);
+		if (n > room)
+			q.pos = fresh + (n - room), q.end = fresh + (q_block ? q_block : n);
+		else
+			q.pos += n;
+		q.rays += n;
+		return slot;
 	}
 	__device__ __forceinline__ void add64(unsigned long long *dst, uint32_t v)
 	{
@@ -111,7 +126,19 @@ struct Ctx
 		// emulation: the "LDS" rows alias the node table (TOP_ROWS = 8), the range check is the device's
 		stk.top = (const f4 *)(p.sc.nodes4 + p.lds_first), stk.top_first = p.lds_first, stk.top_count = p.lds_count;
 	}
-	uint32_t compact(bool flag, uint32_t *counter) { return flag ? (*counter)++ : 0u; }
+	// (emulation: one slot at a time, no blocks, no void entries — queue length == ray count)
+	struct OutQueue
+	{
+		uint32_t rays = 0;
+	};
+	OutQueue q_ext, q_shadow;
+	uint32_t alloc(OutQueue &q, bool flag, uint32_t *queue_len)
+	{
+		if (!flag)
+			return 0u;
+		q.rays++;
+		return (*queue_len)++;
+	}
 	void add64(unsigned long long *dst, uint32_t v) { *dst += v; }
 };
 
@@ -134,6 +161,11 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 			O = xyz(o4), D = xyz(d4);
 			if (GEN == GEN_RANGED)
 				t_min = o4.w, t_max = d4.w;
+			else if (fbits(o4.w) == RAY_VOID) // the unfilled rest of a wave's last queue block
+			{
+				p.wv.hit[i] = mk4(0, 0, 0, ubits((uint32_t)HIT_VOID));
+				active = false;
+			}
 		}
 	}
 	else
@@ -309,14 +341,14 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		}
 	}
 	WaveCounters *c = p.wv.counters;
-	const uint32_t si = ctx.compact(out.emit_shadow, &c->shadow[p.depth]);
+	const uint32_t si = ctx.alloc(ctx.q_shadow, out.emit_shadow, &c->shadow_n[p.depth]);
 	if (out.emit_shadow)
 	{
 		p.wv.sh_org[si] = out.so;
 		p.wv.sh_dir[si] = out.sd;
 		p.wv.sh_rad[si] = out.se;
 	}
-	const uint32_t ei = ctx.compact(out.emit_ext, &c->ext[p.depth + 1]);
+	const uint32_t ei = ctx.alloc(ctx.q_ext, out.emit_ext, &c->ext_n[p.depth + 1]);
 	if (out.emit_ext)
 	{
 		p.wv.org[nb][ei] = out.eo;
@@ -334,7 +366,9 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		const f4 o4 = p.wv.sh_org[i], d4 = p.wv.sh_dir[i];
 		Hit h;
-		if (!trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st))
+		if (d4.w < 0.0f) // void entry
+			active = false;
+		else if (!trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st))
 		{
 			const f4 e4 = p.wv.sh_rad[i];
 			const uint32_t slot = fbits(o4.w);
@@ -435,7 +469,7 @@ RT_FN void kat_item(const Params &p, int function, const float *in, float *out, 
 // (`while (activePaths > 0 && ...)`); evaluated on the device, per wavefront batch — no host read-back.
 RT_FN uint32_t connection_count(const WaveCounters *c, uint32_t depth)
 {
-	return c->ext[depth + 1] ? c->shadow[depth] : 0u;
+	return c->ext[depth + 1] ? c->shadow_n[depth] : 0u; // (queue length: includes the void entries of unfinished blocks)
 }
 
 // Re-arms the per-call part of the counters; thread t of nt takes a strided share (one thread doing the ~500 dependent
@@ -444,7 +478,7 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t 
 {
 	for (uint32_t d = t; d < (uint32_t)MAX_DEPTH_SLOTS; d += nt)
 	{
-		c->ext[d] = d == 0u ? primary_count : 0u, c->shadow[d] = 0u;
+		c->ext[d] = c->ext_n[d] = d == 0u ? primary_count : 0u, c->shadow[d] = c->shadow_n[d] = 0u;
 		if (c->t_last[d] > c->t_first[d]) // fold the previous call's extend-stage clock
 		{
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -757,7 +791,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 {
 	clock_in(p.wv.counters, p.depth);
 	RT_STACK_DECL_CLOSEST
-	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext[p.depth] : fixed_count;
+	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : fixed_count;
 	ChunkQueue w(p, count);
 	uint32_t c;
 	while (w.next(c))
@@ -904,9 +938,18 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 					else
 					{
 						const f4 o4 = ray_o[idx], d4 = ray_d[idx];
-						// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
-						T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
-						has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+						// void entries (the unfilled rest of a shade wave's last queue block) are skipped
+						if (ANY ? d4.w < 0.0f : fbits(o4.w) == RAY_VOID)
+						{
+							if (!ANY)
+								p.wv.hit[idx] = mk4(0, 0, 0, ubits((uint32_t)HIT_VOID));
+						}
+						else
+						{
+							// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
+							T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
+							has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+						}
 					}
 				}
 			}
@@ -962,7 +1005,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
 {
-	const uint32_t count = ANY ? connection_count(p.wv.counters, p.depth) : p.wv.counters->ext[p.depth];
+	const uint32_t count = ANY ? connection_count(p.wv.counters, p.depth) : p.wv.counters->ext_n[p.depth];
 	if (count == 0u)
 		return;
 	if (!ANY)
@@ -1005,7 +1048,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
 	ctx.stk.overflow = nullptr, ctx.stk.stride = 0;
 	ctx.pot = s_pot + threadIdx.x;
-	const uint32_t count = p.wv.counters->ext[p.depth];
+	const uint32_t count = p.wv.counters->ext_n[p.depth];
 	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by lane
 	// on the bounce waves.  Every WAVE keeps its own queue of hit paths in LDS: it walks 64-path chunks, shades a chunk's
 	// misses in place and appends its hits to the queue; whenever 64 hits are queued it shades them as one full wave.
@@ -1018,6 +1061,12 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	const f4 *const hits = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
 	const uint32_t nchunks = (count + 63u) / 64u;
 	const uint32_t nwaves = gridDim.x * (BLOCK / 64u);
+	// queue block: QUEUE_BLOCK slots for big launches; a launch so small that a wave would leave most of a block empty
+	// reserves exactly what each call emits instead (no void entries; the atomics are few then)
+	{
+		const uint32_t per_wave = count / (nwaves * 4u);
+		ctx.q_block = per_wave > QUEUE_BLOCK ? QUEUE_BLOCK : (per_wave < 64u ? 0u : per_wave);
+	}
 	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
 	uint32_t nq = 0;								// queued hits (wave-uniform)
 #pragma nounroll
@@ -1043,12 +1092,13 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			bool valid = idx < count;
 			if (p.depth == 0 && valid)
 				valid = slot_to_pixel(p.fr, idx).valid;
-			const bool is_hit = valid && (int)fbits(hits[idx].w) >= 0;
+			const int prim = valid ? (int)fbits(hits[idx].w) : HIT_VOID;
+			const bool is_hit = prim >= 0;
 			const unsigned long long m = __ballot(is_hit);
 			if (is_hit)
 				q[nq + wave_prefix(m)] = idx;
 			nq += (uint32_t)__popcll(m);
-			act = valid && !is_hit;
+			act = prim == -1; // a miss; HIT_VOID entries (unfilled queue slots) are nobody's path
 			if (__ballot(act) == 0ull)
 				continue;
 		}
@@ -1056,6 +1106,20 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			break;
 		__builtin_amdgcn_wave_barrier();
 		shade_pt_item<TEX>(p, idx, act, ctx);
+	}
+	// what is left of this wave's last queue blocks becomes void entries; the ray counts go to the statistics
+	WaveCounters *const wc = p.wv.counters;
+	const uint32_t nb = (p.depth & 1u) ^ 1u;
+	for (uint32_t s = ctx.q_ext.pos + lane; s < ctx.q_ext.end; s += 64u)
+		p.wv.org[nb][s] = mk4(0, 0, 0, ubits(RAY_VOID));
+	for (uint32_t s = ctx.q_shadow.pos + lane; s < ctx.q_shadow.end; s += 64u)
+		p.wv.sh_dir[s] = mk4(0, 0, 1, -1.0f);
+	if (lane == 0u)
+	{
+		if (ctx.q_ext.rays)
+			atomicAdd(&wc->ext[p.depth + 1], ctx.q_ext.rays);
+		if (ctx.q_shadow.rays)
+			atomicAdd(&wc->shadow[p.depth], ctx.q_shadow.rays);
 	}
 }
 
@@ -1119,7 +1183,7 @@ __global__ void k_init_counters(WaveCounters *c, uint32_t primary_count)
 __global__ void k_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0)
-		c->ext[depth] = count;
+		c->ext[depth] = c->ext_n[depth] = count;
 }
 
 struct RngBase
@@ -1296,6 +1360,9 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 		hipLaunchKernelGGL((k_shade_parity<false>), g, b, 0, (hipStream_t)s, p, max_items);
 }
 
+// slots the void entries of one shade launch over max_items paths can take beyond the rays themselves (per queue)
+uint32_t queue_pad(uint32_t max_items) { return persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU) * (BLOCK / 64u) * QUEUE_BLOCK; }
+
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 {
 	if (p.textured)
@@ -1406,7 +1473,7 @@ void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t 
 void set_device_cus(int) {}
 uint32_t max_lds_nodes() { return MAX_LDS_NODES; }
 void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count, 0u, 1u); }
-void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = count; }
+void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = c->ext_n[depth] = count; }
 
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
 					   uint32_t packets_per_sample, uint32_t spp, stream_t)
@@ -1418,7 +1485,7 @@ void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uin
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
 	Ctx ctx(p);
-	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext[p.depth] : max_items;
+	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : max_items;
 	for (uint32_t i = 0; i < n; i++)
 	{
 		if (gen == GEN_BUFFER)
@@ -1437,12 +1504,14 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 	for (uint32_t i = 0; i < max_items; i++)
 		count ? shade_parity_item<true>(p, i, true, ctx) : shade_parity_item<false>(p, i, true, ctx);
 }
+uint32_t queue_pad(uint32_t) { return 0u; }
 void launch_shade_pt(const Params &p, uint32_t, stream_t)
 {
 	Ctx ctx;
-	const uint32_t n = p.wv.counters->ext[p.depth];
+	const uint32_t n = p.wv.counters->ext_n[p.depth];
 	for (uint32_t i = 0; i < n; i++)
 		p.textured ? shade_pt_item<true>(p, i, true, ctx) : shade_pt_item<false>(p, i, true, ctx);
+	p.wv.counters->ext[p.depth + 1] += ctx.q_ext.rays, p.wv.counters->shadow[p.depth] += ctx.q_shadow.rays;
 }
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)
 {

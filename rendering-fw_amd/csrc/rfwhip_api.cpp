@@ -342,6 +342,7 @@ struct rfwhip_context
 	int ring = 4;			  // single-sub-batch calls rotate through this many sets of wave buffers / streams / counters
 	int ring_active = 0;	  // ring size of the calls in flight (2 for calls cut into sub-batches: radiance double-buffered)
 	size_t paths_active = 0;  // path slots per call of the calls in flight
+	int subs_active = 0;	  // ... and their sub-batch count
 	dm::event_t ev_present_in, ev_present_out; // hand-off to / from a caller's stream (rfwhip_*_stream)
 	bool present_pending = false;
 	bool events_ready = false;
@@ -1638,15 +1639,19 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	// ring of buffer sets: a single-sub-batch call uses set (call number mod ring) of everything — up to `ring` calls are
 	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only
 	const int ring = alternate ? c->ring : 2;
-	if ((alternate ? (size_t)ring * paths : paths) > c->wave_capacity || ring != c->ring_active || paths != c->paths_active)
+	if (ring != c->ring_active || paths != c->paths_active || subs != c->subs_active)
 	{
 		// the calls in flight lay their records out for another ring / batch size
 		RF_TRY(sync_all(c));
 		for (int r = 0; r < rfwhip_context::MAX_RING; r++)
 			c->resolve_recorded[r] = false;
-		c->ring_active = ring, c->paths_active = paths, c->call_slot = 0;
+		c->ring_active = ring, c->paths_active = paths, c->subs_active = subs, c->call_slot = 0;
 	}
-	RF_TRY(ensure_wave_buffers(c, alternate ? (size_t)ring * paths : paths));
+	// the extension / shadow queues are filled in blocks (rt_types.h: QUEUE_BLOCK): every sub-batch's slice of the per-ray
+	// buffers has room for the void entries of its waves' last blocks behind the rays
+	const size_t pad = rtk::queue_pad((uint32_t)std::min<size_t>(paths, 0xFFFFFFFFu));
+	const size_t wave_slots = alternate ? (size_t)ring * (paths + pad) : paths + (size_t)subs * pad;
+	RF_TRY(ensure_wave_buffers(c, wave_slots));
 	RF_TRY(ensure_sub_batches(c, alternate ? ring : subs));
 	const bool pipelined = c->render_pending; // the caller enqueues calls without waiting for them in between
 	if (!c->render_pending)
@@ -1728,7 +1733,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			RF_TRY(dm::stream_wait_event(s, c->ev_conn_last[i]));
 		rtk::Params p = base;
 		const size_t off_rad = (size_t)c->fr.slots * s_begin; // this sub-batch's slice of the radiance buffers of the call
-		const size_t off = alternate ? paths * par : off_rad;	// and of every other per-path buffer
+		const size_t off = alternate ? (paths + pad) * par : off_rad + (size_t)k * pad; // and of every per-ray buffer (padded)
 		for (int q = 0; q < 2; q++)
 			p.wv.org[q] += off, p.wv.dir[q] += off, p.wv.thr[q] += off;
 		p.wv.hit += off, p.wv.hit_inst += off, p.wv.hit0 += off, p.wv.hit0_inst += off;
@@ -1818,7 +1823,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	c->call_slot = (par + 1u) % (uint32_t)ring;
 	RF_TRY(dm::last_launch_error());
 	c->subs_last = subs, c->subs_first = first_slot;
-	c->last_wave_off = alternate ? paths * par : 0;
+	c->last_wave_off = alternate ? (paths + pad) * par : 0;
 	c->samples_done += (uint32_t)c->spp;
 	c->totals.samples += (uint64_t)c->W * c->H * (uint64_t)c->spp / (uint64_t)c->world;
 	return RFWHIP_OK;

@@ -300,10 +300,21 @@ struct FrameView
 // shadow[d] = shadow rays emitted by the shade stage of depth d.
 constexpr int MAX_DEPTH_SLOTS = 16;
 constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch of a render call
+// The extension / shadow queues are filled in BLOCKS: a wave of the shade kernel reserves QUEUE_BLOCK slots with one atomic
+// and hands them out wave-locally (a device-scope atomic on one address completes about every 7 ns on this part: one per
+// shade call and queue was 1 M atomics = 7 ms per 32-spp launch — the whole shade kernel).  What a wave has left of its last
+// block when the kernel ends is filled with VOID entries (extension ray: slot bits all ones; shadow ray: tmax < 0), which
+// the consumers skip; the hit record of a void extension ray carries HIT_VOID so that the next shade stage skips it too.
+// ext_n / shadow_n are the queue lengths including void entries (what the consumers iterate over), ext / shadow the rays.
+constexpr uint32_t QUEUE_BLOCK = 256u;
+constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w of a void extension-queue entry
+constexpr int HIT_VOID = -2;			   // hit.prim of a void entry (-1: miss)
 struct WaveCounters
 {
 	uint32_t ext[MAX_DEPTH_SLOTS];
 	uint32_t shadow[MAX_DEPTH_SLOTS];
+	uint32_t ext_n[MAX_DEPTH_SLOTS];
+	uint32_t shadow_n[MAX_DEPTH_SLOTS];
 	uint32_t work[WORK_QUEUES][8]; // per launch, per XCD: head of the chunk queue the persistent workgroups pull from
 	unsigned long long rays_extend, rays_shadow, inner_extend, tris_extend, inner_shadow, tris_shadow, shaded, samples;
 	unsigned long long lds_extend, lds_shadow; // node visits served by the LDS top-of-tree cache
