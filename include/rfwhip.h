@@ -153,7 +153,7 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  (hides kernel tails when launches are small); "0": in order on the sub-batch's stream; "-1" (default):
  *                  chosen by the size of the render call
  *   sub_batch_paths = a render call's spp are cut into concurrent sub-batches only if each gets at least this many path
- *                  slots and there are four of them (default 24000000)
+ *                  slots and there are four of them (default 50000000)
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 4)
  *   refill       = bit mask, default 7: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,

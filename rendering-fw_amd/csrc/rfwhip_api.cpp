@@ -366,7 +366,7 @@ struct rfwhip_context
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
 	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
-	long long sub_batch_paths = 24000000; // a render call is cut into sub-batches only if each gets at least this many path slots
+	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
 	// scene (host side)
@@ -1629,8 +1629,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	// `sub_batch_paths` path slots and there are four of them: since the bounce / shadow / primary kernels keep their lanes
 	// filled themselves, ONE sub-batch whose calls alternate between two sets of wave buffers / streams / counters (so that
 	// consecutive calls overlap each other's kernel tails, connection waves on a side stream) is as fast or faster up to
-	// ~100 M path slots (MI355X, 1080p terrain, Msamples/s as one sub-batch on the ring / cut into four — 8 spp: 2391 / 2194,
-	// 16 spp: 2544 / 2370, 32 spp: 2556 / 2452, 64 spp: 2453 / 2620).
+	// ~200 M path slots (MI355X, 1080p terrain, Msamples/s as one sub-batch on the ring / cut into four — 16 spp: 2635 / 2366,
+	// 32 spp: 2693 / 2515, 64 spp: 2741 / 2665; beyond that the ring's four sets of path state no longer fit comfortably).
 	const long long want = (long long)paths / c->sub_batch_paths;
 	int subs = (int)std::min<long long>(std::min(std::min(c->streams, (int)rfwhip_context::MAX_SUB), c->spp), want);
 	if (subs < std::min(4, c->streams))
@@ -1638,7 +1638,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const bool alternate = subs == 1;
 	// ring of buffer sets: a single-sub-batch call uses set (call number mod ring) of everything — up to `ring` calls are
 	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only
-	const int ring = alternate ? c->ring : 2;
+	const int ring = alternate ? (paths > 150000000u ? std::min(c->ring, 2) : c->ring) : 2; // (4 x 200 B x 150 M = 120 GB)
 	if (ring != c->ring_active || paths != c->paths_active || subs != c->subs_active)
 	{
 		// the calls in flight lay their records out for another ring / batch size
