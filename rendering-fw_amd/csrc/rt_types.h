@@ -306,7 +306,10 @@ constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch
 // block when the kernel ends is filled with VOID entries (extension ray: slot bits all ones; shadow ray: tmax < 0), which
 // the consumers skip; the hit record of a void extension ray carries HIT_VOID so that the next shade stage skips it too.
 // ext_n / shadow_n are the queue lengths including void entries (what the consumers iterate over), ext / shadow the rays.
-constexpr uint32_t QUEUE_BLOCK = 256u;
+#ifndef RT_QUEUE_BLOCK
+#define RT_QUEUE_BLOCK 256u
+#endif
+constexpr uint32_t QUEUE_BLOCK = RT_QUEUE_BLOCK;
 constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w of a void extension-queue entry
 constexpr int HIT_VOID = -2;			   // hit.prim of a void entry (-1: miss)
 struct WaveCounters
