@@ -1,26 +1,32 @@
 // kernels.hip — the wavefront stages of the HIP rendercore for gfx950 (MI355X, CDNA4).
 //
-//   extend        closest-hit traversal of one wave of rays (primary rays are generated in the same kernel)
+//   extend        closest-hit traversal of one wave of rays: k_primary_stream / k_trace_stream<false> keep 64 traversals in
+//                 flight per wave and refill finished lanes themselves (stream_rays); k_extend is the one-ray-per-lane form
+//                 (parity primaries, small pt launches, rfwhip_trace_rays)
 //   shade_parity  EmbreeRT-equivalent direct-lighting integrator (shadow rays traced inline, fixed light order)
-//   shade_pt      path-tracing shade: emits a compacted shadow-ray wave and a compacted extension-ray wave
-//   connect       any-hit traversal of the shadow wave, adds unoccluded contributions
+//   shade_pt      path-tracing shade: per-wave hit queues, emits the shadow-ray and extension-ray queues in blocks
+//   connect       any-hit traversal of the shadow queue (k_trace_stream<true> / k_connect), adds unoccluded contributions
 //   resolve/present/deinterleave   accumulate the batch, scale by 1/samples, undo the multi-GPU strip interleave
 //   rng_states    xor128 jump-ahead: per-packet generator states for the parity integrator's jitter stream
-//   refit         bottom-up BVH refit after a same-topology set_mesh
+//   refit / skin / morph   bottom-up BVH refit after a same-topology set_mesh; vertex posing on the device
 //
 // CDNA4 specifics:
-//   * one wave64 = one 8x8 pixel tile of the primary wave; a 256-thread workgroup = 4 tiles;
 //   * the traversal stack lives in LDS as stack[entry][thread] (bank = thread % 32: conflict-free), 12 entries per lane
-//     in the closest-hit kernels and 8 in the occlusion kernels, with a private-memory spill behind it that ordinary rays
-//     never reach; the top of the largest BLAS (128 4-wide nodes) is staged in LDS by every workgroup;
-//   * stream compaction uses one __ballot + mbcnt prefix and ONE atomicAdd per wave (the reference issues one
-//     atomicAdd per surviving thread, CUDART/src/Kernels.cu:640,747,788);
-//   * persistent grids of 8..32 workgroups per CU (by launch size) pulling 256-ray chunks from per-XCD queues: chunks
-//     are dealt to the 8 XCDs in groups of one tile row, workgroup b (which runs on XCD b % 8) pulls consecutive chunks of
-//     its XCD's sequence, so neighbouring tiles (which share BVH nodes and triangles) meet in the same 4 MiB L2;
+//     in the closest-hit kernels and 8 in the occlusion kernels, with a 64-entry private-memory spill behind it that
+//     ordinary rays never reach (this array is the "scratch" the kernel statistics show); the top of the largest BLAS
+//     (128 compressed 4-wide nodes, 8 KiB) is staged in LDS by every workgroup;
+//   * a wave takes runs of up to 512 consecutive rays from a launch's queue with one atomic; lanes refill from the run once
+//     32 are idle; the node phase of a wave ends as soon as 32 lanes hold a leaf (leaf vote);
+//   * queue slots are allocated with __ballot + mbcnt prefixes out of blocks of 256 slots a wave reserves with ONE atomic
+//     (the reference issues one atomicAdd per surviving thread, CUDART/src/Kernels.cu:640,747,788; same-address atomics
+//     complete about every 7 ns on this part);
+//   * persistent grids of 8..12 (traversal) / ..16 (shade) workgroups per CU; the one-ray-per-lane kernels pull 256-ray
+//     chunks from per-XCD queues: chunks are dealt to the 8 XCDs in groups of one tile row, workgroup b (which runs on XCD
+//     b % 8) pulls consecutive chunks of its XCD's sequence, so neighbouring tiles meet in the same 4 MiB L2;
 //   * wave counts come from device-side counters; the host never reads a counter between bounces
 //     (contrast CUDART/src/Context.cpp:98,145).
-// No MFMA: the path is divergent pointer chasing, bounded by memory latency/bandwidth.
+// No MFMA: the path is divergent pointer chasing — VALU issue at ~half-full waves and the vector L1's lane-load rate bound
+// the traversal kernels, HBM traffic the shade kernel.
 #include "kernels.h"
 #include "rt_core.h"
 
@@ -57,7 +63,7 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #endif
 #ifndef RT_SHADE_WAVES_PLAIN
 #define RT_SHADE_WAVES_PLAIN 5 // the shade kernel of scenes without textures: 111 registers unbounded; 4 / 5 / 6 waves ->
-								// 10.96 / 10.59 / 10.82 ms per launch (96 registers + 3 spilled dwords at 5)
+								// 2492 / 2589 / 2584 Msamples/s (96 registers + a few spilled dwords at 5)
 #endif
 
 // ================================================================================================================
