@@ -728,12 +728,14 @@ RT_FN f4 fetch_trilinear(const SceneView &sc, const TexDesc &td, float lambda, f
 			chain += (uint32_t)w * h, w >>= 1, h >>= 1;
 	}
 	const bool has_mips = td.texelCount >= chain;
+	// getShadingData.h:66-67: level0 = min(4, (int)lambda), level1 = min(4, level0 + 1) — NOT clamped at 0: for
+	// lambda <= -1 both loops below run zero times and both levels are the base level
 	int level0 = (int)lambda;
 	if (level0 > 4)
 		level0 = 4;
-	if (level0 < 0 || !has_mips)
-		level0 = 0;
 	int level1 = level0 + 1 > 4 ? 4 : level0 + 1;
+	if (!has_mips)
+		level0 = 0;
 	if (!has_mips)
 		level1 = 0;
 	const float f = lambda - floorf(lambda);

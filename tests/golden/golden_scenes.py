@@ -20,3 +20,10 @@ def terrain_small(pkg, W=96, H=64):
     """The bench workload (BASELINE config 3) at 12 x 12 cells = 288 triangles: smooth vertex normals, a glossy metallic and
     a rough material, 8 emissive light triangles + 2 point lights, the synthetic 2048 x 1024 HDR sky."""
     return pkg.scenes.terrain(n=12, width=W, height_px=H)
+
+
+def cards_pt(pkg, W=96, H=64):
+    """The pt-integrator feature scene (scenes.cards): a card with alpha holes (paths pass through), a floor with two
+    normal-map layers and a detail colour layer, a card with three diffuse layers and three normal-map layers — mip-mapped
+    RGBA8 textures — in the Cornell room."""
+    return pkg.scenes.cards(W, H)

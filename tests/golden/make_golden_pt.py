@@ -9,7 +9,8 @@ written from the reference sources only (not from rendering-fw_amd/csrc/rt_core.
     RFW/system/context/rfw/bsdf/compat.h:47-74       ShadingData parameter unpacking
     RFW/backends/CUDART/src/lights.h:17-265          Potential*Contribution, LightPickProb, RandomBarycentrics,
                                                      RandomPointOnLight, CalculateLightPDF
-    RFW/backends/CUDART/src/getShadingData.h:100-217 normals / tangent frame (the golden scenes carry no textures)
+    RFW/backends/CUDART/src/getShadingData.h:22-217  FetchTexel (bilinear), FetchTexelTrilinear, normals / tangent frame,
+                                                     diffuse and normal-map layers, the alpha flag (the `cards` scene)
     RFW/backends/CUDART/src/Kernels.cu:383-426       generatePrimaryRay (the hash-RNG branch)
     RFW/backends/CUDART/src/Kernels.cu:428-499       intersect_rays (closest hit record, shadow connections)
     RFW/backends/CUDART/src/Kernels.cu:571-794       shade_rays
@@ -620,6 +621,58 @@ def half3(x):
     return np.asarray(x, f32).astype(np.float16).astype(f32)
 
 
+MIPLEVELCOUNT = 5  # settings / texture.h
+
+
+def uchar4_to_float4(v):  # getShadingData.h:22-26
+    v = np.asarray(v, np.uint32)
+    r = f32(1.0 / 256.0)
+    return np.stack([(v & u32(255)).astype(f32) * r, ((v >> u32(8)) & u32(255)).astype(f32) * r,
+                     ((v >> u32(16)) & u32(255)).astype(f32) * r, (v >> u32(24)).astype(f32) * r], -1).astype(f32)
+
+
+def fetch_texel(tex, tcx, tcy, o, w, h):  # getShadingData.h:28-61, BILINEAR 1; o, w, h: per-lane arrays
+    fx = ((np.maximum(tcx + f32(1000), f32(0)) * w.astype(f32)) - f32(0.5)).astype(f32)
+    fy = ((np.maximum(tcy + f32(1000), f32(0)) * h.astype(f32)) - f32(0.5)).astype(f32)
+    iu = fx.astype(np.int64) % w
+    iv = fy.astype(np.int64) % h
+    fu = (fx - np.floor(fx)).astype(f32)
+    fv = (fy - np.floor(fy)).astype(f32)
+    w0 = ((f32(1) - fu) * (f32(1) - fv)).astype(f32)
+    w1 = (fu * (f32(1) - fv)).astype(f32)
+    w2 = ((f32(1) - fu) * fv).astype(f32)
+    w3 = (f32(1) - ((w0 + w1) + w2)).astype(f32)
+    iu1, iv1 = (iu + 1) % w, (iv + 1) % h
+    def px(i):
+        i = np.minimum(i, len(tex["data"]) - 1)
+        return tex["data"][i] if tex["float4"] else uchar4_to_float4(tex["data"][i])
+    p0, p1, p2, p3 = px(o + iu + iv * w), px(o + iu1 + iv * w), px(o + iu + iv1 * w), px(o + iu1 + iv1 * w)
+    return (((p0 * w0[:, None] + p1 * w1[:, None]) + p2 * w2[:, None]) + p3 * w3[:, None]).astype(f32)
+
+
+def fetch_trilinear(tex, lam, tcx, tcy, width, height):  # getShadingData.h:63-98
+    n = len(lam)
+    ilam = np.trunc(lam).astype(np.int64)  # (int)lambda
+    level0 = np.minimum(MIPLEVELCOUNT - 1, ilam)
+    level1 = np.minimum(MIPLEVELCOUNT - 1, level0 + 1)
+    f = (lam - np.floor(lam)).astype(f32)
+    def select(level):  # `for (i = 0; i < level; i++)`: a level <= 0 leaves offset, width and height alone
+        o = np.zeros(n, np.int64)
+        w = np.full(n, width, np.int64)
+        h = np.full(n, height, np.int64)
+        for i in range(MIPLEVELCOUNT - 1):
+            step = level > i
+            o = np.where(step, o + w * h, o)
+            w = np.where(step, w >> 1, w)
+            h = np.where(step, h >> 1, h)
+        return o, np.maximum(w, 1), np.maximum(h, 1)
+    o0, w0, h0 = select(level0)
+    o1, w1, h1 = select(level1)
+    p0 = fetch_texel(tex, tcx, tcy, o0, w0, h0)
+    p1 = fetch_texel(tex, tcx, tcy, o1, w1, h1)
+    return ((f32(1) - f)[:, None] * p0 + f[:, None] * p1).astype(f32)
+
+
 class PathTracer:
     def __init__(self, pkg, scene, W, H, blue_noise=None):
         self.W, self.H = W, H
@@ -633,6 +686,13 @@ class PathTracer:
         self.mat_absorption = np.stack([half3(m["absorption"]) for m in scene.host_materials])
         self.mat_params = np.stack([np.asarray(m["parameters"], np.uint32) for m in mats])
         self.mat_flags = np.asarray([int(m["flags"]) for m in mats], np.uint32)
+        self.mat_maps = [m["map"] for m in mats]  # 10 map descriptors per material (structs.h:98-115); addr = texture index
+        self.textures = []
+        for t in scene.textures:
+            f4t = int(t["type"]) == 0  # TexelStorage: RGBA128 (float4) = 0, RGBA32 = 1
+            self.textures.append(dict(float4=f4t, data=(np.asarray(t["data"], f32).reshape(-1, 4) if f4t else np.asarray(t["data"], np.uint32))))
+        # Camera.cpp:80: spreadAngle = (FOV * pi / 180) / pixelCount.y
+        self.spread_angle = f32(f32(scene.camera.FOV) * f32(np.pi) / f32(180)) / f32(H)
         pos, p1, p2, p3 = camera_view(scene.camera)
         self.pos, self.p1 = pos, p1
         self.right, self.up = (p2 - p1).astype(f32), (p3 - p1).astype(f32)
@@ -677,8 +737,11 @@ class PathTracer:
         out[ok] = self.sky[idx[ok]]
         return out
 
-    def shading_data(self, D, bu, bv, inst, prim):  # getShadingData.h:100-217 without textures
+    def shading_data(self, D, bu, bv, inst, prim, t):  # getShadingData.h:100-217
         n = len(D)
+        texu = np.zeros((n, 3), f32)
+        texv = np.zeros((n, 3), f32)
+        lod = np.zeros(n, f32)
         N = np.zeros((n, 3), f32)
         iN = np.zeros((n, 3), f32)
         matid = np.zeros(n, np.int64)
@@ -702,9 +765,59 @@ class PathTracer:
             matid[sel] = mid
             area[sel] = tr["area"]
             ltri[sel] = tr["lightTriIdx"]
+            texu[sel], texv[sel], lod[sel] = tr["u"], tr["v"], tr["LOD"]
         sd = SD(self.mat_color[matid], self.mat_absorption[matid], self.mat_params[matid])
         T, B = create_tangent_space(iN)
-        return sd, N, iN, T, B, area, ltri
+        alpha = np.zeros(n, bool)
+        flag = lambda bit: ((self.mat_flags[matid] >> u32(bit)) & u32(1)).astype(bool)  # noqa: E731  structs.h:67-83
+        has_diffuse = flag(2)
+        if has_diffuse.any():
+            color = sd.color.copy()
+            tu = ((bu * texu[:, 0] + bv * texu[:, 1]) + w * texu[:, 2]).astype(f32)
+            tv = ((bu * texv[:, 0] + bv * texv[:, 1]) + w * texv[:, 2]).astype(f32)
+            coneWidth = (self.spread_angle * t).astype(f32)
+            lam = (lod + np.log2(coneWidth * (f32(1) / np.abs(dot(-D, N)))).astype(f32)).astype(f32)  # eq. 26
+            for mi in np.unique(matid[has_diffuse]):
+                sel = np.nonzero(has_diffuse & (matid == mi))[0]
+                maps = self.mat_maps[mi]
+                def uv(k):
+                    m = maps[k]
+                    us, vs, uo, vo = (f32(m[x]) for x in ("uscale", "vscale", "uoffs", "voffs"))
+                    return (us * (uo + tu[sel])).astype(f32), (vs * (vo + tv[sel])).astype(f32)
+                def layer(k):  # FetchTexelTrilinear of map slot k
+                    m = maps[k]
+                    x, y = uv(k)
+                    return fetch_trilinear(self.textures[int(m["addr"])], lam[sel], x, y, int(m["width"]), int(m["height"]))
+                def nlayer(k):  # (FetchTexel(level 0) - 0.5) * 2
+                    m = maps[k]
+                    x, y = uv(k)
+                    z = np.zeros(len(sel), np.int64)
+                    tx = fetch_texel(self.textures[int(m["addr"])], x, y, z, z + int(m["width"]), z + int(m["height"]))
+                    return ((tx[:, :3] - f32(0.5)) * f32(2.0)).astype(f32)
+                fl = int(self.mat_flags[mi])
+                texel = layer(0)
+                a = np.zeros(len(sel), bool)
+                if (fl >> 12) & 1:  # HasAlpha: the rest of the surface is not evaluated
+                    a = texel[:, 3] < f32(0.5)
+                alpha[sel] = a
+                c = (color[sel] * texel[:, :3]).astype(f32)
+                if (fl >> 9) & 1:   # Has2ndDiffuseMap: additive
+                    c = (c + layer(1)[:, :3]).astype(f32)
+                if (fl >> 10) & 1:  # Has3rdDiffuseMap
+                    c = (c + layer(2)[:, :3]).astype(f32)
+                if (fl >> 3) & 1:   # HasNormalMap (slots 3..5 of the map array)
+                    sn = nlayer(3)
+                    if (fl >> 7) & 1:
+                        sn = (sn + nlayer(4)).astype(f32)
+                    if (fl >> 8) & 1:  # the third layer reads the SECOND layer's descriptor (getShadingData.h:189-196)
+                        sn = (sn + nlayer(4)).astype(f32)
+                    sn = normalize(sn)
+                    wn = normalize(((T[sel] * sn[:, 0:1] + B[sel] * sn[:, 1:2]) + iN[sel] * sn[:, 2:3]).astype(f32))  # tangentToWorld
+                    iN[sel] = np.where(a[:, None], iN[sel], wn)
+                c = (c * texel[:, :3]).astype(f32)  # :206, the second multiplication by the texel
+                color[sel] = np.where(a[:, None], color[sel], c)
+            sd.color = color
+        return sd, N, iN, T, B, area, ltri, alpha
 
     def render_sample(self, acc, sample_index, record=None):
         """One call of CUDAContext::render_frame.  acc: (W*H, 4) accumulator.  samplesTaken == sample_index."""
@@ -756,7 +869,19 @@ class PathTracer:
         O, D, T, bsdfPdf, flags, pid, lastNp = O[h], D[h], T[h], bsdfPdf[h], flags[h], pid[h], lastNp[h]
         t, inst, prim, bu, bv = t[h], inst[h], prim[h], bu[h], bv[h]
         I = (O + s3(t, D)).astype(f32)
-        sd, N, iN, Tg, Bt, area, ltri = self.shading_data(D, bu, bv, inst, prim)
+        sd, N, iN, Tg, Bt, area, ltri, alpha = self.shading_data(D, bu, bv, inst, prim, t)
+        # ---- alpha cut-out (Kernels.cu:633-647): the path goes on behind the surface with its state untouched.  (The
+        # reference stores that state into the wrong buffers — its own TODO says the branch is broken; what it means is kept.)
+        through = None
+        if alpha.any():
+            a = alpha & ~np.isnan(T).any(1)
+            if pathLength < MAX_PATH_LENGTH and a.any():
+                through = dict(O=(I[a] + D[a] * GEO_EPS).astype(f32), D=D[a], T=T[a], pdf=bsdfPdf[a], flags=flags[a], pid=pid[a], lastN=lastNp[a])
+            k = ~alpha
+            O, D, T, bsdfPdf, flags, pid, lastNp = O[k], D[k], T[k], bsdfPdf[k], flags[k], pid[k], lastNp[k]
+            t, inst, prim, bu, bv, I = t[k], inst[k], prim[k], bu[k], bv[k], I[k]
+            N, iN, Tg, Bt, area, ltri = N[k], iN[k], Tg[k], Bt[k], area[k], ltri[k]
+            sd = sd.take(k)
         # ---- emissive: terminate (Kernels.cu:650-692)
         em = (sd.color > 1).any(1)
         if em.any():
@@ -831,6 +956,8 @@ class PathTracer:
         ok = ~((newPdf < f32(1e-6)) | np.isnan(newPdf) | (T < 0).any(1))
         nxt = dict(O=(I[ok] + N[ok] * GEO_EPS).astype(f32), D=R[ok], T=T[ok], pdf=newPdf[ok], flags=flags[ok], pid=pid[ok],
                    lastN=pack_normal(iN[ok]))
+        if through is not None:
+            nxt = {k: np.concatenate([nxt[k], through[k]]) for k in nxt}
         return nxt, shadow
 
 
@@ -935,17 +1062,23 @@ def blue_noise_kat(out):
 
 
 def main():
+    """python make_golden_pt.py [name ...]: (re)generate the named fixtures only; without arguments, all of them."""
     pkg = load_package()
-    kat = make_kat(pkg)
-    blue_noise_kat(kat)
-    np.savez_compressed(os.path.join(HERE, "pt_kat.npz"), **kat)
-    print("pt_kat.npz:", len(kat), "arrays")
+    only = set(sys.argv[1:])
+    if not only or "pt_kat" in only:
+        kat = make_kat(pkg)
+        blue_noise_kat(kat)
+        np.savez_compressed(os.path.join(HERE, "pt_kat.npz"), **kat)
+        print("pt_kat.npz:", len(kat), "arrays")
     W, H, SPP = 96, 64, 4
-    table = reference_blue_noise_table()
+    table = reference_blue_noise_table() if (not only or "pt_cornell96x64_bluenoise" in only) else None
     for name, scene, bn in (("pt_cornell96x64", golden_scenes.cornell_pt(pkg, W, H), None),
                             ("pt_lights96x64", golden_scenes.cornell_lights(pkg, W, H), None),
                             ("pt_cornell96x64_bluenoise", golden_scenes.cornell_pt(pkg, W, H), table),
-                            ("pt_terrain96x64", golden_scenes.terrain_small(pkg, W, H), None)):
+                            ("pt_terrain96x64", golden_scenes.terrain_small(pkg, W, H), None),
+                            ("pt_cards96x64", golden_scenes.cards_pt(pkg, W, H), None)):
+        if only and name not in only:
+            continue
         pt = PathTracer(pkg, scene, W, H, blue_noise=bn)
         acc = np.zeros((W * H, 4), f32)
         per_sample = []

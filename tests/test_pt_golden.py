@@ -124,8 +124,8 @@ def reference_blue_noise():
 def render_golden(ctx, pkg, name, settings=()):
     """Render the golden scene `name` sample by sample; returns (sample 0 image, 4-spp image, per-sample wave counts)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    scene = (golden_scenes.cornell_lights if "lights" in name else
-             golden_scenes.terrain_small if "terrain" in name else golden_scenes.cornell_pt)(pkg, 96, 64)
+    scene = (golden_scenes.cornell_lights if "lights" in name else golden_scenes.terrain_small if "terrain" in name else
+             golden_scenes.cards_pt if "cards" in name else golden_scenes.cornell_pt)(pkg, 96, 64)
     ctx.init(96, 64)
     if "bluenoise" in name:
         ctx.set_blue_noise(reference_blue_noise())
@@ -143,12 +143,16 @@ def render_golden(ctx, pkg, name, settings=()):
     return g, first, ctx.framebuffer()[..., :3], counts
 
 
-def check_image(g, first, img, counts, exact_first):
+def check_image(g, first, img, counts, exact_first, textured=False):
     # sample 0: every discrete decision falls like the golden's => (nearly) every pixel agrees to rounding; the handful that
     # do not are occlusion tests or sky texels decided in the last bit (3 of 6144 pixels allowed on the host, 12 on the GPU)
-    d0 = np.abs(first - g["sample0"]).max(-1)
+    # textured scenes: FetchTexel adds 1000 to the texture coordinate (getShadingData.h:30), which quantises it to 6e-5 = 0.004
+    # texels of a 64-texel map; an ulp of difference before that addition moves a bilinear weight by 0.4 % of the texel contrast
+    rel = 5e-3 if textured else 0.0
+    d0 = (np.abs(first - g["sample0"]) - rel * np.abs(g["sample0"])).max(-1)
     assert (d0 > 1e-3).mean() <= (5e-4 if exact_first else 2e-3), "sample 0: %g of the pixels differ, worst %g" % ((d0 > 1e-3).mean(), d0.max())
-    frac, rmse, d = image_stats(img, g["image"], 1e-3)
+    d = (np.abs(img - g["image"]) - rel * np.abs(g["image"])).max(-1)
+    frac, rmse = float((d > 1e-3).mean()), float(np.sqrt(np.mean((img - g["image"]) ** 2)))
     assert frac <= 2e-3, "4 spp: %g of the pixels differ (rmse %g)" % (frac, rmse)
     # wave sizes per sample: extension rays of depth 1 and 2, connections actually traced (depths 0 and 1)
     for s, (pc, sc, dc, sh) in enumerate(counts):
@@ -158,7 +162,7 @@ def check_image(g, first, img, counts, exact_first):
         assert all(abs(a - b) <= t for a, b, t in zip(got, want, tol)), "sample %d wave counts %s, golden %s" % (s, got, want)
 
 
-GOLDEN_IMAGES = ["pt_cornell96x64", "pt_lights96x64", "pt_cornell96x64_bluenoise", "pt_terrain96x64"]
+GOLDEN_IMAGES = ["pt_cornell96x64", "pt_lights96x64", "pt_cornell96x64_bluenoise", "pt_terrain96x64", "pt_cards96x64"]
 
 
 # ---- CPU tier -------------------------------------------------------------------------------------------------------
@@ -172,12 +176,12 @@ def test_emulation_known_answers(pkg, make_emu):
 
 @pytest.mark.parametrize("name", GOLDEN_IMAGES)
 def test_oracle_reproduces_the_independent_path_tracer(pkg, make_oracle, name):
-    check_image(*render_golden(make_oracle(), pkg, name), exact_first=True)
+    check_image(*render_golden(make_oracle(), pkg, name), exact_first=True, textured="cards" in name)
 
 
 @pytest.mark.parametrize("name", GOLDEN_IMAGES)
 def test_emulation_reproduces_the_independent_path_tracer(pkg, make_emu, name):
-    check_image(*render_golden(make_emu(), pkg, name), exact_first=True)
+    check_image(*render_golden(make_emu(), pkg, name), exact_first=True, textured="cards" in name)
 
 
 def test_blue_noise_table_is_the_references(pkg):
@@ -199,7 +203,7 @@ def test_hip_known_answers(pkg, make_hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", GOLDEN_IMAGES)
 def test_hip_reproduces_the_independent_path_tracer(pkg, make_hip, name):
-    check_image(*render_golden(make_hip(), pkg, name), exact_first=False)
+    check_image(*render_golden(make_hip(), pkg, name), exact_first=False, textured="cards" in name)
 
 
 @pytest.mark.gpu
