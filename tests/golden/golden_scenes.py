@@ -27,3 +27,40 @@ def cards_pt(pkg, W=96, H=64):
     normal-map layers and a detail colour layer, a card with three diffuse layers and three normal-map layers — mip-mapped
     RGBA8 textures — in the Cornell room."""
     return pkg.scenes.cards(W, H)
+
+
+def cards_parity(pkg, W=96, H=64):
+    """Textured scene for the parity integrator (EmbreeRT's retrieve_material reads the first diffuse map only, nearest
+    texel): the Cornell room of the untextured fixture plus three cards — an RGBA8 checker with scale 3, an RGBA8 pattern
+    with scale 2 and a FLOAT4 texture (the case that falls through into the UINT case there) with a scale and a negative
+    offset, so that the fmod wrap and its sign fix are exercised."""
+    import numpy as np
+    s = pkg.scenes.cornell(W, H)
+    s.name = "cards_parity"
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    chk = ((xx // 8) + (yy // 8)) % 2
+    base = np.zeros((n, n, 4), np.uint8)
+    base[..., 0], base[..., 1], base[..., 2], base[..., 3] = np.where(chk, 230, 120), np.where(chk, 220, 110), np.where(chk, 200, 100), 255
+    pat = np.zeros((n, n, 4), np.uint8)
+    pat[..., 0], pat[..., 1], pat[..., 2], pat[..., 3] = 40 + (xx * 3) % 50, 150 + (yy * 2) % 90, 40 + ((xx + yy) % 16) * 8, 255
+    yy, xx = np.mgrid[0:16, 0:16]
+    img = np.zeros((16, 16, 4), np.float32)
+    img[..., 0], img[..., 1], img[..., 2], img[..., 3] = 0.25 + xx / 20.0, 0.9 - yy / 24.0, 0.3 + ((xx + yy) % 4) * 0.15, 1.0
+    t_base = s.add_texture(pkg.scenes.make_texture_rgba8(base))
+    t_pat = s.add_texture(pkg.scenes.make_texture_rgba8(pat, mips=False))
+    t_f4 = s.add_texture(pkg.scenes.make_texture_float4(img))
+    m_base = s.add_material(color=(0.9, 0.9, 0.9), roughness=0.7, texture=t_base, uvscale=(3.0, 3.0))
+    m_pat = s.add_material(color=(1.0, 1.0, 1.0), roughness=0.9, texture=t_pat, uvscale=(2.0, 2.0), uvoffset=(0.125, 0.0))
+    m_f4 = s.add_material(color=(0.9, 0.8, 0.7), roughness=0.8, texture=t_f4, uvscale=(1.5, 2.0), uvoffset=(0.25, -0.75))
+    def card(p0, ex, ey, mat):
+        p0, ex, ey = (np.asarray(v, np.float32) for v in (p0, ex, ey))
+        v = np.array([p0, p0 + ex, p0 + ex + ey, p0 + ey], np.float32)
+        idx = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        s.add_instance(s.add_mesh(v, idx, uvs=uv, material=mat))
+    L = 5.0
+    card((-L + 0.02, 0.02, -L + 0.02), (0.0, 0.0, 2 * L - 0.04), (2 * L - 0.04, 0.0, 0.0), m_base)  # just above the floor
+    card((-4.5, 0.5, -2.5), (3.5, 0.0, 0.4), (0.0, 4.5, 0.0), m_pat)
+    card((4.2, 0.3, -3.5), (-3.5, 0.0, 0.2), (0.0, 2.5, 0.0), m_f4)   # in front of the short box, facing the camera
+    return s

@@ -61,7 +61,7 @@ def world_triangles(scene):
             t = m["triangles"][pi]
             vn = [(Nm @ t[k].astype(np.float64)) for k in ("vN0", "vN1", "vN2")]
             tris.append(dict(p=[v[a].astype(f32), v[b].astype(f32), v[c].astype(f32)], inst=ii, prim=pi, vn=vn,
-                             material=int(t["material"])))
+                             material=int(t["material"]), tu=np.asarray(t["u"], f32), tv=np.asarray(t["v"], f32)))
     return tris
 
 
@@ -111,6 +111,42 @@ def occluded(O, D, tris, tmin, tmax):
     return occ
 
 
+def half(x):
+    return f32(np.float16(x))
+
+
+def diffuse_map(scene, tr, color, b0, b1, b2):
+    """retrieve_material's texture lookup (EmbreeRT/src/Context.cpp:432-472): nearest texel at t * (size - 1), wrap by fmod,
+    and the FLOAT4 case falling through into the UINT case (no break), which reads the same texel index out of the float
+    data reinterpreted as 32-bit words."""
+    m = scene.host_materials[tr["material"]]
+    n = len(b0)
+    out = np.broadcast_to(color, (n, 3)).astype(f32)
+    if m.get("texture", -1) < 0:
+        return out
+    tex = scene.textures[m["texture"]]
+    tu = ((b0 * tr["tu"][0] + b1 * tr["tu"][1]) + b2 * tr["tu"][2]).astype(f32)
+    tv = ((b0 * tr["tv"][0] + b1 * tr["tv"][1]) + b2 * tr["tv"][2]).astype(f32)
+    u = ((tu + half(m["uvoffset"][0])) * half(m["uvscale"][0])).astype(f32)
+    v = ((tv + half(m["uvoffset"][1])) * half(m["uvscale"][1])).astype(f32)
+    tx, ty = np.fmod(u, f32(1)).astype(f32), np.fmod(v, f32(1)).astype(f32)
+    tx = np.where(tx < 0, f32(1) + tx, tx).astype(f32)
+    ty = np.where(ty < 0, f32(1) + ty, ty).astype(f32)
+    w, h = int(tex["width"]), int(tex["height"])
+    ix = (tx * f32(w - 1)).astype(np.uint32).astype(np.int64)
+    iy = (ty * f32(h - 1)).astype(np.uint32).astype(np.int64)
+    tid = iy * w + ix
+    if int(tex["type"]) == 0:  # TextureData::FLOAT4
+        data = np.asarray(tex["data"], f32).reshape(-1, 4)
+        out = (out * data[tid][:, :3]).astype(f32)
+        words = np.asarray(tex["data"], f32).reshape(-1).view(np.uint32)  # ... and no break: falls into case UINT
+    else:
+        words = np.asarray(tex["data"], np.uint32)
+    tc = words[tid]
+    rgb = np.stack([tc & np.uint32(255), (tc >> np.uint32(8)) & np.uint32(255), (tc >> np.uint32(16)) & np.uint32(255)], -1).astype(f32)
+    return ((out * f32(1.0 / 256.0)) * rgb).astype(f32)
+
+
 def render(scene, W, H, jitter):
     cam = scene.camera
     pos, p1, p2, p3 = camera_view(cam)
@@ -157,7 +193,7 @@ def render(scene, W, H, jitter):
         b0 = (f32(1) - bu[sel] - bv[sel]).astype(f32)
         n = b0[:, None] * tr["vn"][0] + bu[sel][:, None] * tr["vn"][1] + bv[sel][:, None] * tr["vn"][2]
         iN[sel] = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(f32)
-        col[sel] = colors[tr["material"]]
+        col[sel] = diffuse_map(scene, tr, colors[tr["material"]], b0, bu[sel], bv[sel])
     contrib = np.full_like(P, 0.1)
     area, point, _, _ = scene.light_arrays()
     for l in area:
@@ -183,7 +219,10 @@ def render(scene, W, H, jitter):
         occ[cand] = occluded(P[cand], L[cand], tris, f32(1e-4), dist[cand])
         lit = cand & ~occ
         contrib[lit] += (l["radiance"][None, :] / sq[lit, None] * ndl[lit, None]).astype(f32)
-    img[hit, :3] = (col * contrib)[hit]
+    shaded = (col * contrib).astype(f32)
+    emissive = (col > 1).any(1)  # Context.cpp:217-221: a colour above 1 is written as it is
+    shaded[emissive] = col[emissive]
+    img[hit, :3] = shaded[hit]
     img[hit, 3] = 1.0
     prim = np.array([tris[k]["prim"] if k >= 0 else -1 for k in which], np.int32)
     inst = np.array([tris[k]["inst"] if k >= 0 else -1 for k in which], np.int32)
@@ -197,10 +236,18 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     W, H = 96, 64  # wider than the box so the fixture also covers sky lookups
     scene = pkg.scenes.cornell(W, H)
-    for name, jitter in (("cornell96x64_center", False), ("cornell96x64_xor128", True)):
+    sys.path.insert(0, out_dir)
+    import golden_scenes
+    for name, jitter in (("cornell96x64_center", False), ("cornell96x64_xor128", True), ("cards96x64_center", False)):
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
+        if name.startswith("cards"):
+            scene = golden_scenes.cards_parity(pkg, W, H)
         r = render(scene, W, H, jitter)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **r)
         print(name, "mean", float(r["image"][..., :3].mean()), "hit fraction", float((r["prim"] >= 0).mean()))
+    if sys.argv[1:] and "rng_kat" not in sys.argv[1:]:
+        return
     # known answers of the integer generators (hand-derivable from xor128.h:20-27 / tools.h:218-235)
     draws, state = xor128_stream(1000)
     np.savez_compressed(os.path.join(out_dir, "rng_kat.npz"), xor128_first8=draws[:8], xor128_state_after_1000=np.array(state, np.uint32),

@@ -10,11 +10,15 @@ import pytest
 from conftest import image_stats
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = [("cornell96x64_center", "center"), ("cornell96x64_xor128", "xor128")]
+CASES = [("cornell96x64_center", "center"), ("cornell96x64_xor128", "xor128"), ("cards96x64_center", "center")]
 
 
-def _render(pkg, ctx, jitter, w=96, h=64, **extra):
-    scene = pkg.scenes.cornell(w, h)
+def _render(pkg, ctx, jitter, w=96, h=64, name="cornell", **extra):
+    import sys
+    sys.path.insert(0, GOLD)
+    import golden_scenes
+    # cards: textured materials — retrieve_material's nearest lookup, fmod wrap, FLOAT4 -> UINT fall-through
+    scene = golden_scenes.cards_parity(pkg, w, h) if name.startswith("cards") else pkg.scenes.cornell(w, h)
     ctx.init(w, h)
     scene.upload(ctx)
     ctx.set_setting("integrator", "parity")
@@ -25,36 +29,37 @@ def _render(pkg, ctx, jitter, w=96, h=64, **extra):
     return ctx.framebuffer(), ctx.primary_hits()
 
 
-def _check(img, hits, g):
+def _check(img, hits, g, textured=False):
     assert (hits["prim"] != g["prim"]).sum() == 0
     assert (hits["inst"] != g["inst"]).sum() == 0
     m = g["prim"] >= 0
     assert np.abs(hits["t"] - g["t"])[m].max() < 1e-4
     assert np.abs(hits["u"] - g["u"])[m].max() < 1e-4 and np.abs(hits["v"] - g["v"])[m].max() < 1e-4
     frac, rmse, d = image_stats(img, g["image"], 1e-3)
-    assert frac == 0.0 and rmse < 2e-4, (frac, rmse, d.max())
+    # (textured: a texel index is uint(t * (size - 1)) — a pixel whose t lands on a texel edge may take the neighbour)
+    assert frac <= (2e-3 if textured else 0.0) and rmse < (2e-3 if textured else 2e-4), (frac, rmse, d.max())
     assert np.array_equal(img[..., 3], g["image"][..., 3])  # alpha: 1 on hits, 0 on sky (Context.cpp:194,281)
 
 
 @pytest.mark.parametrize("name,jitter", CASES)
 def test_oracle_matches_golden(pkg, make_oracle, name, jitter):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    img, hits = _render(pkg, make_oracle(), jitter)
-    _check(img, hits, g)
+    img, hits = _render(pkg, make_oracle(), jitter, name=name)
+    _check(img, hits, g, name.startswith("cards"))
 
 
 @pytest.mark.parametrize("name,jitter", CASES)
 def test_oracle_bruteforce_mode_matches_golden(pkg, make_oracle, name, jitter):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    img, hits = _render(pkg, make_oracle(), jitter, bvh="0")
-    _check(img, hits, g)
+    img, hits = _render(pkg, make_oracle(), jitter, name=name, bvh="0")
+    _check(img, hits, g, name.startswith("cards"))
 
 
 @pytest.mark.parametrize("name,jitter", CASES)
 def test_emulated_core_matches_golden(pkg, make_emu, name, jitter):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    img, hits = _render(pkg, make_emu(), jitter)
-    _check(img, hits, g)
+    img, hits = _render(pkg, make_emu(), jitter, name=name)
+    _check(img, hits, g, name.startswith("cards"))
 
 
 def test_golden_covers_sky_and_all_instances():

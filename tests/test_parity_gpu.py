@@ -443,3 +443,14 @@ def test_image_is_independent_of_how_calls_are_scheduled_gpu(pkg, make_hip, inte
                               ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2)):
         img = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, **extra), 8, wait_every)
         assert np.array_equal(img, ref), (extra, wait_every)
+
+
+@pytest.mark.parametrize("name,jitter", [("cornell96x64_center", "center"), ("cornell96x64_xor128", "xor128"), ("cards96x64_center", "center")])
+def test_hip_matches_the_numpy_goldens_of_the_parity_integrator(pkg, make_hip, name, jitter):
+    """The committed vectors of tests/golden/make_golden.py (independent numpy renderer) on the HIP kernels: primary hits,
+    image, and — cards — retrieve_material's texture lookup incl. the FLOAT4 -> UINT fall-through."""
+    import os
+    import test_golden as TG
+    g = np.load(os.path.join(TG.GOLD, name + ".npz"))
+    img, hits = TG._render(pkg, make_hip(), jitter, name=name)
+    TG._check(img, hits, g, name.startswith("cards"))
