@@ -64,3 +64,22 @@ def cards_parity(pkg, W=96, H=64):
     card((-4.5, 0.5, -2.5), (3.5, 0.0, 0.4), (0.0, 4.5, 0.0), m_pat)
     card((4.2, 0.3, -3.5), (-3.5, 0.0, 0.2), (0.0, 2.5, 0.0), m_f4)   # in front of the short box, facing the camera
     return s
+
+
+def cornell_lens(pkg, W=96, H=64):
+    """cornell_pt seen through a thin lens (aperture 0.35, focus on the tall box): generatePrimaryRay's nine-blade aperture
+    sampling (Kernels.cu:401-416)."""
+    s = cornell_pt(pkg, W, H)
+    s.name = "cornell_lens"
+    s.camera.aperture = 0.35
+    s.camera.focalDistance = 17.0
+    return s
+
+
+def cornell_lens_parity(pkg, W=96, H=64):
+    """The untextured parity fixture's room through a thin lens (aperture 0.35): Ray::generateFromView's aperture sampling."""
+    s = pkg.scenes.cornell(W, H)
+    s.name = "cornell_lens_parity"
+    s.camera.aperture = 0.35
+    s.camera.focalDistance = 17.0
+    return s

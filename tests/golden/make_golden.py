@@ -164,12 +164,30 @@ def render(scene, W, H, jitter):
     u = ((xs.astype(f32) + r0) * (f32(1) / f32(W))).astype(f32)
     v = ((ys.astype(f32) + r1) * (f32(1) / f32(H))).astype(f32)
     pix = p1 + (u[..., None] * right + v[..., None] * up)
-    d = (pix - pos).astype(f32).reshape(-1, 3)
+    org = np.broadcast_to(pos, pix.shape).astype(f32)
+    if f32(cam.aperture) != 0:
+        # Ray::generateFromView (Ray.cpp:16-47), the scalar form: nine-blade aperture, r2 / r3 = draws 16..23 / 24..31 of the packet
+        r2 = np.full((H, W), 0.5, f32)
+        r3 = np.full((H, W), 0.5, f32)
+        if jitter:
+            for j in range(8):
+                r2[(j >> 2)::2, (j & 3)::4] = rnd[:, :, 2, j]
+                r3[(j >> 2)::2, (j & 3)::4] = rnd[:, :, 3, j]
+        blade = (r0 * f32(9)).astype(np.int32).astype(f32)
+        r2 = ((r2 - blade * f32(1.0 / 9.0)) * f32(9.0)).astype(f32)
+        po = f32(3.14159265359) / f32(4.5)
+        x1, y1 = np.cos(blade * po).astype(f32), np.sin(blade * po).astype(f32)
+        x2, y2 = np.cos((blade + f32(1)) * po).astype(f32), np.sin((blade + f32(1)) * po).astype(f32)
+        flip = (r2 + r3) > 1
+        r2, r3 = np.where(flip, f32(1) - r2, r2).astype(f32), np.where(flip, f32(1) - r3, r3).astype(f32)
+        xr, yr = (x1 * r2 + x2 * r3).astype(f32), (y1 * r2 + y2 * r3).astype(f32)
+        org = (pos + f32(cam.aperture) * (xr[..., None] * right + yr[..., None] * up)).astype(f32)
+    d = (pix - org).astype(f32).reshape(-1, 3)
     l2 = (d[:, 0] * d[:, 0]).astype(f32)
     l2 = (d[:, 1] * d[:, 1] + l2).astype(f32)
     l2 = (d[:, 2] * d[:, 2] + l2).astype(f32)
     D = (d * (f32(1) / np.sqrt(l2, dtype=f32))[:, None]).astype(f32)
-    O = np.broadcast_to(pos, D.shape).astype(f32)
+    O = org.reshape(-1, 3).astype(f32)
     tris = world_triangles(scene)
     t, which, bu, bv = intersect_all(O, D, tris, f32(1e-5), f32(1e34))
     img = np.zeros((H * W, 4), f32)
@@ -238,11 +256,14 @@ def main():
     scene = pkg.scenes.cornell(W, H)
     sys.path.insert(0, out_dir)
     import golden_scenes
-    for name, jitter in (("cornell96x64_center", False), ("cornell96x64_xor128", True), ("cards96x64_center", False)):
+    for name, jitter in (("cornell96x64_center", False), ("cornell96x64_xor128", True), ("cards96x64_center", False),
+                         ("lens96x64_xor128", True)):
         if sys.argv[1:] and name not in sys.argv[1:]:
             continue
         if name.startswith("cards"):
             scene = golden_scenes.cards_parity(pkg, W, H)
+        if name.startswith("lens"):
+            scene = golden_scenes.cornell_lens_parity(pkg, W, H)
         r = render(scene, W, H, jitter)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **r)
         print(name, "mean", float(r["image"][..., :3].mean()), "hit fraction", float((r["prim"] >= 0).mean()))

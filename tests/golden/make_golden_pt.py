@@ -1076,7 +1076,8 @@ def main():
                             ("pt_lights96x64", golden_scenes.cornell_lights(pkg, W, H), None),
                             ("pt_cornell96x64_bluenoise", golden_scenes.cornell_pt(pkg, W, H), table),
                             ("pt_terrain96x64", golden_scenes.terrain_small(pkg, W, H), None),
-                            ("pt_cards96x64", golden_scenes.cards_pt(pkg, W, H), None)):
+                            ("pt_cards96x64", golden_scenes.cards_pt(pkg, W, H), None),
+                            ("pt_lens96x64", golden_scenes.cornell_lens(pkg, W, H), None)):
         if only and name not in only:
             continue
         pt = PathTracer(pkg, scene, W, H, blue_noise=bn)

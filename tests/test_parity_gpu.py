@@ -445,7 +445,7 @@ def test_image_is_independent_of_how_calls_are_scheduled_gpu(pkg, make_hip, inte
         assert np.array_equal(img, ref), (extra, wait_every)
 
 
-@pytest.mark.parametrize("name,jitter", [("cornell96x64_center", "center"), ("cornell96x64_xor128", "xor128"), ("cards96x64_center", "center")])
+@pytest.mark.parametrize("name,jitter", [("cornell96x64_center", "center"), ("cornell96x64_xor128", "xor128"), ("cards96x64_center", "center"), ("lens96x64_xor128", "xor128")])
 def test_hip_matches_the_numpy_goldens_of_the_parity_integrator(pkg, make_hip, name, jitter):
     """The committed vectors of tests/golden/make_golden.py (independent numpy renderer) on the HIP kernels: primary hits,
     image, and — cards — retrieve_material's texture lookup incl. the FLOAT4 -> UINT fall-through."""

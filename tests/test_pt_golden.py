@@ -125,7 +125,8 @@ def render_golden(ctx, pkg, name, settings=()):
     """Render the golden scene `name` sample by sample; returns (sample 0 image, 4-spp image, per-sample wave counts)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     scene = (golden_scenes.cornell_lights if "lights" in name else golden_scenes.terrain_small if "terrain" in name else
-             golden_scenes.cards_pt if "cards" in name else golden_scenes.cornell_pt)(pkg, 96, 64)
+             golden_scenes.cards_pt if "cards" in name else golden_scenes.cornell_lens if "lens" in name else
+             golden_scenes.cornell_pt)(pkg, 96, 64)
     ctx.init(96, 64)
     if "bluenoise" in name:
         ctx.set_blue_noise(reference_blue_noise())
@@ -162,7 +163,7 @@ def check_image(g, first, img, counts, exact_first, textured=False):
         assert all(abs(a - b) <= t for a, b, t in zip(got, want, tol)), "sample %d wave counts %s, golden %s" % (s, got, want)
 
 
-GOLDEN_IMAGES = ["pt_cornell96x64", "pt_lights96x64", "pt_cornell96x64_bluenoise", "pt_terrain96x64", "pt_cards96x64"]
+GOLDEN_IMAGES = ["pt_cornell96x64", "pt_lights96x64", "pt_cornell96x64_bluenoise", "pt_terrain96x64", "pt_cards96x64", "pt_lens96x64"]
 
 
 # ---- CPU tier -------------------------------------------------------------------------------------------------------
