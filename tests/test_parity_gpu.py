@@ -454,3 +454,30 @@ def test_hip_matches_the_numpy_goldens_of_the_parity_integrator(pkg, make_hip, n
     g = np.load(os.path.join(TG.GOLD, name + ".npz"))
     img, hits = TG._render(pkg, make_hip(), jitter, name=name)
     TG._check(img, hits, g, name.startswith("cards"))
+
+
+def test_batch_size_changes_between_pipelined_calls_gpu(pkg, make_hip):
+    """spp changes while calls are in flight (the ring is re-laid out behind a synchronisation), 40 calls without a wait:
+    the same 100 samples as one sample per call, up to the summation order of a batch."""
+    scene = pkg.scenes.cornell(480, 272)
+    a = make_hip()
+    a.init(480, 272)
+    scene.upload(a)
+    a.set_setting("integrator", "pt")
+    seq = [2, 4, 2, 1, 1, 8, 1, 1] * 5
+    assert sum(seq) == 100
+    for k, spp in enumerate(seq):
+        a.set_setting("spp", spp)
+        a.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+    a.wait()
+    b = make_hip()
+    b.init(480, 272)
+    scene.upload(b)
+    b.set_setting("integrator", "pt")
+    b.set_setting("spp", 1)
+    for k in range(100):
+        b.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+    b.wait()
+    ia, ib = a.framebuffer(), b.framebuffer()
+    assert np.abs(ia - ib).max() <= 2e-5 * max(1.0, float(ib.max()))
+    assert a.get_stats().primaryCount == 480 * 272
