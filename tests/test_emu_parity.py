@@ -159,6 +159,17 @@ def test_settings_and_errors(pkg, make_emu):
     e.render_frame(scene.camera, pkg.RESET)
     with pytest.raises(RuntimeError):
         e.set_instance(5, 99, np.eye(4))                   # unknown mesh
+    # maximum sizes: a batch of 2^31 path slots or more is refused before anything is allocated; so is a depth beyond the
+    # counter slots
+    big = make_emu()
+    big.init(1920, 1080)
+    pkg.scenes.cornell(1920, 1080).upload(big)
+    big.set_setting("integrator", "pt")
+    big.set_setting("spp", 1100)                           # 1920 x 1088 x 1100 > 2^31
+    with pytest.raises(RuntimeError, match="too large"):
+        big.render_frame(scene.camera, pkg.RESET)
+    with pytest.raises(RuntimeError, match="max_depth"):
+        big.set_setting("max_depth", 64)
     e.cleanup()
     e.cleanup()                                            # idempotent
     with pytest.raises(RuntimeError):
