@@ -82,6 +82,36 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 							 : "v"(m), "v"(c)
 							 : "vcc");
 			}
+			else if (OP == 6)
+			{
+				// v_cndmask with an explicit SGPR-pair mask (VOP3 form, what the traversal loop's selects compile to)
+				asm volatile("s_mov_b32 s10, 0x55555555\n s_mov_b32 s11, 0x55555555\n" REP8("v_cndmask_b32_e64 %0, %0, %8, s[10:11]\n v_cndmask_b32_e64 %1, %1, %8, s[10:11]\n v_cndmask_b32_e64 %2, %2, %9, s[10:11]\n v_cndmask_b32_e64 %3, %3, %9, s[10:11]\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c)
+							 : "s10", "s11");
+			}
+			else if (OP == 7)
+			{
+				// compares writing VCC / an SGPR pair
+				asm volatile(REP8("v_cmp_lt_f32_e32 vcc, %0, %8\n v_cmp_lt_f32_e64 s[10:11], %1, %8\n v_cmp_lt_f32_e32 vcc, %2, %9\n v_cmp_lt_f32_e64 s[10:11], %3, %9\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c)
+							 : "vcc", "s10", "s11");
+			}
+			else if (OP == 8)
+			{
+				// a compare feeding a select, the pattern of a sorting-network comparator
+				asm volatile(REP8("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %2, %0, %1, vcc\n v_cmp_lt_f32_e64 s[10:11], %1, %3\n v_cndmask_b32_e64 %3, %1, %0, s[10:11]\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c)
+							 : "vcc", "s10", "s11");
+			}
+			else if (OP == 9)
+			{
+				asm volatile(REP8("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_min_f32 %2, %2, %9\n v_max_f32 %3, %3, %9\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c));
+			}
 			else if (OP == 5)
 			{
 				// 32 packed instructions = 64 fmas per lane
@@ -103,7 +133,7 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 
 template <int OP> static void run(const char *name, float *out, uint64_t *cyc, uint64_t *h, int blocks)
 {
-	for (int mode = 0; mode < 10; mode++)
+	for (int mode = 0; mode < (OP >= 6 ? 2 : 10); mode++)
 	{
 		hipEvent_t a, b;
 		CHECK(hipEventCreate(&a));
@@ -142,5 +172,9 @@ int main()
 	run<3>("v_cndmask", out, cyc, h, blocks);
 	run<4>("v_mov", out, cyc, h, blocks);
 	run<5>("v_pk_fma", out, cyc, h, blocks);
+	run<6>("cndmask_s", out, cyc, h, blocks);
+	run<7>("v_cmp", out, cyc, h, blocks);
+	run<8>("cmp+cndmsk", out, cyc, h, blocks);
+	run<9>("v_min/max", out, cyc, h, blocks);
 	return 0;
 }
