@@ -112,6 +112,19 @@ template <int OP> __global__ __launch_bounds__(256) void k_valu(float *out, uint
 							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
 							 : "v"(m), "v"(c));
 			}
+			else if (OP == 10)
+			{
+				// mixed-precision fma: f16 half of src0 (op_sel picks lo / hi) x f32 + f32
+				asm volatile(REP8("v_fma_mix_f32 %0, %4, %8, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %5, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %6, %9, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %7, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c));
+			}
+			else if (OP == 11)
+			{
+				asm volatile(REP8("v_perm_b32 %0, %4, %5, %8\n v_perm_b32 %1, %5, %6, %8\n v_perm_b32 %2, %6, %7, %9\n v_perm_b32 %3, %7, %4, %9\n")
+							 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+							 : "v"(m), "v"(c));
+			}
 			else if (OP == 5)
 			{
 				// 32 packed instructions = 64 fmas per lane
@@ -176,5 +189,7 @@ int main()
 	run<7>("v_cmp", out, cyc, h, blocks);
 	run<8>("cmp+cndmsk", out, cyc, h, blocks);
 	run<9>("v_min/max", out, cyc, h, blocks);
+	run<10>("fma_mix", out, cyc, h, blocks);
+	run<11>("v_perm", out, cyc, h, blocks);
 	return 0;
 }
