@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--stage-rates", action="store_true",
                     help="also render one serialised frame (streams = 1) and report Mrays/s per stage; off by default so "
                          "that a kernel trace of the default command holds the timed region's launches only")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra rendercore setting(s) for A/B runs, e.g. --set sample_group=1 (recorded in config.settings)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
@@ -155,6 +157,9 @@ def main():
     ctx.set_setting("streams", args.streams)
     ctx.set_setting("lds_nodes", args.lds_nodes)
     ctx.set_setting("overlap", args.overlap)
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        ctx.set_setting(k, v)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()

@@ -367,6 +367,10 @@ struct rfwhip_context
 	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
+	int sample_group = 32; // slot layout: up to this many samples of a pixel share a wave (rt_core.h; the largest power of two
+						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample)
+	uint32_t knob[4] = {0, 0, 0, 0};
+	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
 	// scene (host side)
@@ -1530,6 +1534,8 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	p.fr.sample_base = c->samples_done;
 	p.fr.probe_pixel = c->probe_y * c->W + c->probe_x;
 	p.max_depth = (uint32_t)c->max_depth;
+	for (int k = 0; k < 4; k++)
+		p.knob[k] = c->knob[k];
 	p.parity_no_jitter = c->jitter == 1;
 	// LDS top-of-tree cache: the first nodes (breadth-first top, bvh::collapse4) of the BLAS with the most nodes
 	p.lds_first = 0, p.lds_count = 0;
@@ -1636,6 +1642,18 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	if (subs < std::min(4, c->streams))
 		subs = 1;
 	const bool alternate = subs == 1;
+	// sample groups of the slot layout (rt_core.h): the largest power of two <= sample_group at which every sub-batch begins
+	uint32_t sgroup_log2 = 0;
+	while ((2 << sgroup_log2) <= c->sample_group)
+	{
+		const int g = 2 << sgroup_log2;
+		bool ok = c->spp % g == 0;
+		for (int k = 1; k < subs && ok; k++)
+			ok = (int)((long long)c->spp * k / subs) % g == 0;
+		if (!ok)
+			break;
+		sgroup_log2++;
+	}
 	// ring of buffer sets: a single-sub-batch call uses set (call number mod ring) of everything — up to `ring` calls are
 	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only
 	const int ring = alternate ? (paths > 150000000u ? std::min(c->ring, 2) : c->ring) : 2; // (4 x 200 B x 150 M = 120 GB)
@@ -1696,7 +1714,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	if (rng_prologue)
 		RF_TRY(dm::event_record(c->ev_prologue, s0));
 	const bool count = c->count_traversal != 0;
-	const uint32_t row_group = std::max(1u, c->fr.tiles_x / 4u); // primary wave: one row of 8x8 tiles per XCD group
+	const uint32_t row_group = std::max(1u, (c->fr.tiles_x << sgroup_log2) / 4u); // primary wave: one row of 8x8 tiles per XCD group
 	const uint32_t par = c->call_slot;							 // buffer set of this call
 	const uint32_t prev = (par + (uint32_t)ring - 1u) % (uint32_t)ring; // ... and of the previous one
 	const bool connect = c->integrator == 1 && total_light_count(c) > 0 && c->max_depth > 0;
@@ -1707,6 +1725,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1 && !pipelined));
 	rtk::Params base;
 	fill_params(c, cam, base);
+	base.fr.sgroup_log2 = sgroup_log2;
+	c->sgroup_last = sgroup_log2;
 	base.wv.rad = alternate ? c->d_rad[0].as<f4>() + paths * par : c->d_rad[par].as<f4>();
 	// the connections always add into their own buffer, on a side stream or not: the image is then bit-identical whichever way
 	// a call is scheduled (e.g. the ranks of a strip split against the single-rank image)
@@ -2038,7 +2058,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2118,6 +2138,15 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "ring must be in [1, %d]", (int)rfwhip_context::MAX_RING);
 		c->ring = n;
 	}
+	else if (k.size() == 5 && k.compare(0, 4, "knob") == 0 && k[4] >= '0' && k[4] <= '3')
+		c->knob[k[4] - '0'] = (uint32_t)atoi(value);
+	else if (k == "sample_group")
+	{
+		const int n = atoi(value);
+		if (n < 1 || n > 64 || (n & (n - 1)))
+			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "sample_group must be a power of two in [1, 64]");
+		c->sample_group = n;
+	}
 	else if (k == "overlap")
 	{
 		const int n = atoi(value);
@@ -2171,6 +2200,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->ring);
 	else if (k == "overlap")
 		snprintf(value, cap, "%d", c->overlap);
+	else if (k == "sample_group")
+		snprintf(value, cap, "%d", c->sample_group);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
@@ -2246,7 +2277,10 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	if (!c->W || c->wave_capacity == 0)
 		return set_error(RFWHIP_ERR_STATE, "no frame rendered yet");
 	RF_TRY(sync_all(c));
-	const size_t slots = c->fr.slots;
+	// the first sample of the most recent call's first sub-batch lives in that sub-batch's first sample group
+	rt::FrameView fr = c->fr;
+	fr.sgroup_log2 = c->sgroup_last;
+	const size_t slots = (size_t)c->fr.slots << fr.sgroup_log2;
 	std::vector<f4> h(slots);
 	std::vector<int> hi(slots);
 	RF_TRY(dm::d2h(h.data(), c->d_hit0.as<f4>() + c->last_wave_off, slots * sizeof(f4), c->stream));
@@ -2276,7 +2310,7 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 			if (parity && (x >= (c->W / 4u) * 4u || y >= (c->H / 2u) * 2u))
 				continue;
 			const uint32_t tile = (yl / rt::TILE) * c->fr.tiles_x + x / rt::TILE;
-			const uint32_t slot = tile * 64u + (yl % rt::TILE) * rt::TILE + (x % rt::TILE);
+			const size_t slot = (size_t)rt::pixel_to_slot(fr, tile, (yl % rt::TILE) * rt::TILE + (x % rt::TILE), 0u);
 			const size_t o = (size_t)y * c->W + x;
 			int pr;
 			memcpy(&pr, &h[slot].w, 4);

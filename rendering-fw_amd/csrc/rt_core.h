@@ -144,8 +144,16 @@ RT_FN float random_float(uint32_t &s)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pixel <-> path-slot mapping.  Within one sample, slots run over 8x8 tiles (one tile per wave), tiles row-major
-// over the rank's compacted local image; samples of a batch are stacked: slot = s * frame.slots + tile*64 + lane.
+// pixel <-> path-slot mapping.  Within one sample, pixels run over 8x8 tiles, tiles row-major over the rank's compacted local
+// image.  Samples of a batch are laid out in GROUPS of g = 2^sgroup_log2 (g <= 64, every sub-batch of a call is a multiple
+// of g): one group of one tile is 64 g consecutive slots, pixel-major —
+//     slot = sgroup * (g * slots) + tile * 64 g + pix * g + si,        sample = sgroup * g + si, pix = 0..63 row-major,
+// so a wave (64 consecutive slots) holds the g samples of 64 / g neighbouring pixels.  g = 1 is the plain layout (slot =
+// s * slots + tile * 64 + pix: a wave = one 8x8 tile of one sample).  With g = 32 a wave is 2 neighbouring pixels x 32
+// samples: its primary rays differ by sub-pixel jitter only, walk the same nodes and reach the same leaves in step — the
+// two phases of the while-while traversal stay converged (the same holds for the shadow rays their first vertices emit).
+// The layout only decides which path sits where; a pixel's samples are still summed in sample order (resolve_item), so the
+// image does not depend on g.
 // ---------------------------------------------------------------------------------------------------------------
 struct PixelRef
 {
@@ -161,12 +169,15 @@ RT_FN uint32_t local_to_global_row(const FrameView &fr, uint32_t yl)
 RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
 {
 	PixelRef p;
-	p.sample = slot / fr.slots;
-	const uint32_t lp = slot - p.sample * fr.slots;
-	const uint32_t tile = lp >> 6, lane = lp & 63u;
+	const uint32_t gl = fr.sgroup_log2;
+	const uint32_t per_group = fr.slots << gl;
+	const uint32_t sgroup = slot / per_group;
+	const uint32_t rem = slot - sgroup * per_group;
+	const uint32_t tile = rem >> (6u + gl), pix = (rem >> gl) & 63u;
+	p.sample = (sgroup << gl) + (rem & ((1u << gl) - 1u));
 	const uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
-	p.x = tx * TILE + (lane & 7u);
-	const uint32_t yl = ty * TILE + (lane >> 3);
+	p.x = tx * TILE + (pix & 7u);
+	const uint32_t yl = ty * TILE + (pix >> 3);
 	p.y = local_to_global_row(fr, yl);
 	p.local = yl * fr.W + p.x;
 	p.valid = p.x < fr.W && p.y < fr.H;

@@ -294,7 +294,16 @@ struct FrameView
 	uint32_t spp;		   // samples in this batch
 	uint32_t sample_base;  // index of the first sample of the batch
 	uint32_t probe_pixel;  // y*W + x
+	uint32_t sgroup_log2;  // log2 of the sample group g (rt_core.h: slot layout): a wave's 64 slots = 64/g pixels x g samples
 };
+
+// Slot layout (rt_core.h, "pixel <-> path-slot mapping"): slot of sample s (within the batch) of pixel `pix` (0..63, row-major) of tile `tile`
+RT_FN unsigned long long pixel_to_slot(const FrameView &fr, uint32_t tile, uint32_t pix, uint32_t s)
+{
+	const uint32_t gl = fr.sgroup_log2;
+	const uint32_t sgroup = s >> gl, si = s & ((1u << gl) - 1u);
+	return ((unsigned long long)sgroup * fr.slots << gl) + ((unsigned long long)tile << (6u + gl)) + (pix << gl) + si;
+}
 
 // Device counters, zeroed per render call.  ext[d] = number of paths entering depth d (ext[0] is set by the host),
 // shadow[d] = shadow rays emitted by the shade stage of depth d.

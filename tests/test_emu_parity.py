@@ -327,7 +327,9 @@ def test_image_is_independent_of_how_calls_are_scheduled(pkg, make_emu, integrat
     base = {"integrator": integrator, "spp": 4, "max_depth": 2}
     ref = _pipelined(pkg, make_emu(), scene, 64, 48, dict(base, ring=1, streams=1), 6, 1)
     for extra, wait_every in (({"ring": 2}, 0), ({"ring": 4}, 0), ({"ring": 4}, 3), ({"ring": 4, "overlap": 1}, 0),
-                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2)):
+                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2),
+                              ({"sample_group": 1}, 0), ({"sample_group": 2, "ring": 2}, 0), ({"sample_group": 64}, 1),
+                              ({"sample_group": 4, "streams": 2, "sub_batch_paths": 1}, 0)):
         img = _pipelined(pkg, make_emu(), scene, 64, 48, dict(base, **extra), 6, wait_every)
         assert np.array_equal(img, ref), (extra, wait_every)
 
@@ -350,3 +352,27 @@ def test_changing_the_batch_size_between_pipelined_calls(pkg, make_emu):
         a.set_setting("ring", 5)
     with pytest.raises(RuntimeError):
         a.set_setting("sub_batch_paths", 0)
+
+
+@pytest.mark.parametrize("group", [1, 8, 64])
+def test_sample_groups_of_the_slot_layout(pkg, make_emu, group):
+    """The slot layout puts up to `sample_group` samples of a pixel into one wave (rt_core.h): which path sits where never
+    changes a pixel — image, primary hits (read back through the layout) and wave counts equal the plain layout's, on an
+    image with partial tiles (70 x 51) and a batch the group does not divide evenly into sub-batches."""
+    scene = pkg.scenes.cornell(70, 51, geometric_emitter=True)
+    out = []
+    for g in (1, group):
+        c = make_emu()
+        c.init(70, 51)
+        scene.upload(c)
+        for k, v in {"integrator": "pt", "spp": 24, "max_depth": 2, "sample_group": g, "streams": 3, "sub_batch_paths": 1}.items():
+            c.set_setting(k, v)
+        c.render_frame(scene.camera, pkg.RESET)
+        st = c.get_stats()
+        out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert out[0][2] == out[1][2]
+    with pytest.raises(RuntimeError):
+        c.set_setting("sample_group", 3)

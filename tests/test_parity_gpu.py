@@ -440,7 +440,9 @@ def test_image_is_independent_of_how_calls_are_scheduled_gpu(pkg, make_hip, inte
     base = {"integrator": integrator, "spp": 4, "max_depth": 2}
     ref = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, ring=1, streams=1), 8, 1)
     for extra, wait_every in (({"ring": 2}, 0), ({"ring": 4}, 0), ({"ring": 4}, 3), ({"ring": 4, "overlap": 1}, 0),
-                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2)):
+                              ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2),
+                              ({"sample_group": 1}, 0), ({"sample_group": 2, "ring": 2}, 0), ({"sample_group": 64}, 1),
+                              ({"sample_group": 4, "streams": 2, "sub_batch_paths": 1}, 0)):
         img = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, **extra), 8, wait_every)
         assert np.array_equal(img, ref), (extra, wait_every)
 
