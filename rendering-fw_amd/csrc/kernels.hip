@@ -372,7 +372,7 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	{
 		const f4 o4 = p.wv.sh_org[i], d4 = p.wv.sh_dir[i];
 		Hit h;
-		if (d4.w < 0.0f) // void entry
+		if (fbits(o4.w) == RAY_VOID) // void entry (a real shadow ray may carry tmax < 0: it is traced, hits nothing, and counts)
 			active = false;
 		else if (!trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st))
 		{
@@ -970,7 +970,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 					{
 						const f4 o4 = ray_o[idx], d4 = ray_d[idx];
 						// void entries (the unfilled rest of a shade wave's last queue block) are skipped
-						if (ANY ? d4.w < 0.0f : fbits(o4.w) == RAY_VOID)
+						if (fbits(o4.w) == RAY_VOID)
 						{
 							if (!ANY)
 								p.wv.hit[idx] = mk4(0, 0, 0, ubits((uint32_t)HIT_VOID));
@@ -1144,7 +1144,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	for (uint32_t s = ctx.q_ext.pos + lane; s < ctx.q_ext.end; s += 64u)
 		p.wv.org[nb][s] = mk4(0, 0, 0, ubits(RAY_VOID));
 	for (uint32_t s = ctx.q_shadow.pos + lane; s < ctx.q_shadow.end; s += 64u)
-		p.wv.sh_dir[s] = mk4(0, 0, 1, -1.0f);
+		p.wv.sh_org[s] = mk4(0, 0, 0, ubits(RAY_VOID));
 	if (lane == 0u)
 	{
 		if (ctx.q_ext.rays)

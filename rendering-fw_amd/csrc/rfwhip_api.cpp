@@ -92,6 +92,11 @@ static void release(void *p)
 	if (p)
 		(void)hipFree(p);
 }
+static void mem_info(size_t *free_b, size_t *total_b)
+{
+	if (hipMemGetInfo(free_b, total_b) != hipSuccess)
+		*free_b = *total_b = ~(size_t)0;
+}
 static int h2d(void *d, const void *h, size_t n, void *s)
 {
 	if (n)
@@ -184,6 +189,7 @@ static int alloc(void **p, size_t bytes)
 	return *p ? 0 : set_error(RFWHIP_ERR_HIP, "out of memory");
 }
 static void release(void *p) { free(p); }
+static void mem_info(size_t *free_b, size_t *total_b) { *free_b = *total_b = ~(size_t)0; }
 static int h2d(void *d, const void *h, size_t n, void *)
 {
 	memcpy(d, h, n);
@@ -250,6 +256,21 @@ struct DevBuf
 		cap = want;
 		return 0;
 	}
+	// exactly `bytes` (the path-state buffers: tens of GB, no headroom); an existing larger allocation is kept
+	int ensure_exact(size_t bytes)
+	{
+		if (bytes <= cap && p)
+			return 0;
+		dm::release(p);
+		p = nullptr, cap = 0;
+		if (dm::alloc(&p, bytes + 256))
+		{
+			p = nullptr;
+			return RFWHIP_ERR_HIP;
+		}
+		cap = bytes + 256;
+		return 0;
+	}
 	void free_()
 	{
 		dm::release(p);
@@ -278,6 +299,7 @@ struct MeshRec
 	// built on the device (builder=device): no host copy of the tree; the mesh-local device arrays below are what
 	// rfwhip_update() places (device-to-device copies + an entry rebase)
 	bool device_built = false;
+	bool built = false; // the last (re)build of this mesh succeeded: the counts below describe its tree
 	DevBuf d_b_nodes, d_b_nodes4, d_b_src, d_b_tri_verts;
 	uint32_t node_count2 = 0, n4_count = 0; // BVH2 nodes / 4-wide nodes of the mesh, whoever built them
 	int stack_need = 0;		   // worst-case traversal-stack entries of the 4-wide tree (bvh::stack_need4)
@@ -395,6 +417,7 @@ struct rfwhip_context
 		d_rad[2], d_rad_nee[2], d_acc, d_counters, d_packet_rng, d_jump_table, d_present;
 	uint32_t samples_done = 0;
 	size_t wave_capacity = 0; // path slots the wave buffers can hold
+	size_t rad_capacity[2] = {0, 0}; // ... and the two radiance sets
 	rt::FrameView fr;
 	bool jump_table_uploaded = false;
 
@@ -585,7 +608,7 @@ static void free_all(rfwhip_context *c)
 	for (int r = 0; r < rfwhip_context::MAX_RING; r++)
 		c->resolve_recorded[r] = false;
 	c->ring_active = 0, c->call_slot = 0;
-	c->wave_capacity = 0;
+	c->wave_capacity = 0, c->rad_capacity[0] = c->rad_capacity[1] = 0;
 	c->blas_nodes4 = 0, c->node4_capacity = 0;
 }
 
@@ -879,6 +902,9 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	// next set_mesh must not take the refit path and the next update must place the mesh again.
 	m.dirty = true, m.resident = false;
 	c->scene_dirty = true;
+	// ... and until the build below has succeeded it describes NO tree (an error return leaves a mesh rfwhip_update() refuses,
+	// not the counts of the previous build beside freed or half-written arrays)
+	m.built = false, m.device_built = false, m.node_count2 = m.n4_count = 0, m.stack_need = 0;
 	const size_t n = mesh->triangleCount;
 	bool device_built = false;
 	if (c->builder == 1 && n > (size_t)BLAS_MAX_LEAF)
@@ -918,10 +944,10 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 			m.bvh = bvh::Result(), m.n4.clear(), m.leaf_verts.clear();
 		}
 	}
-	m.device_built = device_built;
 	if (device_built)
 	{
 		RF_TRY(dm::sync(c->stream));
+		m.device_built = true, m.built = true;
 		return RFWHIP_OK;
 	}
 	if (!device_built)
@@ -963,6 +989,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	RF_TRY(dm::h2d(m.d_parents.p, m.bvh.parents.data(), m.bvh.parents.size() * sizeof(int), c->stream));
 	RF_TRY(m.d_flags.ensure(m.bvh.nodes.size() * sizeof(uint32_t)));
 	RF_TRY(dm::sync(c->stream));
+	m.built = true;
 	return RFWHIP_OK;
 }
 
@@ -1187,6 +1214,9 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		if (c->meshes[i].used && c->meshes[i].max_material >= c->material_count)
 			return set_error(RFWHIP_ERR_STATE, "rfwhip_update: mesh %zu refers to material %u, but %u materials are set",
 							 i, c->meshes[i].max_material, c->material_count);
+	for (size_t i = 0; i < c->meshes.size(); i++)
+		if (c->meshes[i].used && !c->meshes[i].built)
+			return set_error(RFWHIP_ERR_STATE, "rfwhip_update: the last rfwhip_set_mesh of mesh %zu failed; set it again", i);
 	// ---- place meshes in the global arrays (only when some mesh was rebuilt) ----
 	bool relayout = false;
 	size_t live_instances = 0;
@@ -1434,34 +1464,45 @@ extern "C" void rfwhip_camera_get_view(const rfwhip_camera *cam, rfwhip_camera_v
 // render
 // =================================================================================================================
 static int sync_all(rfwhip_context *c);
-static int ensure_wave_buffers(rfwhip_context *c, size_t paths)
+// Path state per slot of the per-ray buffers: origin / direction / throughput x 2 depth parities, hit + instance x 2 (primary
+// wave kept apart), shadow origin / direction / contribution x 2 depth parities = 232 B; radiance: shade + connections = 32 B
+// per radiance slot.  rad_slots[k]: slots of radiance set k (a ring call uses set 0 only, as `ring` slices; a call cut into
+// sub-batches double-buffers sets 0 / 1).
+constexpr size_t WAVE_SLOT_BYTES = 2 * 3 * sizeof(f4) + 2 * (sizeof(f4) + 4) + 2 * 3 * sizeof(f4);
+constexpr size_t RAD_SLOT_BYTES = 2 * sizeof(f4);
+static size_t wave_bytes_held(const rfwhip_context *c);
+static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots0, size_t rad_slots1)
 {
-	if (paths <= c->wave_capacity)
+	const size_t rad_slots[2] = {rad_slots0, rad_slots1};
+	if (paths <= c->wave_capacity && rad_slots0 <= c->rad_capacity[0] && rad_slots1 <= c->rad_capacity[1])
 		return 0;
 	RF_TRY(sync_all(c));
-	const size_t b16 = paths * sizeof(f4);
-	for (int k = 0; k < 2; k++)
-	{
-		RF_TRY(c->d_org[k].ensure(b16));
-		RF_TRY(c->d_dir2[k].ensure(b16));
-		RF_TRY(c->d_thr[k].ensure(b16));
-	}
-	RF_TRY(c->d_hit.ensure(b16));
-	RF_TRY(c->d_hit_inst.ensure(paths * 4));
-	RF_TRY(c->d_hit0.ensure(b16));
-	RF_TRY(c->d_hit0_inst.ensure(paths * 4));
-	for (int k = 0; k < 2; k++)
-	{
-		RF_TRY(c->d_sh_org[k].ensure(b16));
-		RF_TRY(c->d_sh_dir[k].ensure(b16));
-		RF_TRY(c->d_sh_rad[k].ensure(b16));
-		RF_TRY(c->d_rad[k].ensure(b16));
-		RF_TRY(c->d_rad_nee[k].ensure(b16));
-	}
 	for (int r = 0; r < rfwhip_context::MAX_RING; r++) // (everything was synchronised above)
 		c->resolve_recorded[r] = false;
-	c->wave_capacity = paths;
+	// (a failed allocation leaves the capacities at 0: the next call lays everything out again)
+	c->wave_capacity = 0, c->rad_capacity[0] = c->rad_capacity[1] = 0;
+	const size_t b16 = paths * sizeof(f4);
+	int rc = 0;
+	for (int k = 0; k < 2 && !rc; k++)
+		rc = c->d_org[k].ensure_exact(b16) || c->d_dir2[k].ensure_exact(b16) || c->d_thr[k].ensure_exact(b16) ||
+			 c->d_sh_org[k].ensure_exact(b16) || c->d_sh_dir[k].ensure_exact(b16) || c->d_sh_rad[k].ensure_exact(b16) ||
+			 c->d_rad[k].ensure_exact(rad_slots[k] * sizeof(f4)) || c->d_rad_nee[k].ensure_exact(rad_slots[k] * sizeof(f4));
+	rc = rc || c->d_hit.ensure_exact(b16) || c->d_hit_inst.ensure_exact(paths * 4) || c->d_hit0.ensure_exact(b16) ||
+		 c->d_hit0_inst.ensure_exact(paths * 4);
+	if (rc)
+		return set_error(RFWHIP_ERR_HIP, "out of device memory for the path state: %zu slots x %zu B + %zu radiance slots x %zu B "
+										 "(%.1f GB; lower spp, or ring / streams)", paths, WAVE_SLOT_BYTES, rad_slots0 + rad_slots1,
+						 RAD_SLOT_BYTES, (paths * WAVE_SLOT_BYTES + (rad_slots0 + rad_slots1) * RAD_SLOT_BYTES) * 1e-9);
+	c->wave_capacity = paths, c->rad_capacity[0] = rad_slots0, c->rad_capacity[1] = rad_slots1;
 	return 0;
+}
+static size_t wave_bytes_held(const rfwhip_context *c)
+{
+	size_t n = c->d_hit.cap + c->d_hit_inst.cap + c->d_hit0.cap + c->d_hit0_inst.cap;
+	for (int k = 0; k < 2; k++)
+		n += c->d_org[k].cap + c->d_dir2[k].cap + c->d_thr[k].cap + c->d_sh_org[k].cap + c->d_sh_dir[k].cap + c->d_sh_rad[k].cap +
+			 c->d_rad[k].cap + c->d_rad_nee[k].cap;
+	return n;
 }
 
 static dm::event_t *next_event(rfwhip_context *c)
@@ -1655,21 +1696,46 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		sgroup_log2++;
 	}
 	// ring of buffer sets: a single-sub-batch call uses set (call number mod ring) of everything — up to `ring` calls are
-	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only
-	const int ring = alternate ? (paths > 150000000u ? std::min(c->ring, 2) : c->ring) : 2; // (4 x 200 B x 150 M = 120 GB)
-	if (ring != c->ring_active || paths != c->paths_active || subs != c->subs_active)
-	{
-		// the calls in flight lay their records out for another ring / batch size
-		RF_TRY(sync_all(c));
-		for (int r = 0; r < rfwhip_context::MAX_RING; r++)
-			c->resolve_recorded[r] = false;
-		c->ring_active = ring, c->paths_active = paths, c->subs_active = subs, c->call_slot = 0;
-	}
+	// in flight, each a full-size launch chain; a call cut into sub-batches double-buffers its radiance only.  The ring is as
+	// deep as the setting allows and the device's free memory holds (264 B of path state per slot and ring entry: 1080p at
+	// 64 spp = 133 M slots = 35 GB per entry); when it does not fit, 2 and then 1 entries are tried before the call fails.
 	// the extension / shadow queues are filled in blocks (rt_types.h: QUEUE_BLOCK): every sub-batch's slice of the per-ray
 	// buffers has room for the void entries of its waves' last blocks behind the rays
 	const size_t pad = rtk::queue_pad((uint32_t)std::min<size_t>(paths, 0xFFFFFFFFu));
-	const size_t wave_slots = alternate ? (size_t)ring * (paths + pad) : paths + (size_t)subs * pad;
-	RF_TRY(ensure_wave_buffers(c, wave_slots));
+	int ring = alternate ? c->ring : 2;
+	for (;;)
+	{
+		const size_t wave_slots = alternate ? (size_t)ring * (paths + pad) : paths + (size_t)subs * pad;
+		const size_t rad0 = alternate ? (size_t)ring * paths : paths, rad1 = alternate ? 0 : paths;
+		const bool fits_as_is = wave_slots <= c->wave_capacity && rad0 <= c->rad_capacity[0] && rad1 <= c->rad_capacity[1];
+		if (alternate && ring > 1 && !fits_as_is)
+		{
+			size_t free_b = 0, total_b = 0;
+			dm::mem_info(&free_b, &total_b);
+			const double avail = 0.94 * ((double)free_b + (double)wave_bytes_held(c));
+			if ((double)wave_slots * WAVE_SLOT_BYTES + (double)(rad0 + rad1) * RAD_SLOT_BYTES > avail)
+			{
+				ring = ring > 2 ? 2 : 1;
+				continue;
+			}
+		}
+		if (ring != c->ring_active || paths != c->paths_active || subs != c->subs_active)
+		{
+			// the calls in flight lay their records out for another ring / batch size
+			RF_TRY(sync_all(c));
+			for (int r = 0; r < rfwhip_context::MAX_RING; r++)
+				c->resolve_recorded[r] = false;
+			c->ring_active = ring, c->paths_active = paths, c->subs_active = subs, c->call_slot = 0;
+		}
+		const int rc = ensure_wave_buffers(c, wave_slots, rad0, rad1);
+		if (rc && alternate && ring > 1) // (the estimate was too optimistic: another process, fragmentation)
+		{
+			ring = ring > 2 ? 2 : 1;
+			continue;
+		}
+		RF_TRY(rc);
+		break;
+	}
 	RF_TRY(ensure_sub_batches(c, alternate ? ring : subs));
 	const bool pipelined = c->render_pending; // the caller enqueues calls without waiting for them in between
 	if (!c->render_pending)
@@ -1875,8 +1941,6 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	}
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
-	if (stack_overflow)
-		return set_error(RFWHIP_ERR_STATE, "traversal stack overflow: %u entries dropped in the last frame (the image is wrong)", stack_overflow);
 	rfwhip_render_stats &st = c->stats;
 	const float anim = st.animationTime;
 	memset(&st, 0, sizeof(st));
@@ -1931,6 +1995,9 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		st.renderTime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->render_t0).count();
 		c->render_pending = false;
 	}
+	// (reported last: the bookkeeping above is complete, so the context stays usable after the error)
+	if (stack_overflow)
+		return set_error(RFWHIP_ERR_STATE, "traversal stack overflow: %u entries dropped in the last frame (the image is wrong)", stack_overflow);
 	return RFWHIP_OK;
 }
 
@@ -2342,7 +2409,7 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 	if (n >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_trace_rays: too many rays");
 	RF_TRY(sync_all(c)); // the wave buffers are shared with the sub-batch streams of a render in flight
-	RF_TRY(ensure_wave_buffers(c, n));
+	RF_TRY(ensure_wave_buffers(c, std::max(n, c->wave_capacity), c->rad_capacity[0], c->rad_capacity[1]));
 	std::vector<f4> o4(n), d4(n);
 	for (size_t i = 0; i < n; i++)
 	{

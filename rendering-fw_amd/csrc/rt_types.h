@@ -312,14 +312,14 @@ constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch
 // The extension / shadow queues are filled in BLOCKS: a wave of the shade kernel reserves QUEUE_BLOCK slots with one atomic
 // and hands them out wave-locally (a device-scope atomic on one address completes about every 7 ns on this part: one per
 // shade call and queue was 1 M atomics = 7 ms per 32-spp launch — the whole shade kernel).  What a wave has left of its last
-// block when the kernel ends is filled with VOID entries (extension ray: slot bits all ones; shadow ray: tmax < 0), which
+// block when the kernel ends is filled with VOID entries (slot bits of the origin record all ones, extension and shadow rays alike), which
 // the consumers skip; the hit record of a void extension ray carries HIT_VOID so that the next shade stage skips it too.
 // ext_n / shadow_n are the queue lengths including void entries (what the consumers iterate over), ext / shadow the rays.
 #ifndef RT_QUEUE_BLOCK
 #define RT_QUEUE_BLOCK 256u
 #endif
 constexpr uint32_t QUEUE_BLOCK = RT_QUEUE_BLOCK;
-constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w of a void extension-queue entry
+constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w / sh_org.w of a void queue entry (slots are < 2^31)
 constexpr int HIT_VOID = -2;			   // hit.prim of a void entry (-1: miss)
 struct WaveCounters
 {
