@@ -40,8 +40,11 @@ RFWHIP_API const char *rfwhip_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------
  * createRenderContext / destroyRenderContext   (RFW/system/context/rfw/context/export.h:8-15)
- * rank/world: this process renders the image rows whose 8-row strip index s satisfies s % world == rank
- * (SURVEY §8e); world = 1 renders everything. */
+ * rank/world: this context renders the 8-row strips it owns.  Strips are dealt to the ranks in periods of
+ * `world`, forwards in even periods and backwards in odd ones (0 1 .. w-1 | w-1 .. 1 0 | ...): strip s belongs to rank
+ * (s / world) odd ? world - 1 - s % world : s % world — NOT plain s % world (rows get dearer down an image of terrain
+ * under sky, and the serpentine cancels that gradient).  A host that gathers local framebuffers itself de-interleaves
+ * with rfwhip_deinterleave_*; rfwhip_group_* / rfwhip_comm_* below do the whole gather.  world = 1 renders everything. */
 RFWHIP_API int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_context **out);
 /* RenderContext::cleanup() (context.h:93).  Idempotent: the reference calls it twice on unload
  * (system.cpp:160-178 + EmbreeRT/src/Context.cpp:30). */
@@ -127,6 +130,60 @@ RFWHIP_API int rfwhip_read_local_framebuffer_stream(rfwhip_context *ctx, void *r
 RFWHIP_API int rfwhip_deinterleave_stream(rfwhip_context *ctx, const void *gathered_device, void *rgba_device,
 										  void *hip_stream);
 
+/* Where a context runs and what it renders into (for hosts that move its strips themselves). */
+RFWHIP_API int rfwhip_get_placement(rfwhip_context *ctx, int *device_ordinal, int *rank, int *world);
+RFWHIP_API int rfwhip_get_target_size(rfwhip_context *ctx, uint32_t *width, uint32_t *height);
+
+/* ---- multi-GPU below this ABI (no counterpart in the reference, which renders on one device) ------------
+ * The frame is split into interleaved 8-row strips over `world` devices of one node, each device holds the whole scene,
+ * and per presented frame the rank-local strips are gathered ONCE into the root's (rank 0's) HBM and de-interleaved
+ * there.  Transport: RCCL point-to-point over xGMI (ncclSend on every rank, world - 1 ncclRecv on the root, one
+ * ncclGroup), or peer copies (hipMemcpyPeerAsync).  Everything below is enqueue-only unless it says it waits.
+ *
+ * rfwhip_group_*: ONE process, ONE thread drives n devices — the reference's host model (RFW/system/src/rfw/app.cpp:3-26).
+ *   create   n contexts, context i = rank i of world n on devices[i]; a device may be listed more than once only with the
+ *            peer transport (tests on one GPU).  AUTO = RCCL when the devices are distinct and librccl.so opens.
+ *   context  the i-th context, for the scene calls: the host repeats every rfwhip_set_* per context (each device keeps
+ *            its own copy of the scene), then calls rfwhip_group_update.
+ *   init / update / set_setting / render / wait   the context call of the same name on every rank.
+ *   gather   present on every rank -> transfer -> de-interleave into the group's full image on the root's device.
+ *   read_framebuffer   gather + wait + copy to the host: width * height float4.
+ *   framebuffer_device the root-side image (valid after a gather has completed) and the device it lives on. */
+enum rfwhip_transport
+{
+	RFWHIP_TRANSPORT_AUTO = 0,
+	RFWHIP_TRANSPORT_RCCL = 1,
+	RFWHIP_TRANSPORT_PEER = 2
+};
+typedef struct rfwhip_group rfwhip_group;
+RFWHIP_API int rfwhip_group_create(const int *devices, int n, int transport, rfwhip_group **out);
+RFWHIP_API void rfwhip_group_destroy(rfwhip_group *group);
+RFWHIP_API int rfwhip_group_size(const rfwhip_group *group);
+RFWHIP_API int rfwhip_group_transport(const rfwhip_group *group);
+RFWHIP_API rfwhip_context *rfwhip_group_context(rfwhip_group *group, int rank);
+RFWHIP_API int rfwhip_group_init(rfwhip_group *group, uint32_t width, uint32_t height);
+RFWHIP_API int rfwhip_group_update(rfwhip_group *group);
+RFWHIP_API int rfwhip_group_set_setting(rfwhip_group *group, const char *key, const char *value);
+RFWHIP_API int rfwhip_group_render(rfwhip_group *group, const rfwhip_camera *camera, int status);
+RFWHIP_API int rfwhip_group_gather(rfwhip_group *group);
+RFWHIP_API int rfwhip_group_wait(rfwhip_group *group);
+RFWHIP_API int rfwhip_group_read_framebuffer(rfwhip_group *group, float *rgba_host);
+RFWHIP_API int rfwhip_group_framebuffer_device(rfwhip_group *group, void **rgba_device, int *device_ordinal);
+
+/* rfwhip_comm_*: one process per device (e.g. under torch.distributed.run).  Rank 0 calls rfwhip_comm_unique_id and
+ * hands the RFWHIP_COMM_ID_BYTES bytes to the other ranks by any means (a file, MPI, a torch broadcast); then EVERY rank
+ * calls rfwhip_comm_create with its context (rank / world as given to rfwhip_create) — a collective call, like
+ * ncclCommInitRank.  rfwhip_comm_gather is collective too: every rank presents and sends, the root receives and
+ * de-interleaves into rgba_device (width * height float4 on its device; ignored on the other ranks; NULL = an internal
+ * buffer).  The transport is RCCL; nothing but the id travels outside this library. */
+#define RFWHIP_COMM_ID_BYTES 128
+typedef struct rfwhip_comm rfwhip_comm;
+RFWHIP_API int rfwhip_comm_unique_id(void *id, size_t cap);
+RFWHIP_API int rfwhip_comm_create(rfwhip_context *ctx, const void *id, rfwhip_comm **out);
+RFWHIP_API void rfwhip_comm_destroy(rfwhip_comm *comm);
+RFWHIP_API int rfwhip_comm_gather(rfwhip_comm *comm, void *rgba_device);
+RFWHIP_API int rfwhip_comm_wait(rfwhip_comm *comm);
+
 /* get_probe_results / set_probe_index                                                       context.h:104,109 */
 RFWHIP_API int rfwhip_set_probe_index(rfwhip_context *ctx, uint32_t x, uint32_t y);
 RFWHIP_API int rfwhip_get_probe_results(rfwhip_context *ctx, uint32_t *instance_index, uint32_t *primitive_index,
@@ -139,8 +196,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   spp          = samples per pixel enqueued by one rfwhip_render call (default 1)
  *   max_depth    = MAX_PATH_LENGTH of the pt integrator (settings.h:5, default 2)
  *   jitter       = "xor128" (EmbreeRT: rfw::utils::xor128 stream) | "center" (r0=r1=0.5) — parity integrator only
- *   builder      = "host" (parallel binned SAH on the CPU, the default) | "device" (Morton order + Karras hierarchy on the
- *                  GPU, lbvh.hip; applies to the next rfwhip_set_mesh that (re)builds)
+ *   builder      = "host" (parallel binned SAH on the CPU, the default) | "device" (on the GPU, lbvh.hip: 63-bit Morton
+ *                  order, parallel locally-ordered clustering (PLOC), device collapse to 4-wide nodes; applies to the next
+ *                  rfwhip_set_mesh that (re)builds)
  *   sampler      = "hash" (WangHash + xorshift32, tools.h:218-235; default) | "bluenoise" (needs rfwhip_set_blue_noise)
  *                  — pt integrator: primary rays (dimensions 0-3, Kernels.cu:391-394) and, for the first 256 samples, the
  *                  light sample of next-event estimation (dimensions 4-5, Kernels.cu:712-719)
@@ -153,7 +211,10 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  (hides kernel tails when launches are small); "0": in order on the sub-batch's stream; "-1" (default):
  *                  chosen by the size of the render call
  *   sub_batch_paths = a render call's spp are cut into concurrent sub-batches only if each gets at least this many path
- *                  slots and there are four of them (default 50000000)
+ *                  slots and there are four of them (default 50000000: 1080p from 128 spp per call)
+ *   sample_group = slot layout: up to this many samples of a pixel sit side by side in one wave (power of two <= 64,
+ *                  default 32; the largest such group that divides every sub-batch of a call is used; 1 = a wave is one
+ *                  8x8 tile of one sample).  Changes which path sits where, never the image
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 4)
  *   refill       = bit mask, default 7: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,
@@ -169,7 +230,7 @@ typedef struct rfwhip_counters
 {
 	uint64_t rays_extend;	 /* closest-hit rays traced since the last reset (primary + extension) */
 	uint64_t rays_shadow;	 /* any-hit rays traced */
-	uint64_t inner_extend;	 /* popped 4-wide inner nodes (7 rows of 16 B each), closest-hit rays */
+	uint64_t inner_extend;	 /* popped 4-wide inner nodes (64 bytes = 4 rows of 16 B each), closest-hit rays */
 	uint64_t tris_extend;	 /* triangle tests, closest-hit rays */
 	uint64_t inner_shadow;
 	uint64_t tris_shadow;

@@ -12,7 +12,7 @@ from . import gltf
 from . import obj
 from .abi import CONVERGE, RESET
 from .camera import Camera
-from .context import LIB_PATH, RenderContext, load_library
+from .context import LIB_PATH, RenderContext, load_library, render_group
 from .build import build as build_native
 
-__all__ = ["abi", "scenes", "gltf", "obj", "Camera", "RenderContext", "load_library", "LIB_PATH", "build_native", "RESET", "CONVERGE"]
+__all__ = ["abi", "scenes", "gltf", "obj", "Camera", "RenderContext", "load_library", "render_group", "LIB_PATH", "build_native", "RESET", "CONVERGE"]

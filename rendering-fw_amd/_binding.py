@@ -17,12 +17,17 @@ def _f32(a):
 
 
 class CoreBinding:
-    def __init__(self, lib, prefix, device=0, rank=0, world=1):
+    def __init__(self, lib, prefix, device=0, rank=0, world=1, borrowed=None):
+        """borrowed: an existing context pointer owned by somebody else (a RenderGroup): used, never destroyed."""
         self._lib = lib
         self._p = prefix
         self._ctx = C.c_void_p()
+        self._borrowed = borrowed is not None
         self._declare()
-        self._check(self._fn("create")(int(device), int(rank), int(world), C.byref(self._ctx)))
+        if borrowed is not None:
+            self._ctx = C.c_void_p(borrowed)
+        else:
+            self._check(self._fn("create")(int(device), int(rank), int(world), C.byref(self._ctx)))
         self.rank, self.world = rank, world
         self.width = self.height = 0
 
@@ -99,9 +104,9 @@ class CoreBinding:
             self._check(self._fn("cleanup")(self._ctx))
 
     def destroy(self):
-        if self._ctx:
+        if self._ctx and not self._borrowed:
             self._fn("destroy")(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -311,3 +316,100 @@ class CoreBinding:
         self._check(self._fn("get_bvh")(self._ctx, int(mesh_index), nodes.ctypes.data, len(nodes), prims.ctypes.data,
                                         len(prims), C.byref(nn), C.byref(np_)))
         return nodes, prims
+
+
+class RenderGroup:
+    """n devices driven by ONE host thread through rfwhip_group_* (include/rfwhip.h): context i renders the strips of rank i
+    of world n, one gather per presented frame lands the image on the root's device.  Looks like one RenderContext to the
+    scene code: every set_* is repeated per context (each device holds the whole scene)."""
+    TRANSPORTS = {"auto": 0, "rccl": 1, "peer": 2}
+
+    def __init__(self, lib, prefix, devices, transport="auto"):
+        self._lib, self._p = lib, prefix
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        for name, res, args in [("group_create", i32, [C.POINTER(i32), i32, i32, C.POINTER(vp)]), ("group_destroy", None, [vp]),
+                                ("group_size", i32, [vp]), ("group_transport", i32, [vp]), ("group_context", vp, [vp, i32]),
+                                ("group_init", i32, [vp, u32, u32]), ("group_update", i32, [vp]),
+                                ("group_set_setting", i32, [vp, C.c_char_p, C.c_char_p]),
+                                ("group_render", i32, [vp, C.POINTER(abi.CameraPOD), i32]), ("group_gather", i32, [vp]),
+                                ("group_wait", i32, [vp]), ("group_read_framebuffer", i32, [vp, vp]),
+                                ("group_framebuffer_device", i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
+                                ("last_error", C.c_char_p, [])]:
+            f = self._fn(name)
+            f.restype, f.argtypes = res, args
+        devs = (i32 * len(devices))(*[int(d) for d in devices])
+        self._g = vp()
+        self._check(self._fn("group_create")(devs, len(devices), self.TRANSPORTS[transport], C.byref(self._g)))
+        n = self._fn("group_size")(self._g)
+        self.contexts = [CoreBinding(lib, prefix, rank=i, world=n, borrowed=self._fn("group_context")(self._g, i)) for i in range(n)]
+        self.world, self.width, self.height = n, 0, 0
+        self.transport = {v: k for k, v in self.TRANSPORTS.items()}[self._fn("group_transport")(self._g)]
+
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _check(self, code):
+        if code != 0:
+            raise RuntimeError((self._fn("last_error")() or b"unknown error").decode(errors="replace"))
+
+    def __getattr__(self, name):
+        # scene setters and friends: the same call on every context (set_sky, set_mesh, set_lights, set_blue_noise, ...)
+        if name.startswith("set_") or name in ("pose_mesh", "morph_mesh"):
+            def every(*a, **k):
+                for c in self.contexts:
+                    getattr(c, name)(*a, **k)
+            return every
+        raise AttributeError(name)
+
+    def init(self, width, height):
+        self._check(self._fn("group_init")(self._g, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+        for c in self.contexts:
+            c.width, c.height = self.width, self.height
+
+    def update(self):
+        self._check(self._fn("group_update")(self._g))
+
+    def set_setting(self, key, value):
+        self._check(self._fn("group_set_setting")(self._g, str(key).encode(), str(value).encode()))
+
+    def render_async(self, camera, status=abi.RESET):
+        pod = camera.pod() if hasattr(camera, "pod") else camera
+        self._check(self._fn("group_render")(self._g, C.byref(pod), int(status)))
+
+    def gather(self):
+        self._check(self._fn("group_gather")(self._g))
+
+    def wait(self):
+        self._check(self._fn("group_wait")(self._g))
+
+    def render_frame(self, camera, status=abi.RESET):
+        self.render_async(camera, status)
+        self.wait()
+
+    def framebuffer(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._fn("group_read_framebuffer")(self._g, out.ctypes.data))
+        return out
+
+    def framebuffer_device(self):
+        """(device pointer, device ordinal) of the root-side image of the last completed gather."""
+        ptr, dev = C.c_void_p(), C.c_int()
+        self._check(self._fn("group_framebuffer_device")(self._g, C.byref(ptr), C.byref(dev)))
+        return ptr.value, dev.value
+
+    def get_stats(self):
+        return [c.get_stats() for c in self.contexts]
+
+    def destroy(self):
+        if self._g:
+            for c in self.contexts:
+                c.destroy()  # (borrowed: forgets the pointer)
+            self._fn("group_destroy")(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-CORE_SOURCES = ["rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip"]
+CORE_SOURCES = ["rfwhip_api.cpp", "rfwhip_group.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + INCLUDE, "-I" + CSRC,
           "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("RFWHIP_EXTRA_FLAGS", "").split()
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
                 cmd += ["-x", "hip"] if False else []
             _run(cmd, verbose)
             objs.append(obj)
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", core, "-lpthread"], verbose)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", core, "-lpthread", "-ldl"], verbose)
     outs.append(core)
     plugin_src = os.path.join(CSRC, "plugin", "HipRT.cpp")
     if os.path.exists(plugin_src):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from . import abi
-from ._binding import CoreBinding
+from ._binding import CoreBinding, RenderGroup
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librfwhip.so")
 _lib = None
@@ -59,3 +59,8 @@ class RenderContext(CoreBinding):
 
     def version(self):
         return self._fn("version")().decode()
+
+
+def render_group(devices, transport="auto"):
+    """n devices of one node behind one object (rfwhip_group_*): RenderGroup over the in-tree librfwhip.so."""
+    return RenderGroup(load_library(), "rfwhip_", devices, transport)

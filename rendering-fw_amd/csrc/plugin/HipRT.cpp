@@ -5,6 +5,10 @@
 // to one entry point of include/rfwhip.h; C status codes become std::runtime_error, which is how the reference's
 // backends report failures across the plugin boundary (context.h:84-91, utils/logger.h:83-95).
 //
+// Devices: RFWHIP_DEVICES = "0-7" / "0,2,5" (default: RFWHIP_DEVICE or 0) — the plugin always sits on an rfwhip_group: one
+// host thread (the reference's render loop, RFW/system/src/rfw/app.cpp:3-26) drives one context per device, every scene call
+// is repeated per context, and the strips are gathered over xGMI (RCCL, or RFWHIP_TRANSPORT=peer) into device 0's image.
+//
 // Headless by default (RenderTarget::BUFFER, context.h:27-34): the GPU box has no OpenGL.  With
 // -DRFWHIP_PLUGIN_WITH_GL (needs GLEW, i.e. the reference's own build environment) render_frame also uploads the
 // float4 image into the GL texture handed to init(), the same way EmbreeRT presents (EmbreeRT/src/Context.cpp:289-297).
@@ -24,6 +28,7 @@
 #include <GL/glew.h>
 #endif
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -47,26 +52,59 @@ class Context final : public rfw::RenderContext
   public:
 	Context()
 	{
-		// one process per GPU: the launcher's environment selects the device / strip ownership
-		const char *dev = std::getenv("RFWHIP_DEVICE"), *rank = std::getenv("RFWHIP_RANK"), *world = std::getenv("RFWHIP_WORLD");
-		HIPRT_CHECK(rfwhip_create(dev ? std::atoi(dev) : 0, rank ? std::atoi(rank) : 0, world ? std::atoi(world) : 1, &m_Core));
-		if (const char *integ = std::getenv("RFWHIP_INTEGRATOR"))
-			HIPRT_CHECK(rfwhip_set_setting(m_Core, "integrator", integ));
-		else
-			HIPRT_CHECK(rfwhip_set_setting(m_Core, "integrator", "pt"));
+		// the launcher's environment selects the devices: "0-7", "0,2,5", or a single RFWHIP_DEVICE
+		std::vector<int> devices;
+		if (const char *list = std::getenv("RFWHIP_DEVICES"))
+			devices = parse_devices(list);
+		if (devices.empty())
+		{
+			const char *dev = std::getenv("RFWHIP_DEVICE");
+			devices.push_back(dev ? std::atoi(dev) : 0);
+		}
+		int transport = RFWHIP_TRANSPORT_AUTO;
+		if (const char *t = std::getenv("RFWHIP_TRANSPORT"))
+			transport = std::string(t) == "peer" ? RFWHIP_TRANSPORT_PEER : (std::string(t) == "rccl" ? RFWHIP_TRANSPORT_RCCL : RFWHIP_TRANSPORT_AUTO);
+		HIPRT_CHECK(rfwhip_group_create(devices.data(), (int)devices.size(), transport, &m_Group));
+		for (int i = 0; i < rfwhip_group_size(m_Group); i++)
+			m_Cores.push_back(rfwhip_group_context(m_Group, i));
+		const char *integ = std::getenv("RFWHIP_INTEGRATOR");
+		HIPRT_CHECK(rfwhip_group_set_setting(m_Group, "integrator", integ ? integ : "pt"));
 #ifdef RFWHIP_HAVE_BLUE_NOISE_TABLE
 		{
 			// what CUDART does at init (CUDART/src/Context.cpp:43-46): primary rays then use blueNoiseSampler
 			const std::vector<unsigned int> table = createBlueNoiseBuffer();
-			HIPRT_CHECK(rfwhip_set_blue_noise(m_Core, table.data(), table.size()));
-			HIPRT_CHECK(rfwhip_set_setting(m_Core, "sampler", "bluenoise"));
+			for (rfwhip_context *c : m_Cores)
+				HIPRT_CHECK(rfwhip_set_blue_noise(c, table.data(), table.size()));
+			HIPRT_CHECK(rfwhip_group_set_setting(m_Group, "sampler", "bluenoise"));
 		}
 #endif
 	}
 	~Context() override
 	{
-		rfwhip_destroy(m_Core);
-		m_Core = nullptr;
+		rfwhip_group_destroy(m_Group);
+		m_Group = nullptr, m_Cores.clear();
+	}
+
+	static std::vector<int> parse_devices(const std::string &list)
+	{
+		std::vector<int> out;
+		size_t pos = 0;
+		while (pos < list.size())
+		{
+			size_t end = list.find(',', pos);
+			if (end == std::string::npos)
+				end = list.size();
+			const std::string item = list.substr(pos, end - pos);
+			const size_t dash = item.find('-');
+			if (!item.empty())
+			{
+				const int a = std::atoi(item.c_str()), b = dash == std::string::npos ? a : std::atoi(item.c_str() + dash + 1);
+				for (int d = a; d <= b && out.size() < 64; d++)
+					out.push_back(d);
+			}
+			pos = end + 1;
+		}
+		return out;
 	}
 
 	[[nodiscard]] std::vector<rfw::RenderTarget> get_supported_targets() const override
@@ -87,14 +125,18 @@ class Context final : public rfw::RenderContext
 	{
 		m_Target = glTextureID ? *glTextureID : 0;
 		m_Width = width, m_Height = height;
-		HIPRT_CHECK(rfwhip_init(m_Core, width, height));
+		HIPRT_CHECK(rfwhip_group_init(m_Group, width, height));
 		m_Host.assign(size_t(width) * height * 4, 0.0f);
 	}
 
 	void cleanup() override
 	{
-		if (m_Core)
-			HIPRT_CHECK(rfwhip_cleanup(m_Core)); // idempotent: called from system::unload and destroyRenderContext
+		if (m_Group)
+		{
+			HIPRT_CHECK(rfwhip_group_wait(m_Group));
+			for (rfwhip_context *c : m_Cores)
+				HIPRT_CHECK(rfwhip_cleanup(c)); // idempotent: called from system::unload and destroyRenderContext
+		}
 	}
 
 	void render_frame(const rfw::Camera &camera, rfw::RenderStatus status) override
@@ -102,12 +144,12 @@ class Context final : public rfw::RenderContext
 		static_assert(sizeof(rfw::Camera) >= sizeof(rfwhip_camera), "camera layout");
 		rfwhip_camera cam;
 		std::memcpy(&cam, &camera, sizeof(cam)); // position .. pixelCount are the first 60 bytes (camera.h:27-37)
-		HIPRT_CHECK(rfwhip_render(m_Core, &cam, status == rfw::Reset ? RFWHIP_RESET : RFWHIP_CONVERGE));
-		HIPRT_CHECK(rfwhip_wait(m_Core)); // the reference's render_frame returns with the frame finished
+		HIPRT_CHECK(rfwhip_group_render(m_Group, &cam, status == rfw::Reset ? RFWHIP_RESET : RFWHIP_CONVERGE));
+		HIPRT_CHECK(rfwhip_group_wait(m_Group)); // the reference's render_frame returns with the frame finished
 #ifdef RFWHIP_PLUGIN_WITH_GL
 		if (m_Target)
 		{
-			HIPRT_CHECK(rfwhip_read_framebuffer(m_Core, m_Host.data()));
+			HIPRT_CHECK(rfwhip_group_read_framebuffer(m_Group, m_Host.data()));
 			glBindTexture(GL_TEXTURE_2D, m_Target);
 			glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, m_Width, m_Height, GL_RGBA, GL_FLOAT, m_Host.data());
 		}
@@ -117,30 +159,35 @@ class Context final : public rfw::RenderContext
 	void set_materials(const std::vector<rfw::DeviceMaterial> &materials,
 					   const std::vector<rfw::MaterialTexIds> &texDescriptors) override
 	{
-		HIPRT_CHECK(rfwhip_set_materials(m_Core, reinterpret_cast<const rfwhip_material *>(materials.data()),
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_materials(c, reinterpret_cast<const rfwhip_material *>(materials.data()),
 										 reinterpret_cast<const rfwhip_material_tex_ids *>(texDescriptors.data()),
 										 materials.size()));
 	}
 
 	void set_textures(const std::vector<rfw::TextureData> &textures) override
 	{
-		HIPRT_CHECK(rfwhip_set_textures(m_Core, reinterpret_cast<const rfwhip_texture *>(textures.data()), textures.size()));
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_textures(c, reinterpret_cast<const rfwhip_texture *>(textures.data()), textures.size()));
 	}
 
 	void set_mesh(size_t index, const rfw::Mesh &mesh) override
 	{
-		HIPRT_CHECK(rfwhip_set_mesh(m_Core, index, reinterpret_cast<const rfwhip_mesh *>(&mesh)));
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_mesh(c, index, reinterpret_cast<const rfwhip_mesh *>(&mesh)));
 	}
 
 	void set_instance(size_t i, size_t meshIdx, const glm::mat4 &transform, const glm::mat3 &inverse_transform) override
 	{
-		HIPRT_CHECK(rfwhip_set_instance(m_Core, i, meshIdx, reinterpret_cast<const float *>(&transform),
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_instance(c, i, meshIdx, reinterpret_cast<const float *>(&transform),
 										reinterpret_cast<const float *>(&inverse_transform)));
 	}
 
 	void set_sky(const std::vector<glm::vec3> &pixels, size_t width, size_t height) override
 	{
-		HIPRT_CHECK(rfwhip_set_sky(m_Core, reinterpret_cast<const float *>(pixels.data()), width, height));
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_sky(c, reinterpret_cast<const float *>(pixels.data()), width, height));
 	}
 
 	void set_lights(rfw::LightCount lightCount, const rfw::DeviceAreaLight *areaLights,
@@ -149,7 +196,8 @@ class Context final : public rfw::RenderContext
 	{
 		rfwhip_light_count n;
 		std::memcpy(&n, &lightCount, sizeof(n));
-		HIPRT_CHECK(rfwhip_set_lights(m_Core, n, reinterpret_cast<const rfwhip_area_light *>(areaLights),
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_lights(c, n, reinterpret_cast<const rfwhip_area_light *>(areaLights),
 									  reinterpret_cast<const rfwhip_point_light *>(pointLights),
 									  reinterpret_cast<const rfwhip_spot_light *>(spotLights),
 									  reinterpret_cast<const rfwhip_directional_light *>(directionalLights)));
@@ -157,7 +205,23 @@ class Context final : public rfw::RenderContext
 
 	void get_probe_results(unsigned int *instanceIndex, unsigned int *primitiveIndex, float *distance) const override
 	{
-		HIPRT_CHECK(rfwhip_get_probe_results(m_Core, instanceIndex, primitiveIndex, distance));
+		// the probe pixel belongs to one rank's strips; the others report nothing for it
+		unsigned int inst = 0, prim = 0;
+		float dist = 0.0f;
+		for (rfwhip_context *c : m_Cores)
+		{
+			unsigned int i = 0, p = 0;
+			float d = 0.0f;
+			HIPRT_CHECK(rfwhip_get_probe_results(c, &i, &p, &d));
+			if (d > dist)
+				inst = i, prim = p, dist = d;
+		}
+		if (instanceIndex)
+			*instanceIndex = inst;
+		if (primitiveIndex)
+			*primitiveIndex = prim;
+		if (distance)
+			*distance = dist;
 	}
 
 	rfw::AvailableRenderSettings get_settings() const override
@@ -170,26 +234,39 @@ class Context final : public rfw::RenderContext
 
 	void set_setting(const rfw::RenderSetting &setting) override
 	{
-		HIPRT_CHECK(rfwhip_set_setting(m_Core, setting.name.c_str(), setting.value.c_str()));
+		HIPRT_CHECK(rfwhip_group_set_setting(m_Group, setting.name.c_str(), setting.value.c_str()));
 	}
 
-	void update() override { HIPRT_CHECK(rfwhip_update(m_Core)); }
+	void update() override { HIPRT_CHECK(rfwhip_group_update(m_Group)); }
 
-	void set_probe_index(glm::uvec2 probePos) override { HIPRT_CHECK(rfwhip_set_probe_index(m_Core, probePos.x, probePos.y)); }
+	void set_probe_index(glm::uvec2 probePos) override { for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_probe_index(c, probePos.x, probePos.y)); }
 
 	rfw::RenderStats get_stats() const override
 	{
+		// ray counts add up over the ranks; the times are the slowest rank's
 		rfwhip_render_stats st;
-		HIPRT_CHECK(rfwhip_get_stats(m_Core, &st));
+		HIPRT_CHECK(rfwhip_get_stats(m_Cores[0], &st));
+		for (size_t k = 1; k < m_Cores.size(); k++)
+		{
+			rfwhip_render_stats r;
+			HIPRT_CHECK(rfwhip_get_stats(m_Cores[k], &r));
+			st.primaryCount += r.primaryCount, st.secondaryCount += r.secondaryCount, st.deepCount += r.deepCount, st.shadowCount += r.shadowCount;
+			st.primaryTime = std::max(st.primaryTime, r.primaryTime), st.secondaryTime = std::max(st.secondaryTime, r.secondaryTime);
+			st.deepTime = std::max(st.deepTime, r.deepTime), st.shadowTime = std::max(st.shadowTime, r.shadowTime);
+			st.shadeTime = std::max(st.shadeTime, r.shadeTime), st.finalizeTime = std::max(st.finalizeTime, r.finalizeTime);
+			st.renderTime = std::max(st.renderTime, r.renderTime), st.animationTime = std::max(st.animationTime, r.animationTime);
+		}
 		rfw::RenderStats out;
 		std::memcpy(&out, &st, sizeof(out));
 		return out;
 	}
 
-	rfwhip_context *core() const { return m_Core; }
+	rfwhip_group *group() const { return m_Group; }
 
   private:
-	rfwhip_context *m_Core = nullptr;
+	rfwhip_group *m_Group = nullptr;
+	std::vector<rfwhip_context *> m_Cores;
 	GLuint m_Target = 0;
 	uint m_Width = 0, m_Height = 0;
 	std::vector<float> m_Host;
@@ -210,5 +287,5 @@ HIPRT_EXPORT void destroyRenderContext(rfw::RenderContext *ptr)
 // Headless hosts (no GL texture to look at) read the BUFFER target through this extra symbol.
 HIPRT_EXPORT int hiprtReadFramebuffer(rfw::RenderContext *ptr, float *rgba)
 {
-	return rfwhip_read_framebuffer(static_cast<Context *>(ptr)->core(), rgba);
+	return rfwhip_group_read_framebuffer(static_cast<Context *>(ptr)->group(), rgba);
 }

@@ -9,6 +9,7 @@
 #include "rfwhip.h"
 
 #include "bvh_build.h"
+#include "internal.h"
 #include "kernels.h"
 #include "rt_types.h"
 
@@ -33,6 +34,14 @@ using rt::f4;
 // =================================================================================================================
 static thread_local char g_error[1024] = "";
 static int set_error(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	return code;
+}
+int rfwhip_internal_set_error(int code, const char *fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);
@@ -2084,6 +2093,28 @@ extern "C" int rfwhip_deinterleave_stream(rfwhip_context *c, const void *gathere
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null buffer");
 	rtk::launch_deinterleave((const f4 *)gathered_device, (f4 *)rgba_device, c->W, c->H, local_rows_of(c), (uint32_t)c->world, hip_stream);
 	return dm::last_launch_error();
+}
+
+extern "C" int rfwhip_get_placement(rfwhip_context *c, int *device_ordinal, int *rank, int *world)
+{
+	CTX_ENTER(c);
+	if (device_ordinal)
+		*device_ordinal = c->device;
+	if (rank)
+		*rank = c->rank;
+	if (world)
+		*world = c->world;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_get_target_size(rfwhip_context *c, uint32_t *width, uint32_t *height)
+{
+	CTX_ENTER(c);
+	if (width)
+		*width = c->W;
+	if (height)
+		*height = c->H;
+	return RFWHIP_OK;
 }
 
 extern "C" int rfwhip_deinterleave_device(rfwhip_context *c, const void *gathered_device, void *rgba_device)

@@ -17,7 +17,7 @@ OUT = os.path.join(OUT_DIR, "librfwhip_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "rfwhip_group.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):

@@ -1,0 +1,127 @@
+"""Multi-GPU below the C ABI (rfwhip_group_* / rfwhip_comm_*, include/rfwhip.h): one host thread drives n contexts, one
+gather per presented frame.  CPU tier: the host-emulation build, peer transport (memcpy).  GPU tier: n contexts on ONE
+device with the peer transport (RCCL refuses a device twice), bit-equal to the single-context image; the RCCL transport
+itself needs >= 2 devices and is skipped otherwise."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def _render(pkg, target, scene, w, h, settings, frames=2):
+    target.init(w, h)
+    scene.upload(target)
+    for k, v in settings.items():
+        target.set_setting(k, v)
+    for f in range(frames):
+        target.render_async(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+    target.wait()
+    return target.framebuffer()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_group_of_emulated_contexts_equals_the_single_context(pkg, make_emu, emu_lib, n):
+    """70 x 51: partial tiles, strips that do not divide among the ranks; pt integrator with connections.
+    (Scenes: every rank that still has paths at depth 1 must have some at depth 2 — the reference traces the connections of
+    a depth only while paths survive it, CUDART/src/Context.cpp:109-120, a per-batch rule here: DESIGN.md §6.)"""
+    scene = pkg.scenes.terrain(n=24, width=70, height_px=51)
+    settings = {"integrator": "pt", "spp": 4, "max_depth": 2}
+    ref = _render(pkg, make_emu(), scene, 70, 51, settings)
+    g = pkg._binding.RenderGroup(emu_lib, "rfwhip_", [0] * n, "peer")
+    assert g.world == n and g.transport == "peer"
+    img = _render(pkg, g, scene, 70, 51, settings)
+    for st in g.get_stats():
+        assert st.secondaryCount == 0 or st.deepCount > 0
+    assert np.array_equal(img, ref)
+    # a second gather of the same accumulator is the same image; a resize re-lays the staging out
+    assert np.array_equal(g.framebuffer(), ref)
+    scene2 = pkg.scenes.cornell(48, 40)
+    settings2 = {"integrator": "parity", "spp": 2}
+    ref2 = _render(pkg, make_emu(), scene2, 48, 40, settings2)
+    assert np.array_equal(_render(pkg, g, scene2, 48, 40, settings2), ref2)
+    g.destroy()
+
+
+def test_group_of_one_and_argument_errors(pkg, make_emu, emu_lib):
+    scene = pkg.scenes.cornell(64, 48)
+    settings = {"integrator": "parity", "spp": 2}
+    ref = _render(pkg, make_emu(), scene, 64, 48, settings)
+    g = pkg._binding.RenderGroup(emu_lib, "rfwhip_", [0], "auto")
+    assert np.array_equal(_render(pkg, g, scene, 64, 48, settings), ref)
+    g.destroy()
+    with pytest.raises(RuntimeError):
+        pkg._binding.RenderGroup(emu_lib, "rfwhip_", [], "peer")
+    with pytest.raises(RuntimeError):
+        pkg._binding.RenderGroup(emu_lib, "rfwhip_", [0, 0], "rccl")  # the emulation build has no RCCL
+    # the comm front end needs RCCL as soon as the world is larger than one
+    e = make_emu(0, 2)
+    comm = ctypes.c_void_p()
+    emu_lib.rfwhip_comm_create.restype = ctypes.c_int
+    emu_lib.rfwhip_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    assert emu_lib.rfwhip_comm_create(e._ctx, None, ctypes.byref(comm)) != 0
+
+
+def test_comm_of_world_one_gathers_into_a_caller_buffer(pkg, make_emu, emu_lib):
+    """rfwhip_comm_* with world 1 is the degenerate gather: present + copy, no transport."""
+    scene = pkg.scenes.cornell(64, 48)
+    e = make_emu()
+    ref = _render(pkg, e, scene, 64, 48, {"integrator": "parity", "spp": 1}, frames=1)
+    vp = ctypes.c_void_p
+    for name, args in (("rfwhip_comm_create", [vp, vp, ctypes.POINTER(vp)]), ("rfwhip_comm_gather", [vp, vp]), ("rfwhip_comm_wait", [vp])):
+        getattr(emu_lib, name).restype, getattr(emu_lib, name).argtypes = ctypes.c_int, args
+    emu_lib.rfwhip_comm_destroy.restype, emu_lib.rfwhip_comm_destroy.argtypes = None, [vp]
+    comm = vp()
+    assert emu_lib.rfwhip_comm_create(e._ctx, None, ctypes.byref(comm)) == 0
+    out = np.zeros((48, 64, 4), np.float32)  # (emulation: "device" memory is host memory)
+    assert emu_lib.rfwhip_comm_gather(comm, out.ctypes.data) == 0
+    assert emu_lib.rfwhip_comm_wait(comm) == 0
+    assert np.array_equal(out, ref)
+    emu_lib.rfwhip_comm_destroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,integrator", [(2, "pt"), (4, "pt"), (8, "parity")])
+def test_group_on_one_device_equals_the_single_context_gpu(pkg, make_hip, n, integrator):
+    """n contexts on cuda:0 through rfwhip_group_* (peer transport): render -> gather pipelined over four frames, bit-equal
+    to one context; the image also sits in the root's device buffer."""
+    import torch
+    scene = pkg.scenes.cornell(480, 270, geometric_emitter=(integrator == "pt"))
+    settings = {"integrator": integrator, "spp": 4, "max_depth": 2}
+    ref = _render(pkg, make_hip(), scene, 480, 270, settings, frames=4)
+    g = pkg.render_group([0] * n, "peer")
+    g.init(480, 270)
+    scene.upload(g)
+    for k, v in settings.items():
+        g.set_setting(k, v)
+    for f in range(4):  # nothing blocks the host between the frames and their gathers
+        g.render_async(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+        g.gather()
+    g.wait()
+    ptr, dev = g.framebuffer_device()
+    assert dev == 0
+    host = np.empty((270, 480, 4), np.float32)
+    torch.cuda.synchronize()
+    from ctypes import c_void_p
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(c_void_p(host.ctypes.data), c_void_p(ptr), host.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    assert np.array_equal(host, ref)
+    assert np.array_equal(g.framebuffer(), ref)
+    g.destroy()
+
+
+@pytest.mark.gpu
+def test_group_over_rccl_needs_two_devices(pkg, make_hip):
+    """The RCCL transport: ncclSend / ncclRecv between the ranks of one process.  Needs >= 2 visible devices."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(RuntimeError):
+            pkg.render_group([0, 0], "rccl")  # a device listed twice is refused loudly, not downgraded
+        pytest.skip("one visible device: the RCCL transport cannot be exercised here")
+    scene = pkg.scenes.cornell(480, 270, geometric_emitter=True)
+    settings = {"integrator": "pt", "spp": 4, "max_depth": 2}
+    ref = _render(pkg, make_hip(), scene, 480, 270, settings, frames=3)
+    g = pkg.render_group([0, 1], "rccl")
+    assert g.transport == "rccl"
+    img = _render(pkg, g, scene, 480, 270, settings, frames=3)
+    assert np.array_equal(img, ref)
+    g.destroy()

@@ -11,11 +11,17 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_plugin_through_the_virtual_interface(pkg):
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_plugin_through_the_virtual_interface(pkg, devices):
+    """devices "0,0,0": the plugin on an rfwhip_group of three contexts (strip split + gather below the C ABI; one GPU, so
+    the peer transport) must print the very same numbers."""
     host = os.path.join(ROOT, "tests", "plugin", "plugin_host")
     plugin_dir = os.path.dirname(pkg.LIB_PATH)
     assert os.path.exists(host) and os.path.exists(os.path.join(plugin_dir, "HipRT.so")), "run __graft_entry__.build()"
-    r = subprocess.run([host, plugin_dir], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    env = dict(os.environ)
+    if devices:
+        env.update(RFWHIP_DEVICES=devices, RFWHIP_TRANSPORT="peer")
+    r = subprocess.run([host, plugin_dir], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
     out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
     inst, prim, dist = out["probe"].split()
