@@ -268,7 +268,8 @@ enum rfwhip_kat_function
 	RFWHIP_KAT_POINT_ON_LIGHT = 6,	   /* lights.h:159-265 on the context's lights -> P, pickProb, lightPdf, colour */
 	RFWHIP_KAT_LIGHT_PICK_PROB = 7,	   /* lights.h:83-116                      -> probability */
 	RFWHIP_KAT_BLUE_NOISE = 8,		   /* tools.h:163-181, [0..3] = x, y, sample, dimension (ints) -> value */
-	RFWHIP_KAT_HASH = 9				   /* tools.h:218-235, [0] = seed -> WangHash bits, RandomFloat, state bits */
+	RFWHIP_KAT_HASH = 9,			   /* tools.h:218-235, [0] = seed -> WangHash bits, RandomFloat, state bits */
+	RFWHIP_KAT_HALF_TO_FLOAT = 10	   /* half -> float as the shade kernels read materials (structs.h:88-117): [0..7] = 8 half bit patterns (ints) -> 8 floats */
 };
 
 #ifdef __cplusplus

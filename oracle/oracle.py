@@ -25,11 +25,25 @@ def build(force=False):
 
 
 def build_ref():
-    """oracle/_ref/libbluenoise.so from the reference's own blue_noise.h (`make ref`); a no-op without /root/reference."""
+    """oracle/_ref/libbluenoise.so + libhalfref.so from the reference's own blue_noise.h / half.hpp (`make ref`); a no-op
+    without /root/reference."""
     r = subprocess.run(["make", "-C", HERE, "ref"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("oracle/_ref build failed:\n" + r.stdout)
     return os.path.join(HERE, "_ref", "libbluenoise.so")
+
+
+def load_half_ref():
+    """The reference's half_float::half conversions (oracle/_ref/libhalfref.so, built from external/half2.1.0/half.hpp)."""
+    path = os.path.join(HERE, "_ref", "libhalfref.so")
+    if not os.path.exists(path):
+        build_ref()
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.rfw_ref_half_to_float.restype, L.rfw_ref_half_to_float.argtypes = C.c_float, [C.c_uint16]
+    L.rfw_ref_float_to_half.restype, L.rfw_ref_float_to_half.argtypes = C.c_uint16, [C.c_float]
+    return L
 
 
 def load():

@@ -69,8 +69,57 @@ def traffic(spp, streams, workload, tag, *paths):
     print(json.dumps(out, indent=1))
 
 
+def short_name(kernel):
+    """`void rtk::k_trace_stream<true, false>(rtk::Params)` -> `k_trace_stream<true, false>`"""
+    import re
+    m = re.search(r"rtk::(k_\w+(?:<[^>]*>)?)", kernel)
+    return m.group(1) if m else kernel
+
+
+def stages(spp, streams, workload, tag, csrc_hash, *paths):
+    """profiles/stage_counters.json: per kernel of the bench, averaged per dispatch, from the PMC passes of one evidence run
+    (each counter set in its own rocprofv3 --pmc pass of the same command): HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, KB; gfx950
+    correction as in traffic()), L2 bytes (TCC_REQ x 128), VALU wave-instructions, lanes per VALU instruction, dispatch
+    duration under the (serialising) counter pass.  bench.py reads it for roofline.stages and drops it when csrc_hash differs
+    from the sources it runs on."""
+    import json
+    tot, disp, dur = {}, {}, {}
+    for path in paths:
+        c = sqlite3.connect(path).cursor()
+        for name, counter, n, total, d in c.execute(
+                "select kernel_name, counter_name, count(*), sum(value), avg(duration) from counters_collection group by kernel_name, counter_name"):
+            k = short_name(name)
+            tot.setdefault(k, {})[counter] = total
+            disp.setdefault(k, {})[counter] = n
+            dur.setdefault(k, []).append(d / 1e3)
+    out = {"workload": workload, "spp": int(spp), "streams": int(streams), "tag": tag, "csrc_hash": csrc_hash, "kernels": {}}
+    for k, t in tot.items():
+        if not k.startswith("k_"):
+            continue
+        def per(c):
+            return t[c] / disp[k][c] if c in t else None
+        e = {"dispatches": max(disp[k].values()), "avg_dispatch_us": round(sum(dur[k]) / len(dur[k]), 1)}
+        if per("FETCH_SIZE") is not None and per("WRITE_SIZE") is not None:
+            e["hbm_bytes_per_dispatch"] = int((2.0 * per("FETCH_SIZE") + per("WRITE_SIZE")) * 1024)
+        if per("TCC_REQ_sum") is not None:
+            e["l2_bytes_per_dispatch"] = int(per("TCC_REQ_sum") * 128)
+        if per("SQ_INSTS_VALU") is not None:
+            e["sq_insts_valu_per_dispatch"] = int(per("SQ_INSTS_VALU"))
+        if "SQ_THREAD_CYCLES_VALU" in t and "SQ_ACTIVE_INST_VALU" in t and t["SQ_ACTIVE_INST_VALU"] > 0:
+            e["valu_lanes_per_instruction"] = round(t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"], 2)
+        if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t and t["SQ_WAVE_CYCLES"] > 0:
+            e["wave_cycles_waiting_frac"] = round(t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"], 4)
+        out["kernels"][k] = e
+    out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                         "--no-roofline` (tools/evidence.sh); per dispatch averages; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
+                         "l2 bytes = TCC_REQ_sum x 128; csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(*sys.argv[2:])
+    elif sys.argv[1] == "stages":
+        stages(*sys.argv[2:])
     else:
         {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])

@@ -64,3 +64,52 @@ class RenderContext(CoreBinding):
 def render_group(devices, transport="auto"):
     """n devices of one node behind one object (rfwhip_group_*): RenderGroup over the in-tree librfwhip.so."""
     return RenderGroup(load_library(), "rfwhip_", devices, transport)
+
+
+def comm_unique_id():
+    """The 128-byte id rank 0 hands to the other ranks before rfwhip_comm_create (include/rfwhip.h)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    lib.rfwhip_comm_unique_id.restype, lib.rfwhip_comm_unique_id.argtypes = C.c_int, [C.c_void_p, C.c_size_t]
+    if lib.rfwhip_comm_unique_id(buf, 128) != 0:
+        lib.rfwhip_last_error.restype = C.c_char_p
+        raise RuntimeError((lib.rfwhip_last_error() or b"unknown error").decode(errors="replace"))
+    return buf.raw
+
+
+class RenderComm:
+    """One process per device: this rank's end of the strip gather (rfwhip_comm_*, RCCL issued by librfwhip.so).  Collective:
+    every rank of the context's world constructs it with the same id, and every rank calls gather()."""
+
+    def __init__(self, ctx, id_bytes):
+        self._lib = load_library()
+        vp, i32 = C.c_void_p, C.c_int
+        for name, res, args in [("rfwhip_comm_create", i32, [vp, vp, C.POINTER(vp)]), ("rfwhip_comm_gather", i32, [vp, vp]),
+                                ("rfwhip_comm_wait", i32, [vp]), ("rfwhip_comm_destroy", None, [vp]), ("rfwhip_last_error", C.c_char_p, [])]:
+            f = getattr(self._lib, name)
+            f.restype, f.argtypes = res, args
+        self._c = vp()
+        self._id = C.create_string_buffer(bytes(id_bytes), 128) if id_bytes is not None else None
+        self._check(self._lib.rfwhip_comm_create(ctx._ctx, self._id, C.byref(self._c)))
+
+    def _check(self, code):
+        if code != 0:
+            raise RuntimeError((self._lib.rfwhip_last_error() or b"unknown error").decode(errors="replace"))
+
+    def gather(self, full_rgba_device_ptr=0):
+        """Enqueue present -> send / receive -> de-interleave (root: into the given device buffer, 0 = an internal one)."""
+        self._check(self._lib.rfwhip_comm_gather(self._c, C.c_void_p(full_rgba_device_ptr or None)))
+
+    def wait(self):
+        self._check(self._lib.rfwhip_comm_wait(self._c))
+
+    def destroy(self):
+        if self._c:
+            self._lib.rfwhip_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -466,6 +466,10 @@ RT_FN void kat_item(const Params &p, int function, const float *in, float *out, 
 		o[2] = ubits(st);
 		break;
 	}
+	case 10: // half -> float (material colours, uv scales): eight bit patterns per record
+		for (int k = 0; k < KAT_OUT; k++)
+			o[k] = half_to_float((uint16_t)fbits(r[k]));
+		break;
 	default:
 		break;
 	}
