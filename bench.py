@@ -369,6 +369,7 @@ def main():
         ctx.set_setting("streams", 1)
         ctx.set_setting("spp", sub_spp)
         ctx.set_setting("stage_timing", 1)
+        ctx.set_setting("overlap", 0)  # (no connection wave beside the next depth's stages: every launch has the chip to itself)
         ctx.render_frame(scene.camera, pkg.RESET)
         ser_frames, acc = 3, {}
         for k in range(ser_frames):
@@ -378,6 +379,7 @@ def main():
                 acc[key] = acc.get(key, 0.0) + st1[key] / ser_frames
         ctx.set_setting("streams", args.streams)
         ctx.set_setting("spp", args.spp)
+        ctx.set_setting("overlap", args.overlap)
         ser = {"primary": acc["primaryTime"], "bounce": acc["secondaryTime"] + acc["deepTime"], "shadow": acc["shadowTime"],
                "shade": acc["shadeTime"]}
         frac_of_step = 1.0 / subs  # one sub-batch = 1 / subs of a step's samples

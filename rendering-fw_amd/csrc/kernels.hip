@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 
 // the node phase of a wave ends early once this many of its lanes hold a leaf (64: only when none is on an inner node)
 #ifndef RT_LEAF_VOTE_EXT
-#define RT_LEAF_VOTE_EXT 32
+#define RT_LEAF_VOTE_EXT 40 // (of 64: the share of the wave's lanes WITH a ray that must hold a leaf, rt_core.h RT_VOTE_RELATIVE)
 #endif
 #ifndef RT_LEAF_VOTE_PRIMARY
 #define RT_LEAF_VOTE_PRIMARY 32
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #define RT_STREAM_CHUNK 512
 #endif
 #ifndef RT_LEAF_VOTE_ANY
-#define RT_LEAF_VOTE_ANY 32
+#define RT_LEAF_VOTE_ANY 40
 #endif
 
 

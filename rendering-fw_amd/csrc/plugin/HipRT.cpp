@@ -131,11 +131,12 @@ class Context final : public rfw::RenderContext
 
 	void cleanup() override
 	{
-		if (m_Group)
+		if (m_Group && !m_Cleaned) // idempotent: called from system::unload and again from destroyRenderContext
 		{
 			HIPRT_CHECK(rfwhip_group_wait(m_Group));
 			for (rfwhip_context *c : m_Cores)
-				HIPRT_CHECK(rfwhip_cleanup(c)); // idempotent: called from system::unload and destroyRenderContext
+				HIPRT_CHECK(rfwhip_cleanup(c));
+			m_Cleaned = true;
 		}
 	}
 
@@ -267,6 +268,7 @@ class Context final : public rfw::RenderContext
   private:
 	rfwhip_group *m_Group = nullptr;
 	std::vector<rfwhip_context *> m_Cores;
+	bool m_Cleaned = false;
 	GLuint m_Target = 0;
 	uint m_Width = 0, m_Height = 0;
 	std::vector<float> m_Host;

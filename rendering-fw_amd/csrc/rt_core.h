@@ -436,9 +436,20 @@ struct Traverser
 	{
 		O = O_, D = D_, t_min = t_min_;
 		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
-		enter_space(O, D);
 		cur_inst = -1, sp = 0;
+		enter_space(O, D);
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	}
+	// the ray in the object space of an instance (3x4 inverse, direction NOT renormalised so that t is shared:
+	// top_level_bvh.cpp:104-168)
+	RT_FN void enter_instance(const Instance &in)
+	{
+		enter_space(mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
+						in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
+						in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]),
+					mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z,
+						in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
+						in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z));
 	}
 	RT_FN bool done() const { return cur == ENTRY_DONE; }
 
@@ -501,6 +512,9 @@ struct Traverser
 	// phase 1: walk 4-wide inner nodes until this lane holds a leaf entry (or ENTRY_DONE / ENTRY_SENTINEL)
 	// VOTE < 64 (wave kernels only): the wave leaves the node phase as soon as VOTE of its lanes hold a leaf, so that
 	// those lanes do not sit idle while the others finish a long descent (lanes still on an inner node skip visit()).
+#ifndef RT_VOTE_RELATIVE
+#define RT_VOTE_RELATIVE 1
+#endif
 	template <int VOTE = 64> RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -595,8 +609,13 @@ struct Traverser
 				// only the lanes still inside this loop execute the ballot: the lanes with work that are NOT counted here
 				// are the ones already waiting with a leaf (or with a finished ray to retire)
 				const int inner = __popcll(__ballot(!(cur & ENTRY_LEAF)));
+#if RT_VOTE_RELATIVE
+				if ((nwork - inner) * 64 >= nwork * VOTE) // VOTE / 64 of the lanes that HAVE a ray (idle lanes do not count)
+					break;
+#else
 				if (nwork - inner >= VOTE)
 					break;
+#endif
 			}
 #endif
 		}
@@ -621,12 +640,7 @@ struct Traverser
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
 			const Instance &in = sc.instances[ii];
 			push(stk, ENTRY_SENTINEL);
-			enter_space(mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
-							in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
-							in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]),
-						mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z,
-							in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
-							in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z));
+			enter_instance(in);
 			cur_inst = (int)ii;
 			cur = in.root_entry;
 			return;
