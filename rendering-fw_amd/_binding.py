@@ -334,6 +334,7 @@ class RenderGroup:
                                 ("group_render", i32, [vp, C.POINTER(abi.CameraPOD), i32]), ("group_gather", i32, [vp]),
                                 ("group_wait", i32, [vp]), ("group_read_framebuffer", i32, [vp, vp]),
                                 ("group_framebuffer_device", i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
+                                ("group_present_async", i32, [vp, i32]), ("group_present_wait", i32, [vp, i32, C.POINTER(vp)]),
                                 ("last_error", C.c_char_p, [])]:
             f = self._fn(name)
             f.restype, f.argtypes = res, args
@@ -391,6 +392,17 @@ class RenderGroup:
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self._fn("group_read_framebuffer")(self._g, out.ctypes.data))
         return out
+
+    def present_async(self, slot):
+        """Enqueue gather + device-to-host copy of the image into pinned host slot 0 / 1 (frames in flight)."""
+        self._check(self._fn("group_present_async")(self._g, int(slot)))
+
+    def present_wait(self, slot):
+        """Block until slot's copy has landed; returns the image as a numpy view of the pinned buffer."""
+        ptr = C.c_void_p()
+        self._check(self._fn("group_present_wait")(self._g, int(slot), C.byref(ptr)))
+        buf = (C.c_float * (self.width * self.height * 4)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(self.height, self.width, 4)
 
     def framebuffer_device(self):
         """(device pointer, device ordinal) of the root-side image of the last completed gather."""

@@ -118,6 +118,26 @@ int copy_to_host(void *dst, const void *src, size_t bytes, void *s)
 	GR_HIP(hipStreamSynchronize((hipStream_t)s));
 	return 0;
 }
+int host_alloc(void **p, size_t bytes) // pinned: the device-to-host copy of a presented frame runs asynchronously
+{
+	GR_HIP(hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault));
+	return 0;
+}
+void host_free(void *p)
+{
+	if (p)
+		(void)hipHostFree(p);
+}
+int copy_to_host_async(void *dst, const void *src, size_t bytes, void *s)
+{
+	GR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+	return 0;
+}
+int event_sync(event_t e)
+{
+	GR_HIP(hipEventSynchronize(e));
+	return 0;
+}
 int device_count()
 {
 	int n = 0;
@@ -216,6 +236,14 @@ int copy_to_host(void *dst, const void *src, size_t bytes, void *)
 	memcpy(dst, src, bytes);
 	return 0;
 }
+int host_alloc(void **p, size_t bytes) { return dev_alloc(p, bytes); }
+void host_free(void *p) { free(p); }
+int copy_to_host_async(void *dst, const void *src, size_t bytes, void *)
+{
+	memcpy(dst, src, bytes);
+	return 0;
+}
+int event_sync(event_t) { return 0; }
 int device_count() { return 1 << 20; }
 void enable_peer(int, int) {}
 typedef void *comm_t;
@@ -244,6 +272,10 @@ struct rfwhip_group
 	uint32_t W = 0, H = 0, local_rows = 0;
 	void *staging = nullptr, *full = nullptr; // on the root's device
 	int root_local = -1;					  // index of rank 0 in ep, -1 when another process owns it
+	// pipelined presentation (rfwhip_group_present_async / _wait): two pinned host images and the events of their copies
+	void *host_img[2] = {nullptr, nullptr};
+	event_t host_ready[2];
+	bool host_events = false, host_pending[2] = {false, false};
 	size_t chunk_bytes() const { return (size_t)local_rows * W * PIXEL_BYTES; }
 };
 struct rfwhip_comm
@@ -267,6 +299,8 @@ void release_buffers(rfwhip_group *g)
 		dev_free(g->staging), dev_free(g->full);
 	}
 	g->staging = g->full = nullptr;
+	for (int k = 0; k < 2; k++)
+		host_free(g->host_img[k]), g->host_img[k] = nullptr, g->host_pending[k] = false;
 }
 
 // (re)allocate the gather buffers for the contexts' current render target
@@ -424,6 +458,8 @@ void destroy_group(rfwhip_group *g)
 		if (g->owns_contexts && e.ctx)
 			rfwhip_destroy(e.ctx);
 	}
+	if (g->host_events)
+		event_destroy(g->host_ready[0]), event_destroy(g->host_ready[1]), g->host_events = false;
 	g->ep.clear();
 }
 
@@ -588,6 +624,49 @@ extern "C" int rfwhip_group_read_framebuffer(rfwhip_group *g, float *rgba_host)
 	Endpoint &root = g->ep[(size_t)g->root_local];
 	GR_TRY(dev_use(root.device));
 	return copy_to_host(rgba_host, g->full, (size_t)g->W * g->H * PIXEL_BYTES, root.stream);
+}
+
+// Pipelined presentation: frame k's image travels to the host while frame k + 1 renders.  present_async enqueues gather +
+// device-to-host copy into pinned host image `slot` (0 / 1) and returns; present_wait blocks until that copy has landed.
+extern "C" int rfwhip_group_present_async(rfwhip_group *g, int slot)
+{
+	if (!g || slot < 0 || slot > 1)
+		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_group_present_async: bad arguments");
+	if (g->root_local < 0 || !g->full)
+		return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "no render target");
+	Endpoint &root = g->ep[(size_t)g->root_local];
+	GR_TRY(dev_use(root.device));
+	const size_t bytes = (size_t)g->W * g->H * PIXEL_BYTES;
+	if (!g->host_events)
+	{
+		GR_TRY(event_create(&g->host_ready[0]));
+		GR_TRY(event_create(&g->host_ready[1]));
+		g->host_events = true;
+	}
+	if (!g->host_img[slot])
+		GR_TRY(host_alloc(&g->host_img[slot], bytes));
+	GR_TRY(gather(g, nullptr));
+	GR_TRY(dev_use(root.device));
+	GR_TRY(copy_to_host_async(g->host_img[slot], g->full, bytes, root.stream));
+	GR_TRY(event_record(g->host_ready[slot], root.stream));
+	g->host_pending[slot] = true;
+	return RFWHIP_OK;
+}
+
+extern "C" int rfwhip_group_present_wait(rfwhip_group *g, int slot, const float **rgba_host)
+{
+	if (!g || slot < 0 || slot > 1 || !rgba_host)
+		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_group_present_wait: bad arguments");
+	if (!g->host_img[slot])
+		return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "rfwhip_group_present_wait: nothing was presented into slot %d", slot);
+	if (g->host_pending[slot])
+	{
+		GR_TRY(dev_use(g->ep[(size_t)g->root_local].device));
+		GR_TRY(event_sync(g->host_ready[slot]));
+		g->host_pending[slot] = false;
+	}
+	*rgba_host = (const float *)g->host_img[slot];
+	return RFWHIP_OK;
 }
 
 extern "C" int rfwhip_group_framebuffer_device(rfwhip_group *g, void **rgba_device, int *device_ordinal)
