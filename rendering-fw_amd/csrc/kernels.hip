@@ -881,6 +881,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 
 
 
+
 // MODE: where a lane's next ray comes from — the extension-ray buffers of this depth, the shadow-ray buffers, or the
 // pt integrator's primary-ray generator (item = path slot; the ray is also stored for the shade kernel)
 enum

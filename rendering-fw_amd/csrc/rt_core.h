@@ -509,9 +509,100 @@ struct Traverser
 		}
 	}
 
+	// One 4-wide node: fetch its four rows (LDS copy of the top of the tree, or the table), slab-test the four children
+	// (aabb.cpp:39-77 in fma form) and — closest-hit rays — order them by entry distance.  Out: t[k] = entry distance or INF
+	// (a miss, an empty slot = an inverted box), e[k] = the children's stack entries; closest-hit: nearest first.
+	static constexpr float NODE_INF = 3.0e38f;
+	RT_FN void node_step(const SceneView &sc, const TravStack stk, TStat &st, uint32_t entry, float &t0, float &t1, float &t2, float &t3,
+						 uint32_t &e0, uint32_t &e1, uint32_t &e2, uint32_t &e3)
+	{
+		const uint32_t idx = entry & ENTRY_INDEX_MASK;
+		const uint32_t rel = idx - stk.top_first;
+		Node4cRows rows;
+		if (rel < stk.top_count)
+		{
+			rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u));
+#if !defined(RT_DIAG_PHASES)
+			if (COUNT)
+				st.lds++;
+#endif
+		}
+		else // byte offset of the node in the table (tables stay below 4 GiB)
+			rows = load_rows<true>((const char *)sc.nodes4, idx << 6);
+		if (COUNT)
+			st.inner++;
+#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+		if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
+			st.lds++; // wave-level iterations of the node loop (leader lane)
+#endif
+		// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
+		// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
+		// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
+		const float Ax = rows.r0.w * id.x, Ay = rows.r3.z * id.y, Az = rows.r3.w * id.z;
+		const float Bx = fmaf(rows.r0.x, id.x, -oid.x), By = fmaf(rows.r0.y, id.y, -oid.y), Bz = fmaf(rows.r0.z, id.z, -oid.z);
+		const uint32_t lox = fbits(rows.r2.x), loy = fbits(rows.r2.y), loz = fbits(rows.r2.z);
+		const uint32_t hix = fbits(rows.r2.w), hiy = fbits(rows.r3.x), hiz = fbits(rows.r3.y);
+		const uint32_t nxq = neg_x ? hix : lox, fxq = neg_x ? lox : hix;
+		const uint32_t nyq = neg_y ? hiy : loy, fyq = neg_y ? loy : hiy;
+		const uint32_t nzq = neg_z ? hiz : loz, fzq = neg_z ? loz : hiz;
+		const float INF = NODE_INF;
+#define RT_SLAB4(UB, OUT)                                                                                   \
+	{                                                                                                       \
+		const float tmin = fmaxf(fmaxf(fmaf(UB(nxq), Ax, Bx), fmaf(UB(nyq), Ay, By)), fmaf(UB(nzq), Az, Bz)); \
+		const float tmax = fminf(fminf(fmaf(UB(fxq), Ax, Bx), fmaf(UB(fyq), Ay, By)), fmaf(UB(fzq), Az, Bz)); \
+		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                   \
+	}
+		RT_SLAB4(ub0, t0)
+		RT_SLAB4(ub1, t1)
+		RT_SLAB4(ub2, t2)
+		RT_SLAB4(ub3, t3)
+#undef RT_SLAB4
+		e0 = fbits(rows.r1.x), e1 = fbits(rows.r1.y), e2 = fbits(rows.r1.z), e3 = fbits(rows.r1.w);
+		if (!ANY)
+		{
+			// order the four children by entry distance (5-comparator network), nearest first
+#define RT_CSWAP(TA, EA, TB, EB)              \
+	{                                         \
+		const bool sw = TB < TA;              \
+		const float tt = sw ? TB : TA;        \
+		const uint32_t ee = sw ? EB : EA;     \
+		TB = sw ? TA : TB, EB = sw ? EA : EB; \
+		TA = tt, EA = ee;                     \
+	}
+			RT_CSWAP(t0, e0, t1, e1)
+			RT_CSWAP(t2, e2, t3, e3)
+			RT_CSWAP(t0, e0, t2, e2)
+			RT_CSWAP(t1, e1, t3, e3)
+			RT_CSWAP(t1, e1, t2, e2)
+#undef RT_CSWAP
+		}
+	}
+	// What a node step leaves behind: the children that were hit (t < limit = NODE_INF) go on the stack, the next entry comes
+	// back.  closest-hit: t sorted, nearest first; occlusion: any order, the first child hit is next.
+	RT_FN uint32_t take_children(const TravStack stk, float limit, float t0, float t1, float t2, float t3, uint32_t e0, uint32_t e1,
+								 uint32_t e2, uint32_t e3)
+	{
+		if (!ANY)
+		{
+			if (t0 < limit)
+			{
+				// far children first, so the nearest of them is popped first
+				push3(stk, e3, t3 < limit, e2, t2 < limit, e1, t1 < limit);
+				return e0;
+			}
+			return pop(stk);
+		}
+		const bool h0 = t0 < limit, h1 = t1 < limit, h2 = t2 < limit, h3 = t3 < limit;
+		const bool have = h0 || h1 || h2 || h3;
+		const uint32_t next = h0 ? e0 : (h1 ? e1 : (h2 ? e2 : e3));
+		if (have)
+			push3(stk, e1, h1 && h0, e2, h2 && (h0 || h1), e3, h3 && (h0 || h1 || h2));
+		return have ? next : pop(stk);
+	}
+
 	// phase 1: walk 4-wide inner nodes until this lane holds a leaf entry (or ENTRY_DONE / ENTRY_SENTINEL)
-	// VOTE < 64 (wave kernels only): the wave leaves the node phase as soon as VOTE of its lanes hold a leaf, so that
-	// those lanes do not sit idle while the others finish a long descent (lanes still on an inner node skip visit()).
+	// VOTE < 64 (wave kernels only): the wave leaves the node phase as soon as VOTE / 64 of its lanes with a ray hold a leaf,
+	// so that those lanes do not sit idle while the others finish a long descent (lanes still on an inner node skip visit()).
 #ifndef RT_VOTE_RELATIVE
 #define RT_VOTE_RELATIVE 1
 #endif
@@ -522,87 +613,10 @@ struct Traverser
 #endif
 		while (!(cur & ENTRY_LEAF))
 		{
-			const uint32_t idx = cur & ENTRY_INDEX_MASK;
-			const uint32_t rel = idx - stk.top_first;
-			Node4cRows rows;
-			if (rel < stk.top_count)
-			{
-				rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u));
-#if !defined(RT_DIAG_PHASES)
-				if (COUNT)
-					st.lds++;
-#endif
-			}
-			else // byte offset of the node in the table (tables stay below 4 GiB)
-				rows = load_rows<true>((const char *)sc.nodes4, idx << 6);
-			if (COUNT)
-				st.inner++;
-#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
-			if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
-				st.lds++; // wave-level iterations of the node loop (leader lane)
-#endif
-			// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
-			// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
-			// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
-			const float Ax = rows.r0.w * id.x, Ay = rows.r3.z * id.y, Az = rows.r3.w * id.z;
-			const float Bx = fmaf(rows.r0.x, id.x, -oid.x), By = fmaf(rows.r0.y, id.y, -oid.y), Bz = fmaf(rows.r0.z, id.z, -oid.z);
-			const uint32_t lox = fbits(rows.r2.x), loy = fbits(rows.r2.y), loz = fbits(rows.r2.z);
-			const uint32_t hix = fbits(rows.r2.w), hiy = fbits(rows.r3.x), hiz = fbits(rows.r3.y);
-			const uint32_t nxq = neg_x ? hix : lox, fxq = neg_x ? lox : hix;
-			const uint32_t nyq = neg_y ? hiy : loy, fyq = neg_y ? loy : hiy;
-			const uint32_t nzq = neg_z ? hiz : loz, fzq = neg_z ? loz : hiz;
-			// slab test of the four children (aabb.cpp:39-77 in fma form); a miss (and an empty slot: an inverted box) gets
-			// distance +inf
-			const float INF = 3.0e38f;
 			float t0, t1, t2, t3;
-#define RT_SLAB4(UB, OUT)                                                                                   \
-	{                                                                                                       \
-		const float tmin = fmaxf(fmaxf(fmaf(UB(nxq), Ax, Bx), fmaf(UB(nyq), Ay, By)), fmaf(UB(nzq), Az, Bz)); \
-		const float tmax = fminf(fminf(fmaf(UB(fxq), Ax, Bx), fmaf(UB(fyq), Ay, By)), fmaf(UB(fzq), Az, Bz)); \
-		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                   \
-	}
-			RT_SLAB4(ub0, t0)
-			RT_SLAB4(ub1, t1)
-			RT_SLAB4(ub2, t2)
-			RT_SLAB4(ub3, t3)
-#undef RT_SLAB4
-			uint32_t e0 = fbits(rows.r1.x), e1 = fbits(rows.r1.y), e2 = fbits(rows.r1.z), e3 = fbits(rows.r1.w);
-			if (!ANY)
-			{
-				// order the four children by entry distance (5-comparator network), nearest first
-#define RT_CSWAP(TA, EA, TB, EB)              \
-	{                                         \
-		const bool sw = TB < TA;              \
-		const float tt = sw ? TB : TA;        \
-		const uint32_t ee = sw ? EB : EA;     \
-		TB = sw ? TA : TB, EB = sw ? EA : EB; \
-		TA = tt, EA = ee;                     \
-	}
-				RT_CSWAP(t0, e0, t1, e1)
-				RT_CSWAP(t2, e2, t3, e3)
-				RT_CSWAP(t0, e0, t2, e2)
-				RT_CSWAP(t1, e1, t3, e3)
-				RT_CSWAP(t1, e1, t2, e2)
-#undef RT_CSWAP
-				if (t0 < INF)
-				{
-					// far children first, so the nearest of them is popped first
-					push3(stk, e3, t3 < INF, e2, t2 < INF, e1, t1 < INF);
-					cur = e0;
-				}
-				else
-					cur = pop(stk);
-			}
-			else
-			{
-				// occlusion query: any order will do — the first child hit is next, later hits are stacked
-				const bool h0 = t0 < INF, h1 = t1 < INF, h2 = t2 < INF, h3 = t3 < INF;
-				const bool have = h0 || h1 || h2 || h3;
-				const uint32_t next = h0 ? e0 : (h1 ? e1 : (h2 ? e2 : e3));
-				if (have)
-					push3(stk, e1, h1 && h0, e2, h2 && (h0 || h1), e3, h3 && (h0 || h1 || h2));
-				cur = have ? next : pop(stk);
-			}
+			uint32_t e0, e1, e2, e3;
+			node_step(sc, stk, st, cur, t0, t1, t2, t3, e0, e1, e2, e3);
+			cur = take_children(stk, NODE_INF, t0, t1, t2, t3, e0, e1, e2, e3);
 #if defined(__HIP_DEVICE_COMPILE__)
 			if (VOTE < 64)
 			{
