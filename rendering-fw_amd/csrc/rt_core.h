@@ -1276,42 +1276,50 @@ RT_FN float light_pick_prob(const SceneView &sc, int idx, f3 O, f3 N, f3 I)
 		return 0;
 	return mine / sum;
 }
-// lights.h:119-157
+// lights.h:119-157: sixteen rounds of "pick one of the four sub-triangles" (two bits of r0 each, most significant first),
+// then the centroid.  The reference walks the three corners through a 16-iteration loop of four-way branches — ~600
+// instructions per call on a wave whose lanes all take different branches, a quarter of the shade kernel.  Every quantity in
+// that loop is a multiple of 2^-16 in [0, 1] (midpoints of such numbers, halved: exact in float), so the result can be
+// computed in integers, bit for bit the same.  In the frame of corner A with edges u = B - A, v = C - A one round halves
+// both edges and moves A by (alpha u + beta v) / 2, where d = 1: (0, 0), d = 2: (1, 0), d = 3: (0, 1), d = 0: (1, 1) and the
+// frame flips sign (the middle sub-triangle is the parent turned upside down).  Hence
+//     A16 = A0 + (U u0 + V v0) / 2^16,   U = sum_i s_i alpha_i 2^(15 - i),  V = sum_i s_i beta_i 2^(15 - i),
+// s_i = (-1)^(number of rounds j < i with d_j = 0), A0 = (1, 0), u0 = (-1, 1), v0 = (-1, 0), and the sum of the three final
+// corners is 3 A16 + s_16 (u0 + v0) / 2^16.  The one rounding of the reference — (Ax + Bx + Cx) * 0.3333333f on an exact
+// sum — is the one rounding here.  (tests/test_oracle_kat.py compares with the oracle's loop form, bit for bit.)
+RT_FN uint32_t even_bits(uint32_t x) // the 16 bits at even positions, packed
+{
+	x &= 0x55555555u;
+	x = (x ^ (x >> 1)) & 0x33333333u;
+	x = (x ^ (x >> 2)) & 0x0F0F0F0Fu;
+	x = (x ^ (x >> 4)) & 0x00FF00FFu;
+	x = (x ^ (x >> 8)) & 0x0000FFFFu;
+	return x;
+}
 RT_FN f3 random_barycentrics(float r0)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off) // 1 - rx - ry with rx, ry rounded products, not fma(-sum, 1/3, 1): device == emulation == oracle
+#endif
 	const uint32_t uf = f2u_sat(r0 * 4294967295.0f);
-	float Ax = 1.f, Ay = 0.f, Bx = 0.f, By = 1.f, Cx = 0.f, Cy = 0.f;
-	for (int i = 0; i < 16; ++i)
-	{
-		const int d = (int)((uf >> (2 * (15 - i))) & 0x3u);
-		float Anx, Any, Bnx, Bny, Cnx, Cny;
-		if (d == 0)
-		{
-			Anx = (Bx + Cx) * 0.5f, Any = (By + Cy) * 0.5f;
-			Bnx = (Ax + Cx) * 0.5f, Bny = (Ay + Cy) * 0.5f;
-			Cnx = (Ax + Bx) * 0.5f, Cny = (Ay + By) * 0.5f;
-		}
-		else if (d == 1)
-		{
-			Anx = Ax, Any = Ay;
-			Bnx = (Ax + Bx) * 0.5f, Bny = (Ay + By) * 0.5f;
-			Cnx = (Ax + Cx) * 0.5f, Cny = (Ay + Cy) * 0.5f;
-		}
-		else if (d == 2)
-		{
-			Anx = (Bx + Ax) * 0.5f, Any = (By + Ay) * 0.5f;
-			Bnx = Bx, Bny = By;
-			Cnx = (Bx + Cx) * 0.5f, Cny = (By + Cy) * 0.5f;
-		}
-		else
-		{
-			Anx = (Cx + Ax) * 0.5f, Any = (Cy + Ay) * 0.5f;
-			Bnx = (Cx + Bx) * 0.5f, Bny = (Cy + By) * 0.5f;
-			Cnx = Cx, Cny = Cy;
-		}
-		Ax = Anx, Ay = Any, Bx = Bnx, By = Bny, Cx = Cnx, Cy = Cny;
-	}
-	const float rx = (Ax + Bx + Cx) * 0.3333333f, ry = (Ay + By + Cy) * 0.3333333f;
+	// bit 15 - i of hi / lo = high / low bit of round i's digit d_i
+	const uint32_t hi = even_bits(uf >> 1), lo = even_bits(uf);
+	const uint32_t zero = ~(hi | lo) & 0xFFFFu;		// d == 0
+	const uint32_t alpha = ~lo & 0xFFFFu;			// d == 2 or d == 0
+	const uint32_t beta = ~(hi ^ lo) & 0xFFFFu;		// d == 3 or d == 0
+	// neg bit (15 - i) = parity of the zeros among rounds 0 .. i - 1 (an exclusive prefix XOR from the top bit down)
+	uint32_t neg = zero >> 1;
+	neg ^= neg >> 1, neg ^= neg >> 2, neg ^= neg >> 4, neg ^= neg >> 8;
+	const int U = (int)(alpha & ~neg) - (int)(alpha & neg), V = (int)(beta & ~neg) - (int)(beta & neg);
+#if defined(__HIP_DEVICE_COMPILE__)
+	const int s16 = (__popc(zero) & 1) ? -1 : 1;
+#else
+	const int s16 = (__builtin_popcount(zero) & 1) ? -1 : 1;
+#endif
+	// sum of the corners, scaled by 2^16: x: 3 (65536 - U - V) - 2 s16, y: 3 U + s16  (both < 2^18: exact as floats)
+	const float sx = (float)(3 * (65536 - U - V) - 2 * s16) * (1.0f / 65536.0f);
+	const float sy = (float)(3 * U + s16) * (1.0f / 65536.0f);
+	const float rx = sx * 0.3333333f, ry = sy * 0.3333333f;
 	return mk3(rx, ry, 1.0f - rx - ry);
 }
 // lights.h:159-265 with importance sampling over the potential contribution of every light.  The potentials are

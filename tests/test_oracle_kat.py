@@ -163,3 +163,18 @@ def test_bsdf_energy_and_pdf_sanity(orc):
         assert all(np.isfinite(rgb[:])) and min(rgb[:]) >= 0 and pdf.value >= 0
         acc += rgb[0] * z * 2 * np.pi  # uniform hemisphere pdf = 1/2pi
     assert 0.3 < acc / n < 0.75  # albedo 0.5 diffuse + the unavoidable grazing Fresnel lobe
+
+
+def test_random_barycentrics_closed_form_equals_the_loop_bit_for_bit(pkg, make_emu, make_oracle):
+    """lights.h:119-157: the product computes the sixteen sub-triangle rounds in closed form on integers (rt_core.h:
+    random_barycentrics), the oracle walks the reference's loop.  Every intermediate of the loop is exact in float, so the two
+    must agree to the last bit: 200 000 random r0, the ends of the range, and every pattern of the first four rounds."""
+    rng = np.random.default_rng(7)
+    r0 = np.concatenate([rng.random(200000, dtype=np.float32), np.float32([0.0, 1.0, 0.5, 0.25, 0.75, 0.99999994, 1e-9, 2.3283064e-10]),
+                         (np.arange(256, dtype=np.float32) + np.float32(0.37)) / np.float32(256.0)])
+    rec = np.zeros((len(r0), 24), np.float32)
+    rec[:, 20] = r0
+    a = make_emu().kat("random_barycentrics", rec)[:, :3]
+    b = make_oracle().kat("random_barycentrics", rec)[:, :3]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.all(a >= -1e-6) and np.all(np.abs(a.sum(1) - 1.0) < 1e-6)

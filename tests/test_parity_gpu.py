@@ -517,3 +517,15 @@ def test_batch_size_changes_between_pipelined_calls_gpu(pkg, make_hip):
     ia, ib = a.framebuffer(), b.framebuffer()
     assert np.abs(ia - ib).max() <= 2e-5 * max(1.0, float(ib.max()))
     assert a.get_stats().primaryCount == 480 * 272
+
+
+def test_random_barycentrics_closed_form_on_the_gpu(pkg, make_hip, make_oracle):
+    """The integer closed form of lights.h:119-157 (rt_core.h: random_barycentrics) on the device against the oracle's loop:
+    bit for bit (see tests/test_oracle_kat.py for the CPU tier)."""
+    rng = np.random.default_rng(11)
+    r0 = np.concatenate([rng.random(100000, dtype=np.float32), np.float32([0.0, 1.0, 0.5, 0.99999994, 2.3283064e-10])])
+    rec = np.zeros((len(r0), 24), np.float32)
+    rec[:, 20] = r0
+    a = make_hip().kat("random_barycentrics", rec)[:, :3]
+    b = make_oracle().kat("random_barycentrics", rec)[:, :3]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
