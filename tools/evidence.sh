@@ -32,3 +32,19 @@ tail -c 1500 gpurun_out/${tag}_bench.json
 d=$R/gpurun_out/${tag}_stats; rm -rf $d
 (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $d -- python bench.py > $d.log 2>&1)
 (cd $R && python profiles/summarize.py stats $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_kernel_stats.md; head -12 gpurun_out/${tag}_kernel_stats.md)
+# config 4 (atrium: instanced, textured — the k_shade_pt<true> variant) under the same protocol: kernel stats + three PMC passes
+if [ -n "$EVIDENCE_ATRIUM" ]; then
+  apass() { # name counters...
+    name=$1; shift
+    d=$R/gpurun_out/${tag}_atrium_pmc_$name; rm -rf $d
+    (cd $R && timeout 1200 rocprofv3 --pmc "$@" -d $d -- python bench.py --workload atrium --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $d.log 2>&1)
+    (cd $R && python profiles/summarize.py pmc $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_atrium_pmc_$name.md; head -6 gpurun_out/${tag}_atrium_pmc_$name.md)
+  }
+  apass fetch FETCH_SIZE
+  apass write WRITE_SIZE
+  apass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE
+  d=$R/gpurun_out/${tag}_atrium_stats; rm -rf $d
+  (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $d -- python bench.py --workload atrium --no-cpu-baseline > $d.log 2>&1)
+  (cd $R && python profiles/summarize.py stats $(find $d -name "*.db" | head -1) > gpurun_out/${tag}_atrium_kernel_stats.md; head -8 gpurun_out/${tag}_atrium_kernel_stats.md)
+  (cd $R && timeout 600 python bench.py --workload atrium --no-cpu-baseline --stage-rates > gpurun_out/${tag}_atrium_bench.json 2>/dev/null; tail -c 400 gpurun_out/${tag}_atrium_bench.json)
+fi
