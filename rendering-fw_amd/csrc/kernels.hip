@@ -1105,6 +1105,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	}
 	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
 	uint32_t nq = 0;								// queued hits (wave-uniform)
+	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
 #pragma nounroll
 	for (;;)
 	{
@@ -1114,6 +1115,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		{
 			// one wave of queued hits; the rest of the queue moves down
 			const uint32_t n = nq < 64u ? nq : 64u, rest = nq - n;
+			nshaded += n;
 			act = lane < n;
 			idx = act ? q[lane] : 0u;
 			const uint32_t moved = lane < rest ? q[64u + lane] : 0u;
@@ -1156,6 +1158,8 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			atomicAdd(&wc->ext[p.depth + 1], ctx.q_ext.rays);
 		if (ctx.q_shadow.rays)
 			atomicAdd(&wc->shadow[p.depth], ctx.q_shadow.rays);
+		if (nshaded)
+			atomicAdd(&wc->shaded, (unsigned long long)nshaded);
 	}
 }
 
