@@ -158,7 +158,8 @@ def main():
         # development aid for a 1-GPU box: all ranks on GPU 0 and — RCCL refuses two ranks on one device — gloo with host
         # staging for the gather.  Walks through the N > 1 control flow only; its numbers mean nothing.
         local_rank = 0
-        args.gather = "torch"
+        if os.environ.get("RFWHIP_BENCH_TRY_COMM") != "1":  # (RCCL refuses the duplicate device: exercises the loud fall-back)
+            args.gather = "torch"
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
@@ -215,7 +216,7 @@ def main():
     comm = None
     if world > 1 and args.gather == "comm":
         try:
-            idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+            idbuf = torch.zeros(128, dtype=torch.uint8, device="cpu" if one_device else dev)
             if rank == 0:
                 idbuf.copy_(torch.from_numpy(np.frombuffer(pkg.comm_unique_id(), dtype=np.uint8).copy()))
             dist.broadcast(idbuf, src=0)
@@ -223,9 +224,9 @@ def main():
         except Exception as e:  # loudly recorded, never silent: config.gather says which path produced the number
             comm = None
             gather_mode = "torch (rfwhip_comm_create failed: %s)" % str(e)[:200]
-            ok = torch.tensor([0], device=dev)
+            ok = torch.tensor([0], device="cpu" if one_device else dev)
         else:
-            ok = torch.tensor([1], device=dev)
+            ok = torch.tensor([1], device="cpu" if one_device else dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
         if int(ok.item()) == 0 and comm is not None:
             comm.destroy()

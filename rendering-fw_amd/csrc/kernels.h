@@ -20,7 +20,6 @@ struct Params
 	uint32_t queue;		// which WaveCounters::work[] row this launch pulls its chunks from
 	uint32_t group;		// chunks per XCD group (one row of tiles for the primary wave)
 	uint32_t refill;	// incoherent waves: lanes that finish a ray pull the next one (persistent lanes)
-	uint32_t knob[4];	// development knobs (settings knob0..3)
 	uint32_t textured;	// some material carries a texture / normal map: the shade kernel variant with the texture layers
 };
 

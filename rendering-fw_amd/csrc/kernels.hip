@@ -921,8 +921,6 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	// 32-spp launch; the vote threshold stays: 48 / 64 lose 2-7 %)
 	if ((MODE == STREAM_PRIMARY_PT || (MODE == STREAM_ANY && p.depth == 0)) && p.fr.sgroup_log2 >= 3u)
 		REFILL = 64u;
-	if (p.knob[0] && (MODE == STREAM_PRIMARY_PT ? 0u : (MODE == STREAM_ANY ? (p.depth == 0 ? 1u : 2u) : 3u)) + 1u == (p.knob[0] >> 8))
-		REFILL = p.knob[0] & 255u; // development: knob0 = (1 + stream kind) << 8 | threshold
 	constexpr int VOTE = MODE == STREAM_ANY ? RT_LEAF_VOTE_ANY : (MODE == STREAM_EXT ? RT_LEAF_VOTE_EXT : RT_LEAF_VOTE_PRIMARY);
 	for (;;)
 	{

@@ -524,8 +524,16 @@ int launch_device_build(const f4 *verts, const uint32_t *indices, uint32_t tri_c
 	uint32_t cur = n;
 	int in = 0;
 	const uint32_t zero = 0u;
+	// Every pass merges the mutual nearest-neighbour pairs (about a third of the clusters: ~25 passes for 1 M triangles); a pass
+	// that finds no mutual pair pairs neighbours in Morton order instead.  The pass count is bounded: input that makes the
+	// clustering crawl (5 = "did not converge") is handed to the host builder by the caller instead of looping on host round trips.
+	uint32_t passes = 0, max_passes = 64u;
+	for (uint32_t m = n; m > 1u; m >>= 1)
+		max_passes += 8u;
 	while (cur > 1u)
 	{
+		if (++passes > max_passes)
+			return 5;
 		const dim3 g((cur + 255u) / 256u);
 		hipLaunchKernelGGL(k_ploc_nearest, g, dim3(256), 0, st, b.cl[in], cur, b.nearest);
 		uint32_t merged = 0;

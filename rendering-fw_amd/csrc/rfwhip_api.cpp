@@ -400,7 +400,6 @@ struct rfwhip_context
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
 	int sample_group = 32; // slot layout: up to this many samples of a pixel share a wave (rt_core.h; the largest power of two
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample)
-	uint32_t knob[4] = {0, 0, 0, 0};
 	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
@@ -935,7 +934,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 												c->d_lbvh_scratch.p, c->d_lbvh_scratch.cap, m.d_b_nodes.as<rt::Node>(),
 												m.d_parents.as<int>(), m.d_flags.as<uint32_t>(), m.d_b_nodes4.as<rt::Node4c>(),
 												m.d_b_src.as<uint32_t>(), m.d_b_tri_verts.as<f4>(), &res, c->stream);
-		if (rc > 1)
+		if (rc > 1 && rc != 5) // (5: the clustering did not converge within its pass budget — the host builder takes the mesh)
 			return set_error(RFWHIP_ERR_HIP, "rfwhip_set_mesh: device BVH build failed (%d)", rc);
 		RF_TRY(dm::last_launch_error());
 		if (c->stage_timing)
@@ -1584,8 +1583,6 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	p.fr.sample_base = c->samples_done;
 	p.fr.probe_pixel = c->probe_y * c->W + c->probe_x;
 	p.max_depth = (uint32_t)c->max_depth;
-	for (int k = 0; k < 4; k++)
-		p.knob[k] = c->knob[k];
 	p.parity_no_jitter = c->jitter == 1;
 	// LDS top-of-tree cache: the first nodes (breadth-first top, bvh::collapse4) of the BLAS with the most nodes
 	p.lds_first = 0, p.lds_count = 0;
@@ -1927,7 +1924,14 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 extern "C" int rfwhip_wait(rfwhip_context *c)
 {
 	CTX_ENTER(c);
-	RF_TRY(sync_all(c));
+	// every render call ends with its resolve on the main stream, behind the events of all its sub-batch and connection
+	// streams: the main stream alone tells when the enqueued frames are done (one synchronisation instead of up to 17)
+	RF_TRY(dm::sync(c->stream));
+	if (c->present_pending)
+	{
+		RF_TRY(dm::event_sync(c->ev_present_out));
+		c->present_pending = false;
+	}
 	// wave counters of the last frame, summed over its sub-batches.  A sub-batch's connection wave of depth d ran only
 	// if its depth d + 1 had extension rays (k_connect / k_trace_stream: connection_count)
 	rt::WaveCounters wc;
@@ -2236,8 +2240,6 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "ring must be in [1, %d]", (int)rfwhip_context::MAX_RING);
 		c->ring = n;
 	}
-	else if (k.size() == 5 && k.compare(0, 4, "knob") == 0 && k[4] >= '0' && k[4] <= '3')
-		c->knob[k[4] - '0'] = (uint32_t)atoi(value);
 	else if (k == "sample_group")
 	{
 		const int n = atoi(value);
