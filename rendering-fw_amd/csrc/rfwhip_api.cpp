@@ -145,17 +145,6 @@ static int stream_create(void **s)
 	*s = st;
 	return 0;
 }
-// a stream of the highest priority the device offers (its own hardware queue pool: see rfwhip_create)
-static int stream_create_high(void **s)
-{
-	int least = 0, greatest = 0;
-	hipStream_t st;
-	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
-		least = greatest = 0;
-	DM_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
-	*s = st;
-	return 0;
-}
 static void stream_destroy(void *s)
 {
 	if (s)
@@ -236,7 +225,6 @@ static int stream_create(void **s)
 	*s = nullptr;
 	return 0;
 }
-static int stream_create_high(void **s) { return stream_create(s); }
 static void stream_destroy(void *) {}
 static int last_launch_error() { return 0; }
 typedef std::chrono::steady_clock::time_point event_t;
@@ -564,11 +552,7 @@ extern "C" int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_con
 	memset(&c->totals, 0, sizeof(c->totals));
 	memset(&c->sv, 0, sizeof(c->sv));
 	memset(&c->fr, 0, sizeof(c->fr));
-	// The main stream (prologue, resolve, presents) is a HIGH-priority stream: the runtime keeps a separate pool of hardware
-	// queues per priority, so the main stream never shares a queue with the sub-batch streams — a resolve waiting for its
-	// call's chains would otherwise block, head of line, whatever chain of a LATER call sits behind it on the same queue
-	// (measured as 1.16 vs 1.5–1.6 ms per pipelined 1-spp frame depending on the order in which a process had created streams).
-	if (dm::stream_create_high(&c->stream))
+	if (dm::stream_create(&c->stream))
 	{
 		delete c;
 		return RFWHIP_ERR_HIP;
@@ -1657,15 +1641,12 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 		}
 		c->events_ready = true;
 	}
-	// Streams are created in the order main, sub 0..n-1 — and the connection streams only when a call first uses them
-	// (rfwhip_render): the runtime deals streams to its (by default four) hardware queues round-robin in creation order, so the
-	// four launch chains of a ring / of a call's sub-batches land on four different queues.  With sub / connection streams
-	// created alternately they shared two queues and half of the overlap was lost (1080p, 1 spp, pipelined: 1.16 ms per frame
-	// for the first context of a process, 1.63 ms for every later one).
 	for (int i = 0; i < subs; i++)
 	{
 		if (!c->sub_stream[i])
 			RF_TRY(dm::stream_create(&c->sub_stream[i]));
+		if (!c->conn_stream[i])
+			RF_TRY(dm::stream_create(&c->conn_stream[i]));
 		if (i > 0 && !c->d_counters_sub[i].p)
 		{
 			RF_TRY(c->d_counters_sub[i].ensure(sizeof(rt::WaveCounters)));
@@ -1827,8 +1808,6 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	for (int k = 0; k < subs; k++)
 	{
 		const int i = first_slot + k; // which set of streams / counters / buffer slices
-		if (side && !c->conn_stream[i])
-			RF_TRY(dm::stream_create(&c->conn_stream[i]));
 		void *s = c->sub_stream[i], *sc = side ? c->conn_stream[i] : c->sub_stream[i];
 		const uint32_t s_begin = (uint32_t)((long long)c->spp * k / subs), s_end = (uint32_t)((long long)c->spp * (k + 1) / subs);
 		const uint32_t spp_i = s_end - s_begin;
