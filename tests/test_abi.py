@@ -69,3 +69,27 @@ def test_material_packing_matches_reference_rules(pkg):
     assert (p2 >> 24) == int(1.5 * 0.5 * 255) and ((p2 >> 8) & 0xFF) == 255  # eta*0.5, clearcoatGloss default 1
     assert m["flags"] & (1 << 0) and m["flags"] & (1 << 11) and not (m["flags"] & (1 << 2))
     assert ids[0]["texture"][0] == -1
+
+
+def test_bench_counters_are_tied_to_the_sources_they_were_taken_on(tmp_path):
+    """bench.py reports PMC-derived figures only when profiles/stage_counters.json was taken on the sources that run
+    (csrc_hash): a stale file is recognised, a matching one accepted, a file of another workload ignored."""
+    import json
+    import bench
+    h = bench.csrc_hash()
+    assert len(h) == 16 and h == bench.csrc_hash()
+    p = tmp_path / "stage_counters.json"
+    base = {"workload": "terrain_1002k", "spp": 128, "streams": 4, "tag": "t", "kernels": {}}
+    p.write_text(json.dumps(dict(base, csrc_hash=h)))
+    pm, fresh = bench.load_stage_counters(str(p), "terrain_1002k", 128, 4)
+    assert pm is not None and fresh
+    p.write_text(json.dumps(dict(base, csrc_hash="0" * 16)))
+    pm, fresh = bench.load_stage_counters(str(p), "terrain_1002k", 128, 4)
+    assert pm is not None and not fresh
+    assert bench.load_stage_counters(str(p), "atrium", 128, 4) == (None, False)
+    assert bench.load_stage_counters(str(tmp_path / "missing.json"), "terrain_1002k", 128, 4) == (None, False)
+    # the committed file belongs to the committed sources
+    import os
+    committed = os.path.join(os.path.dirname(bench.__file__), "profiles", "stage_counters.json")
+    pm, fresh = bench.load_stage_counters(committed, "terrain_1002k", 128, 4)
+    assert pm is not None and fresh, "profiles/stage_counters.json is stale: re-run tools/evidence.sh after changing csrc/"
