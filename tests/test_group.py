@@ -136,6 +136,9 @@ def test_group_on_one_device_equals_the_single_context_gpu(pkg, make_hip, n, int
     assert hip.hipMemcpy(c_void_p(host.ctypes.data), c_void_p(ptr), host.nbytes, 2) == 0  # hipMemcpyDeviceToHost
     assert np.array_equal(host, ref)
     assert np.array_equal(g.framebuffer(), ref)
+    # frames in flight: the pinned host image of slot 1 is the same frame
+    g.present_async(1)
+    assert np.array_equal(g.present_wait(1), ref)
     g.destroy()
 
 

@@ -11,8 +11,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("devices", [None, "0,0,0"])
-def test_plugin_through_the_virtual_interface(pkg, devices):
+@pytest.mark.parametrize("devices,in_flight", [(None, 1), ("0,0,0", 1), ("0,0", 2)])
+def test_plugin_through_the_virtual_interface(pkg, devices, in_flight):
     """devices "0,0,0": the plugin on an rfwhip_group of three contexts (strip split + gather below the C ABI; one GPU, so
     the peer transport) must print the very same numbers."""
     host = os.path.join(ROOT, "tests", "plugin", "plugin_host")
@@ -21,6 +21,8 @@ def test_plugin_through_the_virtual_interface(pkg, devices):
     env = dict(os.environ)
     if devices:
         env.update(RFWHIP_DEVICES=devices, RFWHIP_TRANSPORT="peer")
+    if in_flight > 1:  # frames in flight: the first render_frame hands out its own frame (there is no earlier one)
+        env.update(RFWHIP_FRAMES_IN_FLIGHT=str(in_flight))
     r = subprocess.run([host, plugin_dir], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
     out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
