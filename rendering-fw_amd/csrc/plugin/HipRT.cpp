@@ -241,7 +241,10 @@ class Context final : public rfw::RenderContext
 
 	void get_probe_results(unsigned int *instanceIndex, unsigned int *primitiveIndex, float *distance) const override
 	{
-		// the probe pixel belongs to one rank's strips; the others report nothing for it
+		// the probe pixel belongs to one rank's strips; the others report nothing for it.  (The probe record is read back by a
+		// wait; with frames in flight nothing else waits.)
+		if (m_InFlight >= 2)
+			HIPRT_CHECK(rfwhip_group_wait(m_Group));
 		unsigned int inst = 0, prim = 0;
 		float dist = 0.0f;
 		for (rfwhip_context *c : m_Cores)
