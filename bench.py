@@ -81,13 +81,15 @@ def probe_embree():
 
 
 def csrc_hash():
-    """Identity of the kernel / host sources a measurement belongs to: sha1 over rendering-fw_amd/csrc/*.{h,hip,cpp} (sorted,
-    names + contents).  profiles/stage_counters.json records it when tools/evidence.sh derives the file; figures taken on
-    other sources are reported as null."""
+    """Identity of the sources a single-GPU measurement belongs to: sha1 over the files of rendering-fw_amd/csrc/ that make
+    up the render path (kernels, device functions, data layout, host-side launch logic and BVH builders; sorted, names +
+    contents — not the multi-GPU gather of rfwhip_group.cpp, which no single-GPU kernel passes through).
+    profiles/stage_counters.json records it when tools/evidence.sh derives the file; figures taken on other sources are
+    reported as null."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "rendering-fw_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".cpp")):
+        if f.endswith((".h", ".hip", ".cpp")) and f not in ("rfwhip_group.cpp", "internal.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

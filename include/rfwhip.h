@@ -169,11 +169,14 @@ RFWHIP_API int rfwhip_group_gather(rfwhip_group *group);
 RFWHIP_API int rfwhip_group_wait(rfwhip_group *group);
 RFWHIP_API int rfwhip_group_read_framebuffer(rfwhip_group *group, float *rgba_host);
 RFWHIP_API int rfwhip_group_framebuffer_device(rfwhip_group *group, void **rgba_device, int *device_ordinal);
-/* Pipelined presentation (frames in flight): present_async = gather + asynchronous copy of the image into one of two
- * pinned host buffers (slot 0 / 1), enqueue only; present_wait blocks until that slot's copy has landed and hands out the
- * buffer (valid until the slot is presented into again).  A host that calls render(k), present_async(k & 1),
- * present_wait((k - 1) & 1) shows frame k - 1 while frame k renders: the devices never idle between frames (1080p, 1 spp:
- * 1.2 ms per frame instead of 2.1 ms for render + wait per frame). */
+/* Pipelined presentation (frames in flight): present_async = gather + asynchronous copy of the image into one of
+ * RFWHIP_PRESENT_SLOTS pinned host buffers, enqueue only; present_wait blocks until that slot's copy has landed and hands out
+ * the buffer (valid until the slot is presented into again).  A host that keeps n <= RFWHIP_PRESENT_SLOTS frames in flight —
+ * render(k), present_async(k % n), present_wait((k + 1) % n) from frame n - 1 on — shows frame k - n + 1 while frames up to
+ * k render: a frame's launch chain is ten dependent kernels of tails, and it takes about four chains in flight to fill the
+ * device (1080p, 1 spp, image on the host every frame: 2.76 ms per frame with render + wait + read-back, 2.14 ms with two
+ * frames in flight, 1.70 ms with four). */
+#define RFWHIP_PRESENT_SLOTS 4
 RFWHIP_API int rfwhip_group_present_async(rfwhip_group *group, int slot);
 RFWHIP_API int rfwhip_group_present_wait(rfwhip_group *group, int slot, const float **rgba_host);
 

@@ -9,9 +9,9 @@
 // host thread (the reference's render loop, RFW/system/src/rfw/app.cpp:3-26) drives one context per device, every scene call
 // is repeated per context, and the strips are gathered over xGMI (RCCL, or RFWHIP_TRANSPORT=peer) into device 0's image.
 //
-// Frames in flight: RFWHIP_FRAMES_IN_FLIGHT=2 (default 1) — render_frame(k) enqueues frame k and its presentation and
-// returns with frame k - 1 on the host (rfwhip_group_present_async / _wait): the devices never idle between frames
-// (1080p, 1 spp: 1.2 instead of 2.1 ms per frame); with 1 it returns with frame k finished, like the reference's backends.
+// Frames in flight: RFWHIP_FRAMES_IN_FLIGHT=n (1..4, default 1) — render_frame(k) enqueues frame k and its presentation and
+// returns with frame k - n + 1 on the host (rfwhip_group_present_async / _wait): the devices never idle between frames; with 1
+// it returns with frame k finished, like the reference's backends.
 //
 // Headless by default (RenderTarget::BUFFER, context.h:27-34): the GPU box has no OpenGL.  With
 // -DRFWHIP_PLUGIN_WITH_GL (needs GLEW, i.e. the reference's own build environment) render_frame also uploads the
@@ -72,7 +72,7 @@ class Context final : public rfw::RenderContext
 		for (int i = 0; i < rfwhip_group_size(m_Group); i++)
 			m_Cores.push_back(rfwhip_group_context(m_Group, i));
 		if (const char *f = std::getenv("RFWHIP_FRAMES_IN_FLIGHT"))
-			m_InFlight = std::atoi(f) >= 2 ? 2 : 1;
+			m_InFlight = std::max(1, std::min(RFWHIP_PRESENT_SLOTS, std::atoi(f)));
 		const char *integ = std::getenv("RFWHIP_INTEGRATOR");
 		HIPRT_CHECK(rfwhip_group_set_setting(m_Group, "integrator", integ ? integ : "pt"));
 #ifdef RFWHIP_HAVE_BLUE_NOISE_TABLE
@@ -155,10 +155,12 @@ class Context final : public rfw::RenderContext
 		const float *image = nullptr;
 		if (m_InFlight >= 2)
 		{
-			// frame k and its way to the host are enqueued; what is handed out is frame k - 1 (the first call waits for its own)
-			const int slot = (int)(m_Frame & 1u);
-			HIPRT_CHECK(rfwhip_group_present_async(m_Group, slot));
-			HIPRT_CHECK(rfwhip_group_present_wait(m_Group, m_Frame ? slot ^ 1 : slot, &image));
+			// frame k and its way to the host are enqueued; what is handed out is frame k - (n - 1) (the first n - 1 calls wait
+			// for frame 0, their own oldest)
+			const int n = m_InFlight;
+			HIPRT_CHECK(rfwhip_group_present_async(m_Group, (int)(m_Frame % (unsigned)n)));
+			const unsigned long long oldest = m_Frame >= (unsigned)(n - 1) ? m_Frame - (unsigned)(n - 1) : 0;
+			HIPRT_CHECK(rfwhip_group_present_wait(m_Group, (int)(oldest % (unsigned)n), &image));
 			m_Latest = image;
 		}
 		else

@@ -273,9 +273,12 @@ struct rfwhip_group
 	void *staging = nullptr, *full = nullptr; // on the root's device
 	int root_local = -1;					  // index of rank 0 in ep, -1 when another process owns it
 	// pipelined presentation (rfwhip_group_present_async / _wait): two pinned host images and the events of their copies
-	void *host_img[2] = {nullptr, nullptr};
-	event_t host_ready[2];
-	bool host_events = false, host_pending[2] = {false, false};
+	static constexpr int SLOTS = RFWHIP_PRESENT_SLOTS;
+	void *host_img[SLOTS] = {};
+	void *slot_img[SLOTS] = {};	 // the de-interleaved image of each slot on the root's device (the copy's source)
+	void *copy_stream = nullptr; // the device-to-host copies run beside the gather chain, not inside it
+	event_t host_ready[SLOTS], slot_done[SLOTS];
+	bool host_events = false, host_pending[SLOTS] = {};
 	size_t chunk_bytes() const { return (size_t)local_rows * W * PIXEL_BYTES; }
 };
 struct rfwhip_comm
@@ -299,8 +302,11 @@ void release_buffers(rfwhip_group *g)
 		dev_free(g->staging), dev_free(g->full);
 	}
 	g->staging = g->full = nullptr;
-	for (int k = 0; k < 2; k++)
+	for (int k = 0; k < rfwhip_group::SLOTS; k++)
+	{
 		host_free(g->host_img[k]), g->host_img[k] = nullptr, g->host_pending[k] = false;
+		dev_free(g->slot_img[k]), g->slot_img[k] = nullptr;
+	}
 }
 
 // (re)allocate the gather buffers for the contexts' current render target
@@ -433,6 +439,11 @@ int wait_all(rfwhip_group *g)
 		GR_TRY(dev_use(e.device));
 		GR_TRY(stream_sync(e.stream));
 	}
+	if (g->copy_stream && g->root_local >= 0)
+	{
+		GR_TRY(dev_use(g->ep[(size_t)g->root_local].device));
+		GR_TRY(stream_sync(g->copy_stream));
+	}
 	return 0;
 }
 
@@ -443,6 +454,11 @@ void destroy_group(rfwhip_group *g)
 		(void)dev_use(e.device);
 		if (e.stream)
 			(void)stream_sync(e.stream);
+	}
+	if (g->copy_stream && g->root_local >= 0)
+	{
+		(void)dev_use(g->ep[(size_t)g->root_local].device);
+		(void)stream_sync(g->copy_stream);
 	}
 	release_buffers(g);
 	for (auto &e : g->ep)
@@ -459,7 +475,12 @@ void destroy_group(rfwhip_group *g)
 			rfwhip_destroy(e.ctx);
 	}
 	if (g->host_events)
-		event_destroy(g->host_ready[0]), event_destroy(g->host_ready[1]), g->host_events = false;
+	{
+		for (int k = 0; k < rfwhip_group::SLOTS; k++)
+			event_destroy(g->host_ready[k]), event_destroy(g->slot_done[k]);
+		g->host_events = false;
+	}
+	stream_destroy(g->copy_stream), g->copy_stream = nullptr;
 	g->ep.clear();
 }
 
@@ -626,11 +647,12 @@ extern "C" int rfwhip_group_read_framebuffer(rfwhip_group *g, float *rgba_host)
 	return copy_to_host(rgba_host, g->full, (size_t)g->W * g->H * PIXEL_BYTES, root.stream);
 }
 
-// Pipelined presentation: frame k's image travels to the host while frame k + 1 renders.  present_async enqueues gather +
-// device-to-host copy into pinned host image `slot` (0 / 1) and returns; present_wait blocks until that copy has landed.
+// Pipelined presentation: frame k's image travels to the host while the next frames render.  present_async enqueues gather +
+// device-to-host copy into pinned host image `slot` (0 .. RFWHIP_PRESENT_SLOTS - 1) and returns; present_wait blocks until
+// that copy has landed.  With n slots a host keeps n frames in flight: render(k), present_async(k % n), present_wait((k + 1) % n).
 extern "C" int rfwhip_group_present_async(rfwhip_group *g, int slot)
 {
-	if (!g || slot < 0 || slot > 1)
+	if (!g || slot < 0 || slot >= rfwhip_group::SLOTS)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_group_present_async: bad arguments");
 	if (g->root_local < 0 || !g->full)
 		return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "no render target");
@@ -639,23 +661,35 @@ extern "C" int rfwhip_group_present_async(rfwhip_group *g, int slot)
 	const size_t bytes = (size_t)g->W * g->H * PIXEL_BYTES;
 	if (!g->host_events)
 	{
-		GR_TRY(event_create(&g->host_ready[0]));
-		GR_TRY(event_create(&g->host_ready[1]));
+		for (int k = 0; k < rfwhip_group::SLOTS; k++)
+		{
+			GR_TRY(event_create(&g->host_ready[k]));
+			GR_TRY(event_create(&g->slot_done[k]));
+		}
+		GR_TRY(stream_create(&g->copy_stream));
 		g->host_events = true;
 	}
 	if (!g->host_img[slot])
 		GR_TRY(host_alloc(&g->host_img[slot], bytes));
-	GR_TRY(gather(g, nullptr));
+	if (!g->slot_img[slot])
+		GR_TRY(dev_alloc(&g->slot_img[slot], bytes));
+	// the slot's device image is rewritten only after its previous copy to the host has read it
+	if (g->host_pending[slot])
+		GR_TRY(stream_wait(root.stream, g->host_ready[slot]));
+	GR_TRY(gather(g, g->slot_img[slot]));
 	GR_TRY(dev_use(root.device));
-	GR_TRY(copy_to_host_async(g->host_img[slot], g->full, bytes, root.stream));
-	GR_TRY(event_record(g->host_ready[slot], root.stream));
+	GR_TRY(event_record(g->slot_done[slot], root.stream));
+	// ... and the copy rides its own stream: the next frame's present / transfer / de-interleave do not queue behind 33 MB of PCIe
+	GR_TRY(stream_wait(g->copy_stream, g->slot_done[slot]));
+	GR_TRY(copy_to_host_async(g->host_img[slot], g->slot_img[slot], bytes, g->copy_stream));
+	GR_TRY(event_record(g->host_ready[slot], g->copy_stream));
 	g->host_pending[slot] = true;
 	return RFWHIP_OK;
 }
 
 extern "C" int rfwhip_group_present_wait(rfwhip_group *g, int slot, const float **rgba_host)
 {
-	if (!g || slot < 0 || slot > 1 || !rgba_host)
+	if (!g || slot < 0 || slot >= rfwhip_group::SLOTS || !rgba_host)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_group_present_wait: bad arguments");
 	if (!g->host_img[slot])
 		return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "rfwhip_group_present_wait: nothing was presented into slot %d", slot);

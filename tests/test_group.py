@@ -42,18 +42,20 @@ def test_group_of_emulated_contexts_equals_the_single_context(pkg, make_emu, emu
     g.destroy()
 
 
-def test_frames_in_flight_hand_out_the_previous_frame(pkg, make_emu, emu_lib):
-    """render(k), present_async(k & 1), present_wait((k - 1) & 1): the image handed out during frame k is frame k - 1's
-    accumulator, bit for bit (here: 1, 2, 3 accumulated samples of a converging series)."""
+@pytest.mark.parametrize("n", [2, 4])
+def test_frames_in_flight_hand_out_earlier_frames(pkg, make_emu, emu_lib, n):
+    """n frames in flight: render(k), present_async(k % n), present_wait((k + 1) % n) — the image handed out during frame k is
+    frame k - n + 1's accumulator, bit for bit (here: the accumulated samples of a converging series)."""
     scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
     settings = {"integrator": "pt", "spp": 1, "max_depth": 2}
+    frames = 6
     want = []
     ref = make_emu()
     ref.init(64, 48)
     scene.upload(ref)
     for k, v in settings.items():
         ref.set_setting(k, v)
-    for k in range(3):
+    for k in range(frames):
         ref.render_frame(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
         want.append(ref.framebuffer())
     g = pkg._binding.RenderGroup(emu_lib, "rfwhip_", [0, 0], "peer")
@@ -63,12 +65,18 @@ def test_frames_in_flight_hand_out_the_previous_frame(pkg, make_emu, emu_lib):
         g.set_setting(k, v)
     with pytest.raises(RuntimeError):
         g.present_wait(0)  # nothing presented yet
-    for k in range(4):
-        if k < 3:
-            g.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
-            g.present_async(k & 1)
-        if k >= 1:
-            assert np.array_equal(g.present_wait((k - 1) & 1), want[k - 1]), k
+    with pytest.raises(RuntimeError):
+        g.present_async(4)  # RFWHIP_PRESENT_SLOTS slots
+    shown = 0
+    for k in range(frames):
+        g.render_async(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+        g.present_async(k % n)
+        if k >= n - 1:
+            assert np.array_equal(g.present_wait((k + 1) % n), want[k - n + 1]), k
+            shown += 1
+    for k in range(frames - n + 1, frames):  # drain
+        assert np.array_equal(g.present_wait(k % n), want[k]), k
+    assert shown == frames - n + 1
     g.destroy()
 
 

@@ -11,7 +11,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("devices,in_flight", [(None, 1), ("0,0,0", 1), ("0,0", 2)])
+@pytest.mark.parametrize("devices,in_flight", [(None, 1), ("0,0,0", 1), ("0,0", 2), (None, 4)])
 def test_plugin_through_the_virtual_interface(pkg, devices, in_flight):
     """devices "0,0,0": the plugin on an rfwhip_group of three contexts (strip split + gather below the C ABI; one GPU, so
     the peer transport) must print the very same numbers."""

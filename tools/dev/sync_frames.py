@@ -21,16 +21,19 @@ for spp in (1, 8):
     for k in range(N):
         g.render_frame(scene.camera, pkg.CONVERGE); img = g.framebuffer()
     a2 = (time.perf_counter() - t) / N * 1e3
-    g.wait()
-    t = time.perf_counter()
-    for k in range(N):
-        g.render_async(scene.camera, pkg.CONVERGE); g.present_async(k & 1)
-        if k: img = g.present_wait((k - 1) & 1)
-    g.present_wait((N - 1) & 1)
-    b = (time.perf_counter() - t) / N * 1e3
+    bs = []
+    for n in (2, 4):
+        g.wait()
+        t = time.perf_counter()
+        for k in range(N):
+            g.render_async(scene.camera, pkg.CONVERGE); g.present_async(k % n)
+            if k >= n - 1: img = g.present_wait((k + 1) % n)
+        g.wait()
+        bs.append((time.perf_counter() - t) / N * 1e3)
+    b = bs[0]
     g.wait()
     t = time.perf_counter()
     for k in range(N): g.render_async(scene.camera, pkg.CONVERGE)
     g.wait()
     c = (time.perf_counter() - t) / N * 1e3
-    print("spp %d: render+wait %.3f ms  render+wait+readback %.3f ms  frames in flight (image on the host every frame) %.3f ms  enqueue only %.3f ms" % (spp, a, a2, b, c), flush=True)
+    print("spp %d: render+wait %.3f ms  render+wait+readback %.3f ms  2 / 4 frames in flight (image on the host every frame) %.3f / %.3f ms  enqueue only %.3f ms" % (spp, a, a2, bs[0], bs[1], c), flush=True)
