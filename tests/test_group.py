@@ -166,3 +166,40 @@ def test_group_over_rccl_needs_two_devices(pkg, make_hip):
     img = _render(pkg, g, scene, 480, 270, settings, frames=3)
     assert np.array_equal(img, ref)
     g.destroy()
+
+
+@pytest.mark.gpu
+def test_two_process_comm_gather_needs_two_devices(pkg):
+    """rfwhip_comm_* end to end, one process per device: `bench.py --gpus 2` under torch.distributed.run (RCCL send / recv issued
+    by librfwhip.so).  Needs >= 2 visible devices; on one device the same launch is walked through with
+    RFWHIP_BENCH_ONE_DEVICE=1 + RFWHIP_BENCH_TRY_COMM=1: RCCL refuses the duplicate device and bench.py must fall back to the
+    torch gather LOUDLY (config.gather says so) and still produce the right image mean."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not two:
+        env.update(RFWHIP_BENCH_ONE_DEVICE="1", RFWHIP_BENCH_TRY_COMM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8",
+           "--width", "480", "--height", "270", "--grid", "64", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    if two:
+        assert d["config"]["gather"] == "comm", d["config"]["gather"]
+    else:
+        assert d["config"]["gather"].startswith("torch (rfwhip_comm_create failed"), d["config"]["gather"]
+    # the same two steps on one rank: the strip split does not change the image
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", "8", "--width", "480",
+                          "--height", "270", "--grid", "64", "--no-roofline", "--no-cpu-baseline"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(d["image_mean"] - d1["image_mean"]) <= 1e-6 * abs(d1["image_mean"]), (d["image_mean"], d1["image_mean"])
