@@ -150,3 +150,21 @@ def test_queue_blocks_and_kernel_forms_do_not_change_the_image(pkg, make_hip, te
     for name in tot:
         assert tot[name] == getattr(sa, name), name
     assert np.abs(c.framebuffer() - a.framebuffer()).max() <= 1e-4 * max(1.0, float(a.framebuffer().max()))
+
+
+def test_sample_groups_at_full_size(pkg, make_hip, terrain):
+    """The slot layout's sample groups (a wave = 64 / g pixels x g samples, rt_core.h) at the bench's own size: 1920 x 1080 x
+    32 spp on the 1 M-triangle terrain with g = 1 (a wave = one 8 x 8 tile of one sample), 8 and 32 — the images, the primary
+    hits read back through the layout and the wave sizes are identical, bit for bit."""
+    out = []
+    for g in (1, 8, 32):
+        c = _ctx(pkg, make_hip, terrain, spp=32, streams=1, sample_group=g)
+        c.render_frame(terrain.camera, pkg.RESET)
+        st = c.get_stats()
+        out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
+        c.destroy()
+    for img, hits, counts in out[1:]:
+        assert np.array_equal(img, out[0][0])
+        for k in ("t", "prim", "inst", "u", "v"):
+            assert np.array_equal(hits[k], out[0][1][k]), k
+        assert counts == out[0][2]
