@@ -207,6 +207,8 @@ def main():
         k, _, v = kv.partition("=")
         ctx.set_setting(k, v)
         extra[k] = v
+    if args.set:
+        ctx.update()  # a setting may be one the acceleration structure depends on (flat_instances)
 
     W, H = args.width, args.height
     local_rows = ctx.local_rows()

@@ -225,6 +225,10 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   sample_group = slot layout: up to this many samples of a pixel sit side by side in one wave (power of two <= 64,
  *                  default 32; the largest such group that divides every sub-batch of a call is used; 1 = a wave is one
  *                  8x8 tile of one sample).  Changes which path sits where, never the image
+ *   flat_instances = "1" (default): an instance with the identity transform whose mesh no other instance uses is linked
+ *                  into the top-level tree directly (rays reach its triangles without an instance switch; hit records,
+ *                  images and counters are unchanged); "0": every instance behind a top-level leaf.  Takes effect with
+ *                  the next rfwhip_update()
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 4)
  *   refill       = bit mask, default 7: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,

@@ -63,6 +63,10 @@ void launch_refit(rt::Node *nodes, uint32_t node_base, const int *parents, uint3
 				  uint32_t tri_base, const rt::f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags,
 				  stream_t s);
 
+// Flat instances (rfwhip_update): the triangles of a mesh whose one instance has the identity transform are reached without
+// entering an instance, so every one of them carries that instance's index (w of its second leaf-ordered vertex).
+void launch_stamp_instance(rt::f4 *tri_verts, uint32_t tri_count, uint32_t instance, stream_t s);
+
 // after a refit of the BVH2 boxes: re-quantise the child boxes of the compressed 4-wide nodes of the same BLAS; src4 = four
 // BLAS-relative BVH2 node indices per 4-wide node (Node4::src of the host's collapse)
 void launch_refresh4(rt::Node4c *nodes4, const uint32_t *src4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);

@@ -1281,6 +1281,18 @@ __global__ void __launch_bounds__(BLOCK) k_refit_nodes(Node *all_nodes, uint32_t
 	}
 }
 
+__global__ void __launch_bounds__(BLOCK) k_stamp_instance(f4 *tri_verts, uint32_t tri_count, uint32_t instance)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < tri_count)
+		tri_verts[3ull * i + 1].w = ubits(instance);
+}
+void launch_stamp_instance(f4 *tri_verts, uint32_t tri_count, uint32_t instance, stream_t s)
+{
+	if (tri_count)
+		hipLaunchKernelGGL(k_stamp_instance, dim3((tri_count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, tri_verts, tri_count, instance);
+}
+
 __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *nodes2)
 {
 	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1595,6 +1607,11 @@ void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, con
 {
 	for (uint32_t i = 0; i < tri_count; i++)
 		skin_shade_item(shade, verts, vnormals, indices, i);
+}
+void launch_stamp_instance(f4 *tri_verts, uint32_t tri_count, uint32_t instance, stream_t)
+{
+	for (uint32_t i = 0; i < tri_count; i++)
+		tri_verts[3ull * i + 1].w = ubits(instance);
 }
 void launch_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *blas_nodes2, stream_t)
 {

@@ -398,6 +398,7 @@ struct rfwhip_context
 	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
+	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly
 	int sample_group = 32; // slot layout: up to this many samples of a pixel share a wave (rt_core.h; the largest power of two
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample)
 	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
@@ -1401,10 +1402,47 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	if (c->blas_nodes4 + tl4.size() > c->node4_capacity)
 		return set_error(RFWHIP_ERR_STATE, "internal: TLAS does not fit behind the BLAS nodes");
 	const uint32_t tlas_base = (uint32_t)c->blas_nodes4;
+	// FLAT instances: an instance with the identity transform whose mesh no other instance uses is linked into the top-level
+	// tree directly — its top-level leaf becomes the entry of its mesh's root, so a ray walks from the top-level nodes into the
+	// mesh's nodes without the instance switch (ray transform and three divisions on the way in, the sentinel and the same on
+	// the way out — and, in the wave kernels, a wait for the wave's next leaf phase each time).  The world-space ray IS the
+	// object-space ray there (1 * x + 0 * y + 0 * z + 0 is exact), so nothing a ray computes changes; the triangles carry the
+	// instance index the hit record needs (rtk::launch_stamp_instance).  Static world geometry is typically instanced this way.
+	std::vector<uint8_t> flat(c->instances.size(), 0);
+	{
+		std::vector<uint32_t> uses(c->meshes.size(), 0u);
+		for (uint32_t i : live)
+			uses[c->instances[i].mesh]++;
+		static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+		for (uint32_t i : live)
+		{
+			bool id = uses[c->instances[i].mesh] == 1u && c->flat_instances != 0;
+			for (int k = 0; k < 12 && id; k++)
+				id = inst[i].inv[k] == ident[k];
+			flat[i] = id ? 1 : 0;
+		}
+	}
+	auto flat_entry = [&](uint32_t e) -> uint32_t { // a top-level leaf entry -> the mesh root's entry when its instance is flat
+		if (e == rt::ENTRY_EMPTY || !(e & rt::ENTRY_LEAF))
+			return e;
+		const uint32_t ii = tprims[e & rt::ENTRY_FIRST_MASK];
+		return flat[ii] ? inst[ii].root_entry : e;
+	};
 	for (rt::Node4 &nd : tl4)
 		for (int j = 0; j < 4; j++)
+		{
 			if (nd.entry[j] != rt::ENTRY_EMPTY && !(nd.entry[j] & rt::ENTRY_LEAF))
 				nd.entry[j] += tlas_base; // inner: absolute node index; leaves index tlas_prims
+			else
+				nd.entry[j] = flat_entry(nd.entry[j]);
+		}
+	for (uint32_t i : live)
+		if (flat[i])
+		{
+			const MeshRec &m = c->meshes[c->instances[i].mesh];
+			rtk::launch_stamp_instance(c->d_tri_verts.as<f4>() + 3ull * m.tri_base, (uint32_t)m.triCount, i, c->stream);
+		}
+	RF_TRY(dm::last_launch_error());
 	RF_TRY(c->d_instances.ensure(std::max<size_t>(1, inst.size()) * sizeof(rt::Instance)));
 	RF_TRY(c->d_tlas_prims.ensure(tprims.size() * 4));
 	RF_TRY(dm::h2d(c->d_instances.p, inst.data(), inst.size() * sizeof(rt::Instance), c->stream));
@@ -1417,7 +1455,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	c->instance_count = (uint32_t)live.size();
 	c->tlas_root_entry = live.empty() ? 0u
 						 : tl_inner	   ? rt::make_entry((int)tlas_base, -1, true)
-									   : rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true);
+									   : flat_entry(rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true));
 
 	rt::SceneView &sv = c->sv;
 	sv.nodes4 = c->d_nodes4.as<rt::Node4c>();
@@ -2160,7 +2198,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2240,6 +2278,11 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 			return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "ring must be in [1, %d]", (int)rfwhip_context::MAX_RING);
 		c->ring = n;
 	}
+	else if (k == "flat_instances")
+	{
+		c->flat_instances = atoi(value) != 0;
+		c->scene_dirty = true; // takes effect with the next rfwhip_update()
+	}
 	else if (k == "sample_group")
 	{
 		const int n = atoi(value);
@@ -2302,6 +2345,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->overlap);
 	else if (k == "sample_group")
 		snprintf(value, cap, "%d", c->sample_group);
+	else if (k == "flat_instances")
+		snprintf(value, cap, "%d", c->flat_instances);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;

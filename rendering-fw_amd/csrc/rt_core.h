@@ -675,7 +675,9 @@ struct Traverser
 			if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
 			{
 				hit.prim = (int)fbits(v0.w);
-				hit.inst = cur_inst;
+				// (outside every instance: the triangle belongs to an instance that was linked into the top-level tree directly,
+				// and carries its index — rfwhip_update, "flat" instances)
+				hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);
 				if (ANY)
 				{
 					cur = ENTRY_DONE;

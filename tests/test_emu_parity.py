@@ -376,3 +376,32 @@ def test_sample_groups_of_the_slot_layout(pkg, make_emu, group):
     assert out[0][2] == out[1][2]
     with pytest.raises(RuntimeError):
         c.set_setting("sample_group", 3)
+
+
+@pytest.mark.parametrize("geometric_emitter", [False, True])
+def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geometric_emitter):
+    """An identity-transform instance of a singly used mesh is linked into the top-level tree directly (rfwhip_update, "flat"
+    instances): image, primary hits with their instance ids and wave counts are those of the two-level walk, in a scene that
+    mixes such instances (the room, the emitter quad) with transformed instances of a shared mesh (the boxes); the oracle
+    always walks two levels."""
+    scene = pkg.scenes.cornell(70, 51, geometric_emitter=geometric_emitter)
+    out = []
+    for flat in (1, 0):
+        c = make_emu()
+        c.init(70, 51)
+        c.set_setting("flat_instances", flat)
+        scene.upload(c)
+        for k, v in {"integrator": "pt", "spp": 6, "max_depth": 3}.items():
+            c.set_setting(k, v)
+        c.render_frame(scene.camera, pkg.RESET)
+        st = c.get_stats()
+        out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in ("inst", "prim", "t"):
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
+    assert out[0][2] == out[1][2]
+    assert 0 in set(np.unique(out[0][1]["inst"])) and {1, 2} <= set(np.unique(out[0][1]["inst"]))
+    e, o = make_emu(), make_oracle()
+    _run(pkg, [e, o], pkg.scenes.cornell(96, 64, geometric_emitter=geometric_emitter), 96, 64, {"integrator": "parity", "jitter": "center"})
+    a, b = e.primary_hits(), o.primary_hits()
+    assert (a["inst"] != b["inst"]).sum() == 0 and (a["prim"] != b["prim"]).sum() == 0
