@@ -529,3 +529,39 @@ def test_random_barycentrics_closed_form_on_the_gpu(pkg, make_hip, make_oracle):
     a = make_hip().kat("random_barycentrics", rec)[:, :3]
     b = make_oracle().kat("random_barycentrics", rec)[:, :3]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_name", ["atrium", "terrain"])
+def test_flat_instances_leave_every_result_alone_on_the_gpu(pkg, make_hip, scene_name):
+    """Identity instances linked into the top-level tree directly (rfwhip_update, "flat" instances) against the two-level walk
+    of every instance, on the device: atrium = an identity room beside 45 transformed instances of shared meshes, terrain = the
+    bench scene's two identity instances.  Image, primary hits (instance ids included) and wave sizes are bit-equal; a mesh
+    refit in between (it rewrites the triangle records that carry the instance index) changes nothing either."""
+    w, h = 480, 270
+    scene = pkg.scenes.atrium(w, h) if scene_name == "atrium" else pkg.scenes.terrain(n=200, width=w, height_px=h)
+    out = []
+    for flat in (1, 0):
+        c = make_hip()
+        c.init(w, h)
+        c.set_setting("flat_instances", flat)
+        scene.upload(c)
+        for k, v in {"integrator": "pt", "spp": 8, "max_depth": 3}.items():
+            c.set_setting(k, v)
+        c.render_frame(scene.camera, pkg.RESET)
+        st = c.get_stats()
+        out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
+        if flat:  # same vertices again = a refit of a flat instance's mesh (unchanged counts): the image must not move
+            uses = [sum(1 for i in scene.instances if i["mesh"] == k) for k in range(len(scene.meshes))]
+            mi = next(i["mesh"] for i in scene.instances if uses[i["mesh"]] == 1 and np.array_equal(i["transform"], np.eye(4)))
+            m = scene.meshes[mi]
+            c.set_mesh(mi, m["vertices"], m["triangles"], m["indices"])
+            c.update()
+            c.render_frame(scene.camera, pkg.RESET)
+            assert np.array_equal(c.framebuffer(), out[0][0])
+            assert np.array_equal(c.primary_hits()["inst"], out[0][1]["inst"])
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in ("inst", "prim", "t"):
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
+    assert out[0][2] == out[1][2]
+    insts = set(np.unique(out[0][1]["inst"])) - {-1}
+    assert len(insts) >= 2, insts
