@@ -421,10 +421,14 @@ def main():
                     # share of the chip's f32 lane-slots that did work
                     "valu_issue_frac": round(insts * n / (pm_ms * 1e-3) / VALU_ISSUE_PEAK, 4) if (insts and pm_ms > 0) else None,
                     "valu_lane_weighted_frac": round(insts * n / (pm_ms * 1e-3) / VALU_ISSUE_PEAK * lanes / 64.0, 4) if (insts and lanes and pm_ms > 0) else None,
+                    # the counters' own answer: share of SIMD cycles a VALU instruction was executing (SQ_ACTIVE_INST_VALU in
+                    # quad-cycles over GRBM_GUI_ACTIVE x CUs x SIMDs) and the cycles one wave64 instruction of this mix occupied
+                    "valu_busy_frac": k.get("valu_busy_frac"),
+                    "valu_cycles_per_instruction": k.get("valu_cycles_per_instruction"),
                 })
             else:
                 ent.update({"counter_hbm_bytes_per_sub_batch": None, "valu_wave_insts_per_sub_batch": None, "valu_lanes_active_of_64": None,
-                            "valu_issue_frac": None, "valu_lane_weighted_frac": None})
+                            "valu_issue_frac": None, "valu_lane_weighted_frac": None, "valu_busy_frac": None})
             stages.append(ent)
 
         # traffic of the headline (extend) launch from the same counters: primary + bounce dispatches, per launch
@@ -464,10 +468,10 @@ def main():
                 "l1_lane_load_frac": round(lane_loads / max(1.0, launches_per_step) / ser_s / LANE_LOADS_PEAK, 5) if ser_s > 0 else None,
                 "l1_lane_load_peak_g_per_s": LANE_LOADS_PEAK / 1e9,
                 "sub_batch_ms_total": round(sum(ser.values()), 4),
-                "binding_ceiling": "VALU issue at the lane utilisation in `stages` (divergent traversal); HBM is not: see counter_hbm_frac_of_peak",
+                "binding_ceiling": "VALU: the traversal kernels keep the SIMDs' VALUs busy 0.85-1.0 of the time (`stages[].valu_busy_frac`) at 34-50 of 64 lanes; HBM is not: see counter_hbm_frac_of_peak",
             },
             "valu_issue_peak_g_per_s": VALU_ISSUE_PEAK / 1e9,
-            "valu_issue_peak_note": "guide: wave64 VALU issues over 2 cycles per SIMD-32; compares / selects / conversions measure ~half (profiles/micro/valu_micro.hip)",
+            "valu_issue_peak_note": "guide: wave64 VALU issues over 2 cycles per SIMD-32; the counters put this instruction mix at 4.0 cycles per instruction (`stages[].valu_cycles_per_instruction`; profiles/micro/valu_micro.hip: compares / selects / conversions at ~half the guide's rate), so valu_issue_frac ~ 0.5 is a saturated SIMD: valu_busy_frac is the figure to read",
             "stages": stages,
         }
         if args.stage_rates:

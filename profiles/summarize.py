@@ -107,12 +107,18 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
             e["sq_insts_valu_per_dispatch"] = int(per("SQ_INSTS_VALU"))
         if "SQ_THREAD_CYCLES_VALU" in t and "SQ_ACTIVE_INST_VALU" in t and t["SQ_ACTIVE_INST_VALU"] > 0:
             e["valu_lanes_per_instruction"] = round(t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"], 2)
+        # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs of 32 CUs x 4 SIMDs
+        if "SQ_ACTIVE_INST_VALU" in t and t.get("GRBM_GUI_ACTIVE", 0) > 0:
+            e["valu_busy_frac"] = round(t["SQ_ACTIVE_INST_VALU"] * 4.0 / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), 4)
+            if t.get("SQ_INSTS_VALU", 0) > 0 and disp[k].get("SQ_INSTS_VALU") == disp[k].get("SQ_ACTIVE_INST_VALU"):
+                e["valu_cycles_per_instruction"] = round(4.0 * t["SQ_ACTIVE_INST_VALU"] / t["SQ_INSTS_VALU"], 2)
         if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t and t["SQ_WAVE_CYCLES"] > 0:
             e["wave_cycles_waiting_frac"] = round(t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"], 4)
         out["kernels"][k] = e
     out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                          "--no-roofline` (tools/evidence.sh); per dispatch averages; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
-                         "l2 bytes = TCC_REQ_sum x 128; csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
+                         "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs): the share of "
+                         "SIMD cycles a VALU instruction was executing; csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
     print(json.dumps(out, indent=1))
 
 
