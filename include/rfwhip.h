@@ -230,7 +230,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  images and counters are unchanged); "0": every instance behind a top-level leaf.  Takes effect with
  *                  the next rfwhip_update()
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
- *                  so that up to `ring` consecutive calls are in flight (1..4, default 4)
+ *                  so that up to `ring` consecutive calls are in flight (1..4, default 3: three chains + the main stream
+ *                  are the HIP runtime's four hardware queues; a host that keeps four frames in flight with
+ *                  rfwhip_group_present_async sets 4)
  *   refill       = bit mask, default 7: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,
  *                  bit 2 the pt integrator's primary wave (a lane that finishes its ray pulls the next one from the
  *                  wave's run of the launch's queue; the primary wave generates it)

@@ -875,6 +875,9 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #ifndef RT_STREAM_CHUNK
 #define RT_STREAM_CHUNK 512
 #endif
+#ifndef RT_STREAM_CHUNK_QUEUED // the same for the kernels that read their rays from a queue (extension, shadow)
+#define RT_STREAM_CHUNK_QUEUED RT_STREAM_CHUNK
+#endif
 #ifndef RT_LEAF_VOTE_ANY
 #define RT_LEAF_VOTE_ANY 40
 #endif
@@ -911,7 +914,8 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	uint32_t q_next = 0, q_end = 0; // wave-uniform: the rest of the run this wave owns
 	// run length: RT_STREAM_CHUNK for big launches, down to 64 when the launch has fewer than ~4 runs per wave
 	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
-	run = run > RT_STREAM_CHUNK ? (uint32_t)RT_STREAM_CHUNK : (run < 64u ? 64u : run);
+	constexpr uint32_t RUN_MAX = MODE == STREAM_PRIMARY_PT ? (uint32_t)RT_STREAM_CHUNK : (uint32_t)RT_STREAM_CHUNK_QUEUED;
+	run = run > RUN_MAX ? RUN_MAX : (run < 64u ? 64u : run);
 #endif
 	uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : (MODE == STREAM_EXT ? RT_REFILL_IDLE_EXT : RT_REFILL_IDLE_PRIMARY);
 	// Waves of near-identical rays — the slot layout's sample groups put >= 8 samples of a pixel side by side (rt_core.h), so a
@@ -1307,11 +1311,15 @@ __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4c *nodes4, const uint32
 // Persistent grids: workgroups per CU, upper bound.  Re-swept after the traversal kernels took the persistent-lane form (a
 // CU holds 8 of their workgroups; more only queue up behind them): traversal 8 / 12 / 16 / 24 / 32 / 48 per CU -> 2673 /
 // 2675 / 2659 / 2640 / 2626 / 2615 Msamples/s, shade kernel 8 / 12 / 16 / 24 / 32 / 64 -> 2592 / 2612 / 2633 / 2668 / 2589 / 2584.
+// Round 3: 8 / 8.  A CU holds 8 workgroups of the traversal kernels; a grid of exactly that many leaves the workgroups of the
+// NEXT chain's kernel nothing to queue behind, which is what a strip-split rank's smaller launches need (33 M paths per call,
+// three calls in flight: 12 / 16 -> 8 / 8 per CU = 10.45 -> 9.78 ms per 128-spp step; the single-GPU bench is the same at
+// 6 / 8 / 12 per CU, 4 loses on every traversal kernel).
 #ifndef RT_GRID_BLOCKS_PER_CU
-#define RT_GRID_BLOCKS_PER_CU 12u
+#define RT_GRID_BLOCKS_PER_CU 8u
 #endif
 #ifndef RT_SHADE_BLOCKS_PER_CU
-#define RT_SHADE_BLOCKS_PER_CU 16u
+#define RT_SHADE_BLOCKS_PER_CU 8u
 #endif
 #ifndef RT_GRID_CHUNKS_PER_BLOCK
 #define RT_GRID_CHUNKS_PER_BLOCK 32u // a workgroup should find about this many 256-item chunks to be worth launching

@@ -75,6 +75,8 @@ class Context final : public rfw::RenderContext
 			m_InFlight = std::max(1, std::min(RFWHIP_PRESENT_SLOTS, std::atoi(f)));
 		const char *integ = std::getenv("RFWHIP_INTEGRATOR");
 		HIPRT_CHECK(rfwhip_group_set_setting(m_Group, "integrator", integ ? integ : "pt"));
+		if (m_InFlight >= RFWHIP_PRESENT_SLOTS) // four frames in flight need four sets of wave buffers (the default ring is three)
+			HIPRT_CHECK(rfwhip_group_set_setting(m_Group, "ring", "4"));
 #ifdef RFWHIP_HAVE_BLUE_NOISE_TABLE
 		{
 			// what CUDART does at init (CUDART/src/Context.cpp:43-46): primary rays then use blueNoiseSampler

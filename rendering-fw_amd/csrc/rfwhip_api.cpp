@@ -370,7 +370,9 @@ struct rfwhip_context
 	bool conn_used[MAX_SUB] = {false, false, false, false, false, false, false, false};
 	bool resolve_recorded[MAX_RING] = {false, false, false, false};
 	uint32_t call_slot = 0;	  // which set of the ring the next render call uses
-	int ring = 4;			  // single-sub-batch calls rotate through this many sets of wave buffers / streams / counters
+	int ring = 3;			  // single-sub-batch calls rotate through this many sets of wave buffers / streams / counters
+							  // (3: with the main stream that is four streams = the HIP runtime's four hardware queues; a
+							  // fourth set shares a queue with another chain: 1-spp frames 1.43 vs 1.67 ms)
 	int ring_active = 0;	  // ring size of the calls in flight (2 for calls cut into sub-batches: radiance double-buffered)
 	size_t paths_active = 0;  // path slots per call of the calls in flight
 	int subs_active = 0;	  // ... and their sub-batch count

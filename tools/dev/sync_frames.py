@@ -10,6 +10,8 @@ W, H = 1920, 1080
 scene = pkg.scenes.terrain(n=708, width=W, height_px=H)
 g = pkg.render_group([0], "peer"); g.init(W, H); scene.upload(g)
 g.set_setting("integrator", "pt")
+for kv in sys.argv[1:]:   # e.g. ring=4
+    k, _, v = kv.partition("="); g.set_setting(k, v)
 N = 100
 for spp in (1, 8):
     g.set_setting("spp", spp)

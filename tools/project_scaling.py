@@ -18,6 +18,8 @@ scene = pkg.scenes.terrain(n=708, width=W, height_px=H)
 def run(rank, world, steps=10, warm=3):
     ctx = pkg.RenderContext(0, rank, world); ctx.init(W, H); scene.upload(ctx)
     ctx.set_setting("integrator", "pt"); ctx.set_setting("spp", spp); ctx.set_setting("streams", streams)
+    for kv in os.environ.get("PROJ_SET", "").split():   # e.g. PROJ_SET="ring=4"
+        k, _, v = kv.partition("="); ctx.set_setting(k, v)
     rows = ctx.local_rows()
     local = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0")
     flat = torch.empty((world, rows, W, 4), dtype=torch.float32, device="cuda:0")
