@@ -100,9 +100,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=128,
-                    help="samples per pixel per step (one wavefront batch; config 3: >= 64 spp; 128 keeps the launches of an "
-                         "8-GPU strip split large: path state = 61 GB of the 288 GB per GPU at N = 1)")
+    ap.add_argument("--spp", type=int, default=256,
+                    help="samples per pixel per step (one wavefront batch; config 3: >= 64 spp; 256 = four sub-batches of 64, so a "
+                         "wave is one pixel x 64 samples, and the calls of an 8-GPU strip split stay large: path state = 140 GB of "
+                         "the 288 GB per GPU at N = 1)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=708, help="terrain cells per side (708 -> 1 002 528 triangles)")

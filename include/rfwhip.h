@@ -223,8 +223,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   sub_batch_paths = a render call's spp are cut into concurrent sub-batches only if each gets at least this many path
  *                  slots and there are four of them (default 50000000: 1080p from 128 spp per call)
  *   sample_group = slot layout: up to this many samples of a pixel sit side by side in one wave (power of two <= 64,
- *                  default 32; the largest such group that divides every sub-batch of a call is used; 1 = a wave is one
- *                  8x8 tile of one sample).  Changes which path sits where, never the image
+ *                  default 64 = a wave is one pixel; the largest such group that divides every sub-batch of a call is
+ *                  used: 32 for a 128-spp call cut into four sub-batches; 1 = a wave is one 8x8 tile of one sample).
+ *                  Changes which path sits where, never the image
  *   flat_instances = "1" (default): an instance with the identity transform whose mesh no other instance uses is linked
  *                  into the top-level tree directly (rays reach its triangles without an instance switch; hit records,
  *                  images and counters are unchanged); "0": every instance behind a top-level leaf.  Takes effect with

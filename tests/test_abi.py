@@ -91,5 +91,5 @@ def test_bench_counters_are_tied_to_the_sources_they_were_taken_on(tmp_path):
     # the committed file belongs to the committed sources
     import os
     committed = os.path.join(os.path.dirname(bench.__file__), "profiles", "stage_counters.json")
-    pm, fresh = bench.load_stage_counters(committed, "terrain_1002k", 128, 4)
+    pm, fresh = bench.load_stage_counters(committed, "terrain_1002k", 256, 4)
     assert pm is not None and fresh, "profiles/stage_counters.json is stale: re-run tools/evidence.sh after changing csrc/"

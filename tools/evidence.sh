@@ -24,9 +24,9 @@ t=$(pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum | tail -1)
 p=$(pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum | tail -1)
 q=$(pass sq_issue SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY | tail -1)
 l=$(pass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE | tail -1)
-(cd $R && python profiles/summarize.py traffic 128 4 terrain_1002k "$tag" $f $w $t $p $q $l > gpurun_out/${tag}_traffic_extend.json; cp gpurun_out/${tag}_traffic_extend.json profiles/traffic_extend.json)
+(cd $R && python profiles/summarize.py traffic 256 4 terrain_1002k "$tag" $f $w $t $p $q $l > gpurun_out/${tag}_traffic_extend.json; cp gpurun_out/${tag}_traffic_extend.json profiles/traffic_extend.json)
 h=$(cd $R && python -c "import bench; print(bench.csrc_hash())")
-(cd $R && python profiles/summarize.py stages 128 4 terrain_1002k "$tag" $h $f $w $t $q $l > gpurun_out/${tag}_stage_counters.json; cat gpurun_out/${tag}_stage_counters.json; cp gpurun_out/${tag}_stage_counters.json profiles/stage_counters.json)
+(cd $R && python profiles/summarize.py stages 256 4 terrain_1002k "$tag" $h $f $w $t $q $l > gpurun_out/${tag}_stage_counters.json; cat gpurun_out/${tag}_stage_counters.json; cp gpurun_out/${tag}_stage_counters.json profiles/stage_counters.json)
 cd $R && timeout 900 python bench.py --stage-rates > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 1500 gpurun_out/${tag}_bench.json
 d=$R/gpurun_out/${tag}_stats; rm -rf $d
