@@ -294,8 +294,13 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	bool write_rad = false;
 	// the primary wave has one entry per path slot, including the padding slots of partial tiles / strips whose
 	// records were never written: validity comes from the slot index, not from the buffers
+	PixelRef pr;
+	pr.x = 0, pr.y = 0, pr.local = 0, pr.sample = 0, pr.valid = false;
 	if (p.depth == 0 && active)
-		active = slot_to_pixel(p.fr, i).valid;
+	{
+		pr = slot_to_pixel(p.fr, i); // (the primary wave's entry i IS path slot i: no second mapping below)
+		active = pr.valid;
+	}
 	if (active)
 	{
 		const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
@@ -313,7 +318,8 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 			const f4 t4 = p.wv.thr[b][i];
 			in.T = xyz(t4), in.bsdfPdf = t4.w;
 		}
-		const PixelRef pr = slot_to_pixel(p.fr, in.slot);
+		if (p.depth != 0)
+			pr = slot_to_pixel(p.fr, in.slot);
 		{
 			in.pixel = pr.y * p.fr.W + pr.x;
 			in.px = pr.x, in.py = pr.y;
@@ -469,6 +475,10 @@ RT_FN void kat_item(const Params &p, int function, const float *in, float *out, 
 	case 10: // half -> float (material colours, uv scales): eight bit patterns per record
 		for (int k = 0; k < KAT_OUT; k++)
 			o[k] = half_to_float((uint16_t)fbits(r[k]));
+		break;
+	case 11: // fast_div (rt_types.h): four (n, d) pairs of 31-bit integers per record -> n / d
+		for (int k = 0; k < 4; k++)
+			o[k] = ubits(fast_div(fbits(r[2 * k]), make_fastdiv(fbits(r[2 * k + 1]))));
 		break;
 	default:
 		break;

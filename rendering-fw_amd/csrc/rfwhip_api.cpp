@@ -532,6 +532,11 @@ static uint32_t total_light_count(const rfwhip_context *c)
 	return c->lc.areaLightCount + c->lc.pointLightCount + c->lc.spotLightCount + c->lc.directionalLightCount;
 }
 
+static void set_sample_group(rt::FrameView &fr, uint32_t sgroup_log2)
+{
+	fr.sgroup_log2 = sgroup_log2;
+	fr.div_group = rt::make_fastdiv((uint32_t)std::min<unsigned long long>((unsigned long long)fr.slots << sgroup_log2, 0x7FFFFFFFull));
+}
 static uint32_t local_rows_of(const rfwhip_context *c)
 {
 	const uint32_t strips = (c->H + rt::STRIP_ROWS - 1) / rt::STRIP_ROWS;
@@ -668,7 +673,9 @@ extern "C" int rfwhip_init(rfwhip_context *c, uint32_t width, uint32_t height)
 	c->samples_done = 0;
 	c->fr.W = width, c->fr.H = height, c->fr.local_rows = lr;
 	c->fr.tiles_x = (width + rt::TILE - 1) / rt::TILE;
+	c->fr.div_tiles_x = rt::make_fastdiv(c->fr.tiles_x);
 	c->fr.slots = c->fr.tiles_x * rt::TILE * lr;
+	set_sample_group(c->fr, 0);
 	c->fr.rank = (uint32_t)c->rank, c->fr.world = (uint32_t)c->world;
 	return RFWHIP_OK;
 }
@@ -1838,7 +1845,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1 && !pipelined));
 	rtk::Params base;
 	fill_params(c, cam, base);
-	base.fr.sgroup_log2 = sgroup_log2;
+	set_sample_group(base.fr, sgroup_log2);
 	c->sgroup_last = sgroup_log2;
 	base.wv.rad = alternate ? c->d_rad[0].as<f4>() + paths * par : c->d_rad[par].as<f4>();
 	// the connections always add into their own buffer, on a side stream or not: the image is then bit-identical whichever way
@@ -2427,7 +2434,7 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 	RF_TRY(sync_all(c));
 	// the first sample of the most recent call's first sub-batch lives in that sub-batch's first sample group
 	rt::FrameView fr = c->fr;
-	fr.sgroup_log2 = c->sgroup_last;
+	set_sample_group(fr, c->sgroup_last);
 	const size_t slots = (size_t)c->fr.slots << fr.sgroup_log2;
 	std::vector<f4> h(slots);
 	std::vector<int> hi(slots);
@@ -2542,7 +2549,7 @@ extern "C" int rfwhip_kat(rfwhip_context *c, int function, size_t n, const float
 	CTX_ENTER(c);
 	if (n && (!in || !out))
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: null records");
-	if (function < 0 || function > RFWHIP_KAT_HALF_TO_FLOAT)
+	if (function < 0 || function > RFWHIP_KAT_FASTDIV)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: unknown function %d", function);
 	if ((function == RFWHIP_KAT_POINT_ON_LIGHT || function == RFWHIP_KAT_LIGHT_PICK_PROB) && c->scene_dirty)
 		return set_error(RFWHIP_ERR_STATE, "rfwhip_kat: the light functions use the lights of the last rfwhip_update()");

@@ -171,11 +171,11 @@ RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
 	PixelRef p;
 	const uint32_t gl = fr.sgroup_log2;
 	const uint32_t per_group = fr.slots << gl;
-	const uint32_t sgroup = slot / per_group;
+	const uint32_t sgroup = fast_div(slot, fr.div_group); // (slots are < 2^31: rt_types.h)
 	const uint32_t rem = slot - sgroup * per_group;
 	const uint32_t tile = rem >> (6u + gl), pix = (rem >> gl) & 63u;
 	p.sample = (sgroup << gl) + (rem & ((1u << gl) - 1u));
-	const uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+	const uint32_t ty = fast_div(tile, fr.div_tiles_x), tx = tile - ty * fr.tiles_x;
 	p.x = tx * TILE + (pix & 7u);
 	const uint32_t yl = ty * TILE + (pix >> 3);
 	p.y = local_to_global_row(fr, yl);

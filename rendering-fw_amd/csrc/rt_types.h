@@ -283,6 +283,35 @@ struct CamView
 };
 constexpr uint32_t BLUE_NOISE_WORDS = 5u * 65536u;
 
+// Division of a 31-bit index by a per-frame constant without the ~30-instruction udiv sequence (every path maps its slot to a
+// pixel in the primary and in every shade kernel): Granlund-Montgomery, m = ceil(2^(31 + L) / d) with L = ceil(log2 d) fits 32
+// bits and floor(n * m / 2^(31 + L)) == n / d for every n < 2^31 (RFWHIP_KAT_FASTDIV checks it on both builds).
+struct FastDiv
+{
+	uint32_t m, s; // m == 0: the divisor is 1
+};
+RT_FN FastDiv make_fastdiv(uint32_t d)
+{
+	FastDiv f;
+	f.m = 0, f.s = 0;
+	if (d <= 1u)
+		return f;
+	uint32_t L = 0;
+	while (L < 32u && (1ull << L) < (unsigned long long)d)
+		L++;
+	f.m = (uint32_t)(((1ull << (31u + L)) + d - 1u) / d);
+	f.s = L - 1u;
+	return f;
+}
+RT_FN uint32_t fast_div(uint32_t n, const FastDiv f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return f.m ? __umulhi(n, f.m) >> f.s : n;
+#else
+	return f.m ? (uint32_t)(((unsigned long long)n * f.m) >> 32) >> f.s : n;
+#endif
+}
+
 // Which image rows this rank owns, and how path slots map to pixels.
 struct FrameView
 {
@@ -295,6 +324,8 @@ struct FrameView
 	uint32_t sample_base;  // index of the first sample of the batch
 	uint32_t probe_pixel;  // y*W + x
 	uint32_t sgroup_log2;  // log2 of the sample group g (rt_core.h: slot layout): a wave's 64 slots = 64/g pixels x g samples
+	FastDiv div_tiles_x;   // n / tiles_x
+	FastDiv div_group;	   // n / (slots << sgroup_log2): which sample group a slot belongs to
 };
 
 // Slot layout (rt_core.h, "pixel <-> path-slot mapping"): slot of sample s (within the batch) of pixel `pix` (0..63, row-major) of tile `tile`
