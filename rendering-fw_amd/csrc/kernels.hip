@@ -913,7 +913,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
 	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
 	Traverser<ANY, COUNT> T;
-	T.cur = ENTRY_DONE;
+	T.cur = ENTRY_DONE, T.held = ENTRY_DONE;
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
 	uint32_t nrays = 0;

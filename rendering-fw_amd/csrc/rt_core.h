@@ -409,6 +409,13 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 //
 // The traversal is a resumable per-lane state machine (begin / descend / visit) so that the persistent kernels can
 // hand a finished lane a new ray while its neighbours are still busy; trace() below runs it to completion.
+// RT_SPECULATE = 1: speculative traversal — a lane takes its first triangle leaf in hand and walks on (Traverser::descend).
+// Bit-identical hit records, and measured on the MI355X as a loss: the leaf vote already keeps the waiting short, and the
+// nodes a held leaf's hit would have culled are extra instructions in kernels that are VALU-bound (primary wave 7.32 -> 8.25 ms,
+// bounce wave 6.97 -> 7.28 ms per 64-spp sub-batch, bench 3812 -> 3672 Msamples/s).  Off.
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 0
+#endif
 template <bool ANY, bool COUNT>
 struct Traverser
 {
@@ -418,6 +425,7 @@ struct Traverser
 	int cur_inst;
 	int sp;
 	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
+	uint32_t held; // RT_SPECULATE: a triangle leaf taken in hand while the lane walks on (ENTRY_DONE: none)
 	float t_min;
 	Hit hit;
 
@@ -436,7 +444,7 @@ struct Traverser
 	{
 		O = O_, D = D_, t_min = t_min_;
 		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
-		cur_inst = -1, sp = 0;
+		cur_inst = -1, sp = 0, held = ENTRY_DONE;
 		enter_space(O, D);
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
 	}
@@ -451,7 +459,11 @@ struct Traverser
 						in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
 						in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z));
 	}
-	RT_FN bool done() const { return cur == ENTRY_DONE; }
+	RT_FN bool done() const { return cur == ENTRY_DONE && (!RT_SPECULATE || held == ENTRY_DONE); }
+	// a triangle leaf (not a top-level leaf, the sentinel or ENTRY_DONE, which all carry the ENTRY_TLAS bit)
+	static RT_FN bool tri_leaf(uint32_t e) { return (e & (ENTRY_LEAF | ENTRY_TLAS)) == ENTRY_LEAF; }
+	// has this lane nothing left to do in the node phase?
+	RT_FN bool parked() const { return (cur & ENTRY_LEAF) && !(RT_SPECULATE && held == ENTRY_DONE && tri_leaf(cur)); }
 
 	static constexpr int LDS_DEPTH = ANY ? LDS_STACK_ANY : LDS_STACK;
 	RT_FN void push(const TravStack stk, uint32_t e)
@@ -606,13 +618,22 @@ struct Traverser
 #ifndef RT_VOTE_RELATIVE
 #define RT_VOTE_RELATIVE 1
 #endif
+	// RT_SPECULATE (Aila & Laine's speculative traversal): a lane that reaches a triangle leaf takes it in hand (`held`) and walks
+	// on from its stack instead of idling until the wave's leaf phase; it parks only with a SECOND leaf (or an instance entry, the
+	// sentinel, an empty stack).  The leaves of a ray are still tested in the same order — visit() tests `held` before anything
+	// else — so every hit record is unchanged; what changes is that some nodes are visited which the held leaf's hit would have
+	// culled (counters), and that the node phase runs with more of its lanes.
 	template <int VOTE = 64> RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
-		const int nwork = VOTE < 64 ? __popcll(__ballot(cur != ENTRY_DONE)) : 0;
+		const int nwork = VOTE < 64 ? __popcll(__ballot(!done())) : 0;
 #endif
-		while (!(cur & ENTRY_LEAF))
+		for (;;)
 		{
+			if (RT_SPECULATE && held == ENTRY_DONE && tri_leaf(cur))
+				held = cur, cur = pop(stk);
+			if (cur & ENTRY_LEAF)
+				break;
 			float t0, t1, t2, t3;
 			uint32_t e0, e1, e2, e3;
 			node_step(sc, stk, st, cur, t0, t1, t2, t3, e0, e1, e2, e3);
@@ -622,7 +643,7 @@ struct Traverser
 			{
 				// only the lanes still inside this loop execute the ballot: the lanes with work that are NOT counted here
 				// are the ones already waiting with a leaf (or with a finished ray to retire)
-				const int inner = __popcll(__ballot(!(cur & ENTRY_LEAF)));
+				const int inner = __popcll(__ballot(!parked()));
 #if RT_VOTE_RELATIVE
 				if ((nwork - inner) * 64 >= nwork * VOTE) // VOTE / 64 of the lanes that HAVE a ray (idle lanes do not count)
 					break;
@@ -638,9 +659,13 @@ struct Traverser
 	// phase 2: the leaf in hand — enter an instance (top-level leaf) or test the triangles, then fetch the next entry
 	RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st)
 	{
-		if (cur == ENTRY_DONE || !(cur & ENTRY_LEAF)) // (an inner node in hand: the wave left descend<VOTE>() early)
+		uint32_t leaf = cur;
+		const bool from_held = RT_SPECULATE && held != ENTRY_DONE;
+		if (from_held)
+			leaf = held, held = ENTRY_DONE; // the leaf in hand comes first; whatever `cur` is waits for the next phase
+		else if (cur == ENTRY_DONE || !(cur & ENTRY_LEAF)) // (an inner node in hand: the wave left descend<VOTE>() early)
 			return;
-		if (cur == ENTRY_SENTINEL)
+		else if (cur == ENTRY_SENTINEL)
 		{
 			// leaving an instance: back to the world-space ray
 			enter_space(O, D);
@@ -648,7 +673,7 @@ struct Traverser
 			cur = pop(stk);
 			return;
 		}
-		if (cur & ENTRY_TLAS)
+		else if (cur & ENTRY_TLAS)
 		{
 			// top-level leaf: exactly one instance (the TLAS builder never merges)
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
@@ -659,8 +684,8 @@ struct Traverser
 			cur = in.root_entry;
 			return;
 		}
-		const uint32_t first = cur & ENTRY_FIRST_MASK;
-		const uint32_t count = ((cur >> 27) & 7u) + 1u;
+		const uint32_t first = leaf & ENTRY_FIRST_MASK;
+		const uint32_t count = ((leaf >> 27) & 7u) + 1u;
 		for (uint32_t i = 0; i < count; i++)
 		{
 			const f4 *tv = sc.tri_verts + 3u * (first + i);
@@ -685,7 +710,8 @@ struct Traverser
 				}
 			}
 		}
-		cur = pop(stk);
+		if (!from_held)
+			cur = pop(stk);
 	}
 };
 

@@ -16,7 +16,13 @@ OUT_DIR = os.path.join(ROOT, "tests", "_emu")
 OUT = os.path.join(OUT_DIR, "librfwhip_emu.so")
 
 
-def build(force=False):
+def build(force=False, defines=(), tag=""):
+    """defines / tag: a variant of the library built with other compile-time constants (e.g. ("-DRT_SPECULATE=1",), "_spec")."""
+    out = OUT if not tag else os.path.join(OUT_DIR, "librfwhip_emu%s.so" % tag)
+    return _build(force, list(defines), out)
+
+
+def _build(force, defines, OUT):
     srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "rfwhip_group.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
@@ -24,7 +30,7 @@ def build(force=False):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DRFWHIP_HOST_EMULATION", "-fvisibility=hidden",
-           "-mavx2", "-mfma", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+           "-mavx2", "-mfma", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + defines
     for s in srcs:
         cmd += ["-x", "c++", s]
     cmd += ["-o", OUT, "-lpthread"]
