@@ -430,3 +430,41 @@ def test_speculative_traversal_changes_no_hit_record(pkg, emu_lib):
         for k in ("inst", "prim", "t"):
             assert np.array_equal(out[0][1][k], out[1][1][k]), k
         assert out[0][2] == out[1][2]
+
+
+def _no_survivor_scene(pkg, w, h):
+    """Cornell with every reflecting material given a negative red channel: each first vertex still connects to a light
+    (Kernels.cu:702-755 has no sign test) but its throughput goes negative and the path ends (Kernels.cu:786) — depth 1 has no
+    extension ray, so the reference's host loop traces NO connection of depth 0 (CUDART/src/Context.cpp:109-120)."""
+    s = pkg.scenes.cornell(w, h, geometric_emitter=True)
+    for m in s.host_materials:
+        if max(m["color"]) <= 1.0:
+            m["color"] = (-5.0, 0.3, 0.3)
+    return s
+
+
+def _gated_depth0_connections(pkg, make_ctx, make_oracle, w, h):
+    normal, dead = pkg.scenes.cornell(w, h, geometric_emitter=True), _no_survivor_scene(pkg, w, h)
+    settings = {"integrator": "pt", "spp": 4, "max_depth": 2}
+    used = make_ctx()
+    used.init(w, h)
+    normal.upload(used)
+    for k, v in settings.items():
+        used.set_setting(k, v)
+    for k in range(5):   # every buffer set of the ring has held real connection terms
+        used.render_frame(normal.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+    assert used.get_stats().shadowCount > 0
+    dead.upload(used)
+    used.render_frame(dead.camera, pkg.RESET)
+    st = used.get_stats()
+    assert st.primaryCount == w * h * 4 and st.secondaryCount == 0 and st.shadowCount == 0, (st.secondaryCount, st.shadowCount)
+    fresh, ref = make_ctx(), make_oracle()
+    img = _run(pkg, [fresh, ref], dead, w, h, settings)
+    # the depth-0 connection wave is skipped, and the slots the shade kernel left for it to initialise start at zero all the same
+    assert np.array_equal(used.framebuffer(), img[0])
+    frac, rmse, _ = image_stats(img[0], img[1], 1e-3)
+    assert frac <= 2e-3, (frac, rmse)
+
+
+def test_skipped_depth0_connections_leave_no_stale_terms(pkg, make_emu, make_oracle):
+    _gated_depth0_connections(pkg, make_emu, make_oracle, 48, 32)

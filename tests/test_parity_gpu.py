@@ -565,3 +565,11 @@ def test_flat_instances_leave_every_result_alone_on_the_gpu(pkg, make_hip, scene
     assert out[0][2] == out[1][2]
     insts = set(np.unique(out[0][1]["inst"])) - {-1}
     assert len(insts) >= 2, insts
+
+
+def test_skipped_depth0_connections_leave_no_stale_terms_on_the_gpu(pkg, make_hip, make_oracle):
+    """The depth-0 connection wave stores the first term of a slot's connection sum and the shade kernel zeroes only the slots
+    that emit no shadow ray; when the reference's rule skips that wave (no path reaches depth 1), the device kernels still zero
+    the slots left to it — at a size where the persistent-lane kernels run (test_emu_parity.py has the scene)."""
+    from test_emu_parity import _gated_depth0_connections
+    _gated_depth0_connections(pkg, make_hip, make_oracle, 480, 272)
