@@ -70,6 +70,12 @@ void launch_stamp_instance(rt::f4 *tri_verts, uint32_t tri_count, uint32_t insta
 // after a refit of the BVH2 boxes: re-quantise the child boxes of the compressed 4-wide nodes of the same BLAS; src4 = four
 // BLAS-relative BVH2 node indices per 4-wide node (Node4::src of the host's collapse)
 void launch_refresh4(rt::Node4c *nodes4, const uint32_t *src4, uint32_t count4, const rt::Node *blas_nodes2, stream_t s);
+// traversal-stack entries the packet form of the primary wave holds: the 64 lanes of one VGPR minus the sentinel at the
+// bottom and two slots of slack above the top (its three-entry push writes unconditionally); the host uses the per-lane
+// kernels for a scene whose trees could need more
+constexpr uint32_t PACKET_STACK = 61;
+// every compressed node once more with float planes (rt::Node4f), for the packet traversal's scalar fetches
+void launch_expand4(const rt::Node4c *nodes4, rt::Node4f *out, uint32_t count4, stream_t s);
 // BVH construction on the device (lbvh.hip), end to end in mesh-local arrays (node_base = tri_base = n4_base = 0):
 //   nodes / parents / flags   2 n entries   BVH2 in the reference's layout, device entries, one triangle per leaf
 //   nodes4 / src4             <= n / 4 n    the compressed 4-wide nodes the rays fetch, breadth-first, + their BVH2 sources

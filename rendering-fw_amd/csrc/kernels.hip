@@ -730,6 +730,29 @@ RT_FN void refresh4_item(Node4c *nodes4, const uint32_t *src4, const Node *nodes
 	pack_boxes4c(nodes4[i], lo, hi, valid);
 }
 
+// The float form of one compressed node (rt_types.h: Node4f): exactly the planes the per-lane traversal decodes,
+// plane = q * scale + org, for the packet traversal's scalar fetches.  Runs over the whole table at the end of rfwhip_update.
+RT_FN void expand4_item(const Node4c *nodes4, Node4f *out, uint32_t i)
+{
+	const Node4c n = nodes4[i];
+	const float scale[3] = {n.scale_x, n.scale_y, n.scale_z};
+	Node4f f;
+	for (int k = 0; k < 4; k++)
+	{
+		bool empty = n.entry[k] == ENTRY_EMPTY;
+		for (int a = 0; a < 3; a++)
+			empty = empty || ((n.qlo[a] >> (8 * k)) & 255u) > ((n.qhi[a] >> (8 * k)) & 255u);
+		for (int a = 0; a < 3; a++)
+		{
+			const float ql = (float)((n.qlo[a] >> (8 * k)) & 255u), qh = (float)((n.qhi[a] >> (8 * k)) & 255u);
+			f.lo[a][k] = empty ? 1e30f : fmaf(ql, scale[a], n.org[a]);
+			f.hi[a][k] = empty ? -1e30f : fmaf(qh, scale[a], n.org[a]);
+		}
+		f.entry[k] = n.entry[k], f.pad[k] = 0u;
+	}
+	out[i] = f;
+}
+
 // refit, pass 1: rewrite the leaf-ordered triangle vertices from the new mesh vertices
 RT_FN void refit_tris_item(f4 *tri_verts, const f4 *verts, const uint32_t *indices, uint32_t slot)
 {
@@ -1095,6 +1118,348 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primar
 	clock_out(p.wv.counters, 0);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Wave-uniform ("packet") closest-hit traversal for waves of near-identical rays: the pt primary wave, where the slot
+// layout's sample groups make a wave the g samples of 64 / g neighbouring pixels (g = 64: ONE pixel; g = 1: one 8x8 tile).
+// Such a wave walks the same nodes anyway, so it walks them ONCE: one node index for the wave, the node's float planes
+// (rt::Node4f) and a leaf's triangles fetched through SCALAR loads into SGPRs, one stack for the wave (a VGPR used as a
+// 64-entry array: v_writelane / v_readlane), the children ordered on the scalar unit by the entry distance of the first lane
+// that hits each.  What stays per lane is the arithmetic that differs per lane: six fmas + max3 / min3 + one compare per
+// child, and the triangle test.  Against the per-lane form (Traverser::node_step: 24 byte -> float conversions, the frame of
+// the node, 6 selects for the direction signs, a 5-comparator sort of (distance, entry) pairs, LDS pushes and pops: ~117 VALU
+// instructions per node step in a kernel that is bound by VALU issue) a node step is ~50 VALU instructions, with about as
+// many scalar ones beside them; the wave pays for every node ANY of its lanes visits, which for the rays of one pixel is
+// hardly more than one ray's.
+// Every ray still gets exactly its closest hit: a lane tests every triangle of every leaf the wave reaches with the same
+// tri_test() on its own ray — a superset of the leaves its own traversal would reach — and culls with its own hit distance.
+// (Which of two triangles hit at bit-identical distance is reported can depend on the order leaves are reached in, as it
+// does between any two traversal orders.)  Direction signs pick the near / far plane rows per wave (row offsets, no selects);
+// a wave whose lanes disagree about a sign on some axis takes min / max per plane pair instead (MIXED).  Instances: the
+// transform is wave-uniform, every lane transforms its ray; the sentinel restores the world-space ray.
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef RT_PACKET_FULL_SORT
+#define RT_PACKET_FULL_SORT 0 // 0: the nearest entered child first, the others in no particular order (3 of the 5 comparators)
+#endif
+#define RT_CONST_AS __attribute__((address_space(4)))
+typedef float pk_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t pk_v4u __attribute__((ext_vector_type(4)));
+// a 16-byte load whose address is wave-uniform: from the constant address space the compiler selects s_load_dwordx4
+__device__ __forceinline__ pk_v4f sload4(const void *base, uint32_t off)
+{
+	return *(const RT_CONST_AS pk_v4f *)((const char *)base + off);
+}
+__device__ __forceinline__ pk_v4u sload4u(const void *base, uint32_t off)
+{
+	return *(const RT_CONST_AS pk_v4u *)((const char *)base + off);
+}
+__device__ __forceinline__ uint32_t sload1u(const void *base, uint32_t off)
+{
+	return *(const RT_CONST_AS uint32_t *)((const char *)base + off);
+}
+
+// v_writelane_b32 (this clang has no __builtin for it; the intrinsic is reached by its name)
+extern "C" __device__ int rt_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// 1 when k is not all ones, else 0 — on the scalar unit (written as a compare, the compiler keeps the wave-uniform bool in a lane
+// mask and adds it up on the VALU)
+__device__ __forceinline__ uint32_t packet_flag(uint32_t k)
+{
+	uint32_t r;
+	asm("s_cmp_lg_u32 %1, -1\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(k) : "scc");
+	return r;
+}
+// The six plane rows of a float node and its entries: seven scalar loads with the node's byte offset as the SGPR offset of
+// wave-constant row pointers (no address arithmetic; the compiler adds base and offset as 64-bit integers first).  The wait is
+// part of the block — the compiler does not track loads it did not issue.
+struct PacketRows
+{
+	pk_v4f nx, ny, nz, fx, fy, fz;
+	pk_v4u ent;
+};
+__device__ __forceinline__ void packet_load_rows(PacketRows &r, const char *const rn[3], const char *const rf[3], const char *nodes, uint32_t nb)
+{
+	asm volatile("s_load_dwordx4 %0, %7, %14\n\t"
+				 "s_load_dwordx4 %1, %8, %14\n\t"
+				 "s_load_dwordx4 %2, %9, %14\n\t"
+				 "s_load_dwordx4 %3, %10, %14\n\t"
+				 "s_load_dwordx4 %4, %11, %14\n\t"
+				 "s_load_dwordx4 %5, %12, %14\n\t"
+				 "s_load_dwordx4 %6, %13, %14 offset:0x60\n\t"
+				 "s_waitcnt lgkmcnt(0)"
+				 : "=&s"(r.nx), "=&s"(r.ny), "=&s"(r.nz), "=&s"(r.fx), "=&s"(r.fy), "=&s"(r.fz), "=&s"(r.ent)
+				 : "s"(rn[0]), "s"(rn[1]), "s"(rn[2]), "s"(rf[0]), "s"(rf[1]), "s"(rf[2]), "s"(nodes), "s"(nb)
+				 : "memory");
+}
+
+struct PacketStack
+{
+	// ONE stack for the wave: entry j lives in lane j of a VGPR.  Lane 0 holds ENTRY_DONE for good, so a pop never has to ask
+	// whether the stack is empty; 63 entries above it (rfwhip_update computes every tree's worst-case need and the host launches
+	// the packet kernel only for scenes within PACKET_STACK).  All arithmetic on sp is integer min / max / add: a wave-uniform
+	// bool would live in a lane mask and drag the selects onto the VALU.
+	int s0;
+	uint32_t sp; // wave-uniform: number of entries including the sentinel
+	__device__ __forceinline__ PacketStack() : s0((int)ENTRY_DONE), sp(1u) {}
+	__device__ __forceinline__ void push(uint32_t e)
+	{
+		s0 = rt_writelane((int)e, (int)sp, s0);
+		sp++;
+	}
+	__device__ __forceinline__ uint32_t pop()
+	{
+		sp--;
+		return (uint32_t)__builtin_amdgcn_readlane(s0, (int)sp);
+	}
+	// up to three entries, each only if its count is 1: the three writes are unconditional (an unwanted entry lands on the
+	// slot the next wanted one overwrites, or above the new top)
+	__device__ __forceinline__ void push3(uint32_t ea, uint32_t na, uint32_t eb, uint32_t nb, uint32_t ec, uint32_t nc)
+	{
+		s0 = rt_writelane((int)ea, (int)sp, s0);
+		s0 = rt_writelane((int)eb, (int)(sp + na), s0);
+		s0 = rt_writelane((int)ec, (int)(sp + na + nb), s0);
+		sp += na + nb + nc;
+	}
+};
+
+struct PacketSpace
+{
+	f3 o, d, id, noid;	  // the lane's ray in the current space, 1/d, -o/d
+	const char *row_n[3]; // wave-uniform: the node table offset to the near / far plane row of a Node4f per axis — a row is
+	const char *row_f[3]; // fetched as s_load_dwordx4 dst, row, node_byte_offset with no address arithmetic
+	bool mixed;			  // the lanes disagree about a direction sign on some axis
+	__device__ __forceinline__ void enter(f3 o_, f3 d_, unsigned long long act, const char *nodes)
+	{
+		o = o_, d = d_;
+		id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+		noid = mk3(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
+		const unsigned long long mx = __ballot(id.x < 0.0f) & act, my = __ballot(id.y < 0.0f) & act, mz = __ballot(id.z < 0.0f) & act;
+		mixed = (mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act);
+		row_n[0] = nodes + (mx ? 48u : 0u), row_f[0] = nodes + (mx ? 0u : 48u);
+		row_n[1] = nodes + (my ? 64u : 16u), row_f[1] = nodes + (my ? 16u : 64u);
+		row_n[2] = nodes + (mz ? 80u : 32u), row_f[2] = nodes + (mz ? 32u : 80u);
+	}
+};
+
+// sort key of a child on the scalar unit: the entry distance of the wave's reference lane (bits of a float >= 0: they order
+// like unsigned integers); a child no lane enters sorts last
+__device__ __forceinline__ uint32_t packet_key(float tk_lane, unsigned long long m, int ref_lane)
+{
+	const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)fbits(tk_lane), ref_lane);
+	return m ? bits : 0xFFFFFFFFu;
+}
+
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_packet(const SceneView &sc, const bool active, const f3 O, const f3 D, const float t_min, Hit &hit, TStat &st)
+{
+	const unsigned long long act = __ballot(active);
+	// a lane without a ray never enters a box (tmin < hit.t fails) and never takes a hit (t > tt fails)
+	hit.t = active ? hit.t : -3.0e38f;
+	if (act == 0ull)
+		return;
+	const int ref_lane = __ffsll((long long)act) - 1;
+	PacketSpace sp;
+	const char *const nodes = (const char *)sc.nodes4f; // (the table stays below 4 GiB: 32-bit byte offsets)
+	sp.enter(O, D, act, nodes);
+	PacketStack stk;
+	int cur_inst = -1;
+	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	for (;;)
+	{
+		while (!(cur & ENTRY_LEAF))
+		{
+			const uint32_t nb = (cur & ENTRY_INDEX_MASK) << 7;
+			float tk[4];
+			pk_v4u ent;
+			unsigned long long m[4];
+			// per child: tmin = max3 of the near-plane distances, clamped at 0; tmax = min3 of the far-plane distances, capped by the
+			// lane's hit distance; the lane enters the child when tmin < tmax.  (Traverser::node_step accepts tmax > tmin && tmin <
+			// hit.t && tmax >= 0; a box whose far side passes through the origin exactly, tmax == 0, holds nothing beyond t_min.)
+			if (!sp.mixed)
+			{
+				PacketRows r;
+				packet_load_rows(r, sp.row_n, sp.row_f, nodes, nb);
+				ent = r.ent;
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+				{
+					const float tmin = fmaxf(fmaxf(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y)), fmaf(r.nz[k], sp.id.z, sp.noid.z));
+					const float tmax = fminf(fminf(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y)), fmaf(r.fz[k], sp.id.z, sp.noid.z));
+					tk[k] = fmaxf(tmin, 0.0f);
+					m[k] = __ballot(tk[k] < fminf(tmax, hit.t));
+				}
+			}
+			else
+			{
+				ent = sload4u(nodes, nb + 96u);
+				const pk_v4f lx = sload4(nodes, nb), ly = sload4(nodes, nb + 16u), lz = sload4(nodes, nb + 32u);
+				const pk_v4f hx = sload4(nodes, nb + 48u), hy = sload4(nodes, nb + 64u), hz = sload4(nodes, nb + 80u);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+				{
+					const float ax = fmaf(lx[k], sp.id.x, sp.noid.x), bx = fmaf(hx[k], sp.id.x, sp.noid.x);
+					const float ay = fmaf(ly[k], sp.id.y, sp.noid.y), by = fmaf(hy[k], sp.id.y, sp.noid.y);
+					const float az = fmaf(lz[k], sp.id.z, sp.noid.z), bz = fmaf(hz[k], sp.id.z, sp.noid.z);
+					const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+					const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+					tk[k] = fmaxf(tmin, 0.0f);
+					m[k] = __ballot(tk[k] < fminf(tmax, hit.t));
+				}
+			}
+			if (COUNT)
+				st.inner += active ? 1u : 0u;
+			// the nearest child some lane enters comes next, the other entered children go on the stack (scalar unit)
+			uint32_t k0 = packet_key(tk[0], m[0], ref_lane), k1 = packet_key(tk[1], m[1], ref_lane);
+			uint32_t k2 = packet_key(tk[2], m[2], ref_lane), k3 = packet_key(tk[3], m[3], ref_lane);
+			uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3];
+#define RT_PSWAP(KA, EA, KB, EB)                          \
+	{                                                     \
+		const bool sw = KB < KA;                          \
+		const uint32_t kl = sw ? KB : KA, el = sw ? EB : EA; \
+		KB = sw ? KA : KB, EB = sw ? EA : EB;             \
+		KA = kl, EA = el;                                 \
+	}
+			RT_PSWAP(k0, e0, k1, e1)
+			RT_PSWAP(k2, e2, k3, e3)
+			RT_PSWAP(k0, e0, k2, e2)
+#if RT_PACKET_FULL_SORT
+			RT_PSWAP(k1, e1, k3, e3)
+			RT_PSWAP(k1, e1, k2, e2)
+#endif
+#undef RT_PSWAP
+			// far children first (full sort), so the nearest of them is popped first; the pop below reads what was just written
+			// (1 when the key is not all ones, as integer arithmetic)
+			stk.push3(e3, packet_flag(k3), e2, packet_flag(k2), e1, packet_flag(k1));
+			if (k0 == 0xFFFFFFFFu)
+				e0 = stk.pop();
+			cur = e0;
+		}
+		if (cur == ENTRY_DONE)
+			break;
+		if (cur == ENTRY_SENTINEL)
+		{
+			sp.enter(O, D, act, nodes); // leaving an instance: back to the world-space ray
+			cur_inst = -1;
+			cur = stk.pop();
+			continue;
+		}
+		if (cur & ENTRY_TLAS)
+		{
+			// top-level leaf: exactly one instance; its inverse transform is wave-uniform, every lane transforms its own ray
+			// (direction NOT renormalised so that t is shared: top_level_bvh.cpp:104-168)
+			const uint32_t ii = sload1u(sc.tlas_prims, (cur & ENTRY_FIRST_MASK) * 4u);
+			const char *const ib = (const char *)(sc.instances + ii);
+			const pk_v4f r0 = sload4(ib, 0u), r1 = sload4(ib, 16u), r2 = sload4(ib, 32u);
+			const uint32_t root = sload1u(ib, (uint32_t)offsetof(Instance, root_entry));
+			stk.push(ENTRY_SENTINEL);
+			sp.enter(mk3(r0[0] * O.x + r0[1] * O.y + r0[2] * O.z + r0[3], r1[0] * O.x + r1[1] * O.y + r1[2] * O.z + r1[3],
+						 r2[0] * O.x + r2[1] * O.y + r2[2] * O.z + r2[3]),
+					 mk3(r0[0] * D.x + r0[1] * D.y + r0[2] * D.z, r1[0] * D.x + r1[1] * D.y + r1[2] * D.z,
+						 r2[0] * D.x + r2[1] * D.y + r2[2] * D.z),
+					 act, nodes);
+			cur_inst = (int)ii;
+			cur = root;
+			continue;
+		}
+		// a triangle leaf: every lane tests every triangle (Traverser::visit's test on its own ray)
+		{
+			const uint32_t first = cur & ENTRY_FIRST_MASK, count = ((cur >> 27) & 7u) + 1u;
+			const char *const tb = (const char *)sc.tri_verts + (size_t)first * 48u;
+			for (uint32_t i = 0; i < count; i++)
+			{
+				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
+				if (COUNT)
+					st.tris += active ? 1u : 0u;
+				if (tri_test(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v))
+				{
+					hit.prim = (int)fbits(v0[3]);
+					hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
+				}
+			}
+			cur = stk.pop();
+		}
+	}
+}
+
+// The pt primary wave in packet form: a wave takes runs of consecutive path slots from the launch's queue (one atomic per
+// run), generates the 64 primary rays of one 64-slot group per lane and walks the tree once for all of them.  No LDS.
+#ifndef RT_PACKET_WAVES
+#define RT_PACKET_WAVES 8
+#endif
+
+// The kernel's Params read afresh from the kernarg segment (the first argument sits at offset 0).  The packet kernel asks for
+// them once per stage of a group — generation, traversal, hit store: read once at kernel entry, the ~60 scalars of camera,
+// frame and scene stay live across the node loop, which needs ~65 SGPRs itself, and spill into VGPR lanes (a v_readlane per
+// use, on the VALU); a scalar load from the kernarg segment per stage costs the VALU nothing.
+__device__ __forceinline__ const Params &fresh_params()
+{
+	auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(ka));
+	return *(const Params *)ka;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet(const Params p, const uint32_t count)
+{
+	clock_in(p.wv.counters, 0);
+	uint32_t *const head = &p.wv.counters->work[p.queue][0];
+	const uint32_t lane = __lane_id();
+	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
+	run = run > (uint32_t)RT_STREAM_CHUNK ? (uint32_t)RT_STREAM_CHUNK : (run < 64u ? 64u : (run & ~63u));
+	TStat st;
+	st.inner = 0, st.tris = 0, st.lds = 0;
+	uint32_t nrays = 0;
+	for (;;)
+	{
+		uint32_t g = 0;
+		if (lane == 0)
+			g = atomicAdd(head, run);
+		g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+		if (g >= count)
+			break;
+		const uint32_t end = g + run < count ? g + run : count;
+		for (uint32_t base = g; base < end; base += 64u)
+		{
+			const uint32_t idx = base + lane;
+			bool active = idx < end;
+			f3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
+			{
+				const Params &q = fresh_params();
+				if (active)
+				{
+					const PixelRef pr = slot_to_pixel(q.fr, idx);
+					active = pr.valid;
+					if (active)
+					{
+						pt_primary_ray(q.cam, q.fr.W, q.fr.H, pr.x, pr.y, q.fr.sample_base + pr.sample, O, D);
+						q.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
+						q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+					}
+				}
+			}
+			Hit h;
+			h.t = 1e34f, h.u = 0.0f, h.v = 0.0f, h.prim = -1, h.inst = -1;
+			trace_packet<COUNT>(fresh_params().sc, active, O, D, 1e-5f, h, st);
+			if (active)
+			{
+				const Params &q = fresh_params();
+				q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
+				q.wv.hit0_inst[idx] = h.inst;
+				nrays++;
+			}
+		}
+	}
+	if (COUNT)
+	{
+		WaveCounters *const wc = p.wv.counters;
+		Ctx ctx;
+		ctx.add64(&wc->inner_extend, st.inner);
+		ctx.add64(&wc->tris_extend, st.tris);
+		ctx.add64(&wc->rays_extend, nrays);
+	}
+	clock_out(p.wv.counters, 0);
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_TRAVERSAL_WAVES) k_shade_parity(const Params p, const uint32_t count)
 {
@@ -1340,6 +1705,18 @@ __global__ void __launch_bounds__(BLOCK) k_refresh4(Node4c *nodes4, const uint32
 		refresh4_item(nodes4, src4, nodes2, i);
 }
 
+__global__ void __launch_bounds__(BLOCK) k_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4)
+{
+	const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < count4)
+		expand4_item(nodes4, out, i);
+}
+void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t s)
+{
+	if (count4)
+		hipLaunchKernelGGL(k_expand4, dim3((count4 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)s, nodes4, out, count4);
+}
+
 // Grid of the persistent kernels: more workgroups than fit on the chip at once (4-7 per CU).  The queue-driven kernels
 // do not care much (late workgroups find their queue empty), the shade kernel walks its chunks with a static stride
 // and balances better the finer that stride is.  Swept on MI355X: 8 / 16 / 32 / 64 / 128 per CU -> 1820 / 1835 /
@@ -1419,6 +1796,15 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 			RT_EXT(GEN_RANGED, true);
 		else
 			RT_EXT(GEN_RANGED, false);
+	}
+	else if (gen == GEN_PT && (p.refill & 8u))
+	{
+		// packet form of the primary wave: no LDS, one wave = one 64-slot group at a time
+		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
+		if (count)
+			hipLaunchKernelGGL((k_primary_packet<true>), gt, bt, 0, st, p, max_items);
+		else
+			hipLaunchKernelGGL((k_primary_packet<false>), gt, bt, 0, st, p, max_items);
 	}
 	else if (gen == GEN_PT && (p.refill & 4u) && max_items >= RT_PRIMARY_STREAM_MIN)
 	{
@@ -1664,6 +2050,11 @@ void launch_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, cons
 {
 	for (uint32_t i = 0; i < count4; i++)
 		refresh4_item(nodes4, src4, blas_nodes2, i);
+}
+void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t)
+{
+	for (uint32_t i = 0; i < count4; i++)
+		expand4_item(nodes4, out, i);
 }
 void launch_refit(Node *all_nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
 				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)

@@ -134,6 +134,8 @@ class Context final : public rfw::RenderContext
 		m_Target = glTextureID ? *glTextureID : 0;
 		m_Width = width, m_Height = height;
 		HIPRT_CHECK(rfwhip_group_init(m_Group, width, height));
+		// a resize frees the pinned host images of the frames in flight: the window of frames starts over
+		m_Frame = 0, m_Latest = nullptr;
 		m_Host.assign(size_t(width) * height * 4, 0.0f);
 	}
 
@@ -251,13 +253,13 @@ class Context final : public rfw::RenderContext
 			HIPRT_CHECK(rfwhip_group_wait(m_Group));
 		unsigned int inst = 0, prim = 0;
 		float dist = 0.0f;
-		for (rfwhip_context *c : m_Cores)
+		// only the rank that owns the probe pixel's 8-row strip has a record for it (every context keeps its last valid one:
+		// asking the others would hand back the hit of wherever the probe was before)
 		{
-			unsigned int i = 0, p = 0;
-			float d = 0.0f;
-			HIPRT_CHECK(rfwhip_get_probe_results(c, &i, &p, &d));
-			if (d > dist)
-				inst = i, prim = p, dist = d;
+			const unsigned world = (unsigned)m_Cores.size();
+			const unsigned strip = m_ProbeY / 8u, k = strip / world, pos = strip % world;
+			const unsigned owner = (k & 1u) ? world - 1u - pos : pos; // rfwhip.h: serpentine strip ownership
+			HIPRT_CHECK(rfwhip_get_probe_results(m_Cores[owner], &inst, &prim, &dist));
 		}
 		if (instanceIndex)
 			*instanceIndex = inst;
@@ -282,8 +284,12 @@ class Context final : public rfw::RenderContext
 
 	void update() override { HIPRT_CHECK(rfwhip_group_update(m_Group)); }
 
-	void set_probe_index(glm::uvec2 probePos) override { for (rfwhip_context *c : m_Cores)
-			HIPRT_CHECK(rfwhip_set_probe_index(c, probePos.x, probePos.y)); }
+	void set_probe_index(glm::uvec2 probePos) override
+	{
+		m_ProbeY = probePos.y;
+		for (rfwhip_context *c : m_Cores)
+			HIPRT_CHECK(rfwhip_set_probe_index(c, probePos.x, probePos.y));
+	}
 
 	rfw::RenderStats get_stats() const override
 	{
@@ -315,6 +321,7 @@ class Context final : public rfw::RenderContext
 	bool m_Cleaned = false;
 	int m_InFlight = 1;
 	unsigned long long m_Frame = 0;
+	unsigned m_ProbeY = 0; // row of the probe pixel: decides which rank's record get_probe_results reads
 	const float *m_Latest = nullptr;
 	GLuint m_Target = 0;
 	uint m_Width = 0, m_Height = 0;

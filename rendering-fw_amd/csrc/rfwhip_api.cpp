@@ -397,7 +397,9 @@ struct rfwhip_context
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
-	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave
+	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave;
+					// bit 3: the pt primary wave in packet form (wave-uniform traversal, kernels.hip: trace_packet)
+	bool packet_ok = false; // the scene's trees fit the packet kernel's stack and its 32-bit node offsets
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly
@@ -414,6 +416,7 @@ struct rfwhip_context
 	bool scene_dirty = true;
 
 	// scene (device side)
+	DevBuf d_nodes4f; // float form of d_nodes4 (rt::Node4f), refreshed at the end of every rfwhip_update
 	DevBuf d_nodes, d_nodes4, d_nodes4_src, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
 	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
@@ -588,7 +591,7 @@ static void free_all(rfwhip_context *c)
 	}
 	c->d_lbvh_scratch.free_(), c->d_blue_noise.free_();
 	c->have_blue_noise = false;
-	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
+	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4f, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
 					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org[0], &c->d_sh_org[1],
@@ -1405,6 +1408,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		int blas_need = 0;
 		for (uint32_t i : live)
 			blas_need = std::max(blas_need, c->meshes[c->instances[i].mesh].stack_need);
+		// the packet form of the primary wave keeps ONE stack of PACKET_STACK entries per wave (kernels.hip: PacketStack)
+		c->packet_ok = tlas_need + 1 + blas_need <= (int)rtk::PACKET_STACK;
 		if (tlas_need + 1 + blas_need > rt::STACK_CAPACITY)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "rfwhip_update: top-level tree over %zu instances needs %d traversal-stack "
 							 "entries + 1 + %d for the deepest mesh (capacity %d)", live.size(), tlas_need, blas_need, rt::STACK_CAPACITY);
@@ -1461,6 +1466,11 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		tl4c[k] = compress4(tl4[k]);
 	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4c>() + tlas_base, tl4c.data(), tl4c.size() * sizeof(rt::Node4c), c->stream));
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
+	// the float form of every traversal node (mesh trees as rebuilt / refitted above + the top-level tree): one streaming pass
+	RF_TRY(c->d_nodes4f.ensure(c->node4_capacity * sizeof(rt::Node4f)));
+	c->packet_ok = c->packet_ok && (tlas_base + tl4c.size()) * sizeof(rt::Node4f) < (1ull << 32);
+	rtk::launch_expand4(c->d_nodes4.as<rt::Node4c>(), c->d_nodes4f.as<rt::Node4f>(), (uint32_t)(tlas_base + tl4c.size()), c->stream);
+	RF_TRY(dm::last_launch_error());
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
 	c->tlas_root_entry = live.empty() ? 0u
@@ -1468,7 +1478,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 									   : flat_entry(rt::make_entry(tl.nodes[0].left_first, tl.nodes[0].count, true));
 
 	rt::SceneView &sv = c->sv;
-	sv.nodes4 = c->d_nodes4.as<rt::Node4c>();
+	sv.nodes4 = c->d_nodes4.as<rt::Node4c>(), sv.nodes4f = c->d_nodes4f.as<rt::Node4f>();
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
 	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
 	sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();
@@ -1644,7 +1654,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 		if (big && want)
 			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, big->n4_count);
 	}
-	p.refill = (uint32_t)c->refill;
+	p.refill = (uint32_t)c->refill & (c->packet_ok ? 15u : 7u);
 	p.textured = c->textured ? 1u : 0u;
 }
 
@@ -2273,7 +2283,7 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	else if (k == "lds_nodes")
 		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
-		c->refill = atoi(value) & 7;
+		c->refill = atoi(value) & 15;
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);

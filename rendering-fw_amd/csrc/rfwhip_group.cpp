@@ -271,6 +271,11 @@ struct rfwhip_group
 	bool owns_contexts = false;
 	uint32_t W = 0, H = 0, local_rows = 0;
 	void *staging = nullptr, *full = nullptr; // on the root's device
+	// peer transport: recorded on the root's stream once a frame's de-interleave has read the staging image; every rank's next
+	// push waits for it (frames in flight: without it a fast rank overwrites its chunk while the root still waits for a slow one)
+	event_t staging_read;
+	bool staging_event = false, staging_read_valid = false;
+	bool poisoned = false; // a call failed half-way through the ranks: sample counts / ring slots diverge, re-init needed
 	int root_local = -1;					  // index of rank 0 in ep, -1 when another process owns it
 	// pipelined presentation (rfwhip_group_present_async / _wait): two pinned host images and the events of their copies
 	static constexpr int SLOTS = RFWHIP_PRESENT_SLOTS;
@@ -302,6 +307,7 @@ void release_buffers(rfwhip_group *g)
 		dev_free(g->staging), dev_free(g->full);
 	}
 	g->staging = g->full = nullptr;
+	g->staging_read_valid = false;
 	for (int k = 0; k < rfwhip_group::SLOTS; k++)
 	{
 		host_free(g->host_img[k]), g->host_img[k] = nullptr, g->host_pending[k] = false;
@@ -349,12 +355,17 @@ int init_rccl(rfwhip_group *g, const ncclUniqueId &id)
 {
 	// every local rank joins the communicator; inside one ncclGroup so that a single thread can own several ranks
 	GR_NCCL(g_rccl.GroupStart());
-	for (auto &e : g->ep)
-	{
-		GR_TRY(dev_use(e.device));
-		GR_NCCL(g_rccl.CommInitRank(&e.comm, g->world, id, e.rank));
-	}
-	GR_NCCL(g_rccl.GroupEnd());
+	const int rc_group = [&]() -> int {
+		for (auto &e : g->ep)
+		{
+			GR_TRY(dev_use(e.device));
+			GR_NCCL(g_rccl.CommInitRank(&e.comm, g->world, id, e.rank));
+		}
+		return 0;
+	}();
+	const ncclResult_t r_end = g_rccl.GroupEnd(); // (closed on every path)
+	GR_TRY(rc_group);
+	GR_NCCL(r_end);
 	return 0;
 }
 #endif
@@ -383,19 +394,25 @@ int gather(rfwhip_group *g, void *full_out)
 			// 2a. one ncclGroup: a send per non-root rank, world - 1 receives on the root, each pair on its own xGMI link
 			const size_t count = chunk / sizeof(float);
 			GR_NCCL(g_rccl.GroupStart());
-			for (auto &e : g->ep)
-				if (e.rank != 0)
+			// (whatever fails inside, the group is closed again: an open ncclGroup would swallow every later call)
+			const int rc_group = [&]() -> int {
+				for (auto &e : g->ep)
+					if (e.rank != 0)
+					{
+						GR_TRY(dev_use(e.device));
+						GR_NCCL(g_rccl.Send(e.local_fb, count, ncclFloat, 0, e.comm, (hipStream_t)e.stream));
+					}
+				if (root)
 				{
-					GR_TRY(dev_use(e.device));
-					GR_NCCL(g_rccl.Send(e.local_fb, count, ncclFloat, 0, e.comm, (hipStream_t)e.stream));
+					GR_TRY(dev_use(root->device));
+					for (int r = 1; r < g->world; r++)
+						GR_NCCL(g_rccl.Recv((char *)g->staging + (size_t)r * chunk, count, ncclFloat, r, root->comm, (hipStream_t)root->stream));
 				}
-			if (root)
-			{
-				GR_TRY(dev_use(root->device));
-				for (int r = 1; r < g->world; r++)
-					GR_NCCL(g_rccl.Recv((char *)g->staging + (size_t)r * chunk, count, ncclFloat, r, root->comm, (hipStream_t)root->stream));
-			}
-			GR_NCCL(g_rccl.GroupEnd());
+				return 0;
+			}();
+			const ncclResult_t r_end = g_rccl.GroupEnd();
+			GR_TRY(rc_group);
+			GR_NCCL(r_end);
 		}
 		else
 #endif
@@ -423,6 +440,16 @@ int gather(rfwhip_group *g, void *full_out)
 		{
 			if (rfwhip_deinterleave_stream(root->ctx, g->staging, full_out ? full_out : g->full, root->stream))
 				return RFWHIP_ERR_STATE;
+			if (g->transport != RFWHIP_TRANSPORT_RCCL) // (RCCL: the receives sit on the root's stream behind the de-interleave)
+			{
+				if (!g->staging_event)
+				{
+					GR_TRY(event_create(&g->staging_read));
+					g->staging_event = true;
+				}
+				GR_TRY(event_record(g->staging_read, root->stream));
+				g->staging_read_valid = true;
+			}
 		}
 		else
 			GR_TRY(copy_async(full_out ? full_out : g->full, root->device, g->staging, root->device, (size_t)g->W * g->H * PIXEL_BYTES, root->stream));
@@ -432,13 +459,21 @@ int gather(rfwhip_group *g, void *full_out)
 
 int wait_all(rfwhip_group *g)
 {
+	// every rank is waited for, whatever one of them reports: the first error comes back afterwards (the contexts keep their
+	// own messages; rfwhip_last_error() holds the last one set)
+	int first = 0;
 	for (auto &e : g->ep)
 	{
-		if (rfwhip_wait(e.ctx))
-			return RFWHIP_ERR_STATE;
-		GR_TRY(dev_use(e.device));
-		GR_TRY(stream_sync(e.stream));
+		if (rfwhip_wait(e.ctx) && !first)
+			first = RFWHIP_ERR_STATE;
+		int rc = dev_use(e.device);
+		if (!rc)
+			rc = stream_sync(e.stream);
+		if (rc && !first)
+			first = rc;
 	}
+	if (first)
+		return first;
 	if (g->copy_stream && g->root_local >= 0)
 	{
 		GR_TRY(dev_use(g->ep[(size_t)g->root_local].device));
@@ -480,6 +515,8 @@ void destroy_group(rfwhip_group *g)
 			event_destroy(g->host_ready[k]), event_destroy(g->slot_done[k]);
 		g->host_events = false;
 	}
+	if (g->staging_event)
+		event_destroy(g->staging_read), g->staging_event = false;
 	stream_destroy(g->copy_stream), g->copy_stream = nullptr;
 	g->ep.clear();
 }
@@ -576,10 +613,11 @@ extern "C" int rfwhip_group_init(rfwhip_group *g, uint32_t width, uint32_t heigh
 {
 	if (!g)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null group");
-	GR_TRY(wait_all(g)); // a gather in flight still uses the buffers
+	(void)wait_all(g); // a gather in flight still uses the buffers (a poisoned group may report its old error here)
 	for (auto &e : g->ep)
 		if (rfwhip_init(e.ctx, width, height))
 			return RFWHIP_ERR_STATE;
+	g->poisoned = false; // every rank starts from sample 0 of a fresh target again
 	return size_buffers(g, width, height);
 }
 
@@ -587,13 +625,14 @@ extern "C" int rfwhip_group_update(rfwhip_group *g)
 {
 	if (!g)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null group");
+	int first = 0; // every rank is updated; the first error comes back afterwards
 	for (auto &e : g->ep)
 	{
 		const int rc = rfwhip_update(e.ctx);
-		if (rc)
-			return rc;
+		if (rc && !first)
+			first = rc;
 	}
-	return RFWHIP_OK;
+	return first;
 }
 
 extern "C" int rfwhip_group_set_setting(rfwhip_group *g, const char *key, const char *value)
@@ -613,13 +652,19 @@ extern "C" int rfwhip_group_render(rfwhip_group *g, const rfwhip_camera *camera,
 {
 	if (!g)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "null group");
-	for (auto &e : g->ep) // enqueue only: the n devices render side by side
+	if (g->poisoned && status != RFWHIP_RESET)
+		return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "rfwhip_group_render: an earlier call failed on some ranks only — the ranks' sample "
+																 "counts differ; render with RFWHIP_RESET (or call rfwhip_group_init) first");
+	int first = 0;
+	for (auto &e : g->ep) // enqueue only: the n devices render side by side; every rank is asked even when one fails
 	{
 		const int rc = rfwhip_render(e.ctx, camera, status);
-		if (rc)
-			return rc;
+		if (rc && !first)
+			first = rc;
 	}
-	return RFWHIP_OK;
+	// a RESET that every rank took puts them in step again; a failure on some ranks leaves their sample counts apart
+	g->poisoned = first != 0;
+	return first;
 }
 
 extern "C" int rfwhip_group_gather(rfwhip_group *g)

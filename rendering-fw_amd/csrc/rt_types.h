@@ -132,6 +132,22 @@ struct alignas(16) Node4c
 };
 static_assert(sizeof(Node4c) == 64, "compressed 4-wide node");
 
+// The same node once more with FLOAT planes — exactly the planes the compressed node decodes to (plane = fma(q, scale, org)):
+// what the wave-uniform ("packet") traversal of the coherent waves fetches through SCALAR loads (kernels.hip: trace_packet).
+// A wave that walks one node for all its lanes has the node in SGPRs; byte -> float conversions of wave-uniform data would
+// cost a full VALU issue each, so they are done once per node and update (k_expand4) instead of once per visit.  Row order:
+// which of a child's two planes per axis is the entry plane depends only on the sign of the ray direction, so the kernel
+// reads "near" and "far" rows by choosing the row offset per wave (lo rows at 0 / 16 / 32, hi rows at 48 / 64 / 80).
+// An unused slot: lo = +1e30, hi = -1e30 (never hit).
+struct alignas(16) Node4f
+{
+	float lo[3][4];
+	float hi[3][4];
+	uint32_t entry[4];
+	uint32_t pad[4];
+};
+static_assert(sizeof(Node4f) == 128, "float 4-wide node");
+
 // Quantise the (up to four) child boxes lo[axis][child] .. hi[axis][child] into n (entries untouched).  Shared by the host
 // (upload) and the device (after a refit), so both produce the same bytes.
 RT_FN void pack_boxes4c(Node4c &n, const float lo[3][4], const float hi[3][4], const bool valid[4])
@@ -253,6 +269,7 @@ struct SceneView
 							 // triangle index into tri_verts): a traversal step is base + 32-bit offset, no per-lane
 							 // base pointers
 	const Node4c *nodes4;	 // traversal form: all BLAS 4-wide nodes (compressed), then the TLAS's (absolute entries)
+	const Node4f *nodes4f;	 // the same nodes with float planes (scalar-fetched by the packet traversal of the coherent waves)
 	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
 	const TriShade *tri_shade;
 	const uint32_t *tlas_prims; // instance index per TLAS leaf slot

@@ -150,6 +150,61 @@ def test_group_on_one_device_equals_the_single_context_gpu(pkg, make_hip, n, int
     g.destroy()
 
 
+def _moving_cameras(scene, frames):
+    import copy
+    cams = []
+    for k in range(frames):
+        cam = copy.deepcopy(scene.camera)
+        x, y, z = cam.position
+        cam.position = (x + 0.35 * k, y + 0.11 * (k % 3), z + 0.2 * k)
+        cams.append(cam)
+    return cams
+
+
+def _frames_in_flight_do_not_tear(pkg, make_one, group, w, h, n_slots, frames, settings):
+    """Every frame a NEW camera and a RESET: a presented image that holds strips of two frames (the write-after-read hazard on
+    the root's staging image when a fast rank pushes frame k + 1 before the root has de-interleaved frame k) differs from the
+    single-context image of its camera."""
+    # (terrain: every rank keeps paths alive at every depth — the per-batch connection rule of DESIGN.md §6 never differs)
+    scene = pkg.scenes.terrain(n=24, width=w, height_px=h)
+    cams = _moving_cameras(scene, frames)
+    ref = make_one()
+    ref.init(w, h)
+    scene.upload(ref)
+    group.init(w, h)
+    scene.upload(group)
+    for k, v in settings.items():
+        ref.set_setting(k, v), group.set_setting(k, v)
+    want = []
+    for cam in cams:
+        ref.render_frame(cam, pkg.RESET)
+        want.append(ref.framebuffer())
+    assert not np.array_equal(want[0], want[1])
+    for k, cam in enumerate(cams):
+        group.render_async(cam, pkg.RESET)
+        group.present_async(k % n_slots)
+        if k >= n_slots - 1:
+            assert np.array_equal(group.present_wait((k + 1) % n_slots), want[k - n_slots + 1]), k
+    for k in range(frames - n_slots + 1, frames):
+        assert np.array_equal(group.present_wait(k % n_slots), want[k]), k
+
+
+def test_frames_in_flight_with_a_moving_camera_do_not_tear(pkg, make_emu, emu_lib):
+    g = pkg._binding.RenderGroup(emu_lib, "rfwhip_", [0, 0, 0], "peer")
+    _frames_in_flight_do_not_tear(pkg, make_emu, g, 64, 48, 3, 7, {"integrator": "pt", "spp": 1, "max_depth": 2})
+    g.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,slots", [(4, 4), (8, 2)])
+def test_frames_in_flight_with_a_moving_camera_do_not_tear_gpu(pkg, make_hip, n, slots):
+    """n contexts on one device (the hardware schedules their streams in any order: the ranks are as imbalanced as it gets),
+    peer transport, frames handed out late, the camera moving every frame."""
+    g = pkg.render_group([0] * n, "peer")
+    _frames_in_flight_do_not_tear(pkg, make_hip, g, 480, 270, slots, 14, {"integrator": "pt", "spp": 2, "max_depth": 2})
+    g.destroy()
+
+
 @pytest.mark.gpu
 def test_group_over_rccl_needs_two_devices(pkg, make_hip):
     """The RCCL transport: ncclSend / ncclRecv between the ranks of one process.  Needs >= 2 visible devices."""
