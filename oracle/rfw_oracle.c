@@ -264,21 +264,22 @@ void rfwo_xor128_jump(uint32_t state[4], uint64_t draws)
 /* bvh_tree.cpp:166-196.  u,v are the weights of p1 and p2 (Embree convention used by Context.cpp:210-211). */
 static inline int tri_test(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, v3 p2, float *u_out, float *v_out)
 {
+	/* (fixed-shape arithmetic: rfw_oracle_math.h, rounded()) */
 	const v3 e1 = vsub(p1, p0), e2 = vsub(p2, p0);
-	const v3 h = vcross(dir, e2);
-	const float a = vdot(e1, h);
+	const v3 h = vcross_r(dir, e2);
+	const float a = vdot_r(e1, h);
 	if (a > -TRI_EPS && a < TRI_EPS)
 		return 0;
 	const float f = 1.f / a;
 	const v3 s = vsub(org, p0);
-	const float u = f * vdot(s, h);
+	const float u = rounded(f * vdot_r(s, h));
 	if (u < 0.0f || u > 1.0f)
 		return 0;
-	const v3 q = vcross(s, e1);
-	const float v = f * vdot(dir, q);
+	const v3 q = vcross_r(s, e1);
+	const float v = rounded(f * vdot_r(dir, q));
 	if (v < 0.0f || u + v > 1.0f)
 		return 0;
-	const float tt = f * vdot(e2, q);
+	const float tt = rounded(f * vdot_r(e2, q));
 	if (tt > t_min && *t > tt)
 	{
 		*t = tt;
@@ -1617,11 +1618,14 @@ static void pt_path(rfwo_context *c, const rfwhip_camera_view *view, float clamp
 	const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
 	if ((r2 + r3) > 1.0f)
 		r2 = 1.0f - r2, r3 = 1.0f - r3;
-	const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
+	/* (fixed-shape arithmetic from here on: rfw_oracle_math.h, rounded()) */
+	const float xr = fmaf(x2, r3, rounded(x1 * r2)), yr = fmaf(y2, r3, rounded(y1 * r2));
 	const v3 right = vsub(v3p(view->p2), v3p(view->p1)), up = vsub(v3p(view->p3), v3p(view->p1));
-	v3 O = vadd(v3p(view->pos), vscale(vadd(vscale(right, xr), vscale(up, yr)), view->aperture));
-	const float uu = ((float)sx + r0) * (1.0f / (float)W), vv = ((float)sy + r1) * (1.0f / (float)H);
-	v3 D = vnorm(vsub(vadd(vadd(v3p(view->p1), vscale(right, uu)), vscale(up, vv)), O));
+	v3 O = v3p(view->pos);
+	if (view->aperture != 0.0f) /* (with aperture 0 the offset is exactly zero) */
+		O = vmadd2_r(v3p(view->pos), right, rounded(xr * view->aperture), up, rounded(yr * view->aperture));
+	const float uu = rounded(((float)sx + r0) * (1.0f / (float)W)), vv = rounded(((float)sy + r1) * (1.0f / (float)H));
+	v3 D = vnorm_r(vsub(vmadd2_r(v3p(view->p1), right, uu, up, vv), O));
 
 	v3 T = V3(1, 1, 1);
 	float bsdfPdf = 1.0f;

@@ -27,6 +27,33 @@ static inline v3 vscale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static inline v3 vcross(v3 a, v3 b) { return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 static inline float vlen(v3 a) { return sqrtf(vdot(a, a)); }
+/* Fixed-shape arithmetic for the results that are compared bit for bit across implementations (triangle test, pt primary ray):
+ * fmaf() where a fused multiply-add is meant, rounded() around a product that is rounded on its own — an empty asm keeps the
+ * compiler's fma contraction from deciding otherwise.  The product states the same shapes (csrc/rt_core.h: rounded()). */
+static inline float rounded(float x)
+{
+#if defined(__x86_64__)
+	__asm__("" : "+x"(x));
+#else
+	volatile float y = x;
+	x = y;
+#endif
+	return x;
+}
+static inline float vdot_r(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, rounded(a.x * b.x))); }
+static inline v3 vcross_r(v3 a, v3 b)
+{
+	return V3(fmaf(a.y, b.z, -rounded(b.y * a.z)), fmaf(a.z, b.x, -rounded(b.z * a.x)), fmaf(a.x, b.y, -rounded(b.x * a.y)));
+}
+static inline v3 vmadd2_r(v3 p, v3 a, float s, v3 b, float t)
+{
+	return V3(fmaf(b.x, t, fmaf(a.x, s, p.x)), fmaf(b.y, t, fmaf(a.y, s, p.y)), fmaf(b.z, t, fmaf(a.z, s, p.z)));
+}
+static inline v3 vnorm_r(v3 a)
+{
+	const float inv = 1.0f / sqrtf(vdot_r(a, a));
+	return V3(rounded(a.x * inv), rounded(a.y * inv), rounded(a.z * inv));
+}
 /* glm::normalize = v * inversesqrt(dot(v, v)) */
 static inline v3 vnorm(v3 a) { return vscale(a, 1.0f / sqrtf(vdot(a, a))); }
 static inline v3 vlerp(v3 a, v3 b, float t) { return vadd(a, vscale(vsub(b, a), t)); }

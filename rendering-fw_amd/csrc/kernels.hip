@@ -52,6 +52,9 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 8
 #endif
+#ifndef RT_TRACE_VGPRS
+#define RT_TRACE_VGPRS 64 // (launch bounds alone let the allocator settle one register above the 8-wave budget)
+#endif
 #ifndef RT_PRIMARY_WAVES
 #define RT_PRIMARY_WAVES 7 // k_extend: the kernel that also generates the primary rays (6 / 7 / 8 -> 6.95 / 6.65 / 7.42 ms per launch)
 #endif
@@ -60,6 +63,11 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
+#endif
+// packet form of the primary wave (trace_packet): 0 = the nearest entered child first, the others in no particular order (3 of
+// the 5 comparators of the sorting network); 1 = all entered children by distance
+#ifndef RT_PACKET_FULL_SORT
+#define RT_PACKET_FULL_SORT 0
 #endif
 #ifndef RT_SHADE_WAVES_PLAIN
 #define RT_SHADE_WAVES_PLAIN 5 // the shade kernel of scenes without textures: 111 registers unbounded; 4 / 5 / 6 waves ->
@@ -75,6 +83,7 @@ struct Ctx
 {
 	TravStack stk;
 	float *pot = nullptr; // this lane's column of the light-potential cache (shade kernel)
+	volatile uint16_t *tri_map = nullptr; // this WAVE's 64 entries of the triangle phase's pair map (wave_triangle_phase)
 
 	// Block-wise slot allocation of the shade kernel's two output queues (rt_types.h: QUEUE_BLOCK).  Wave-uniform state.
 	struct OutQueue
@@ -218,7 +227,10 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		}
 		if (active)
 		{
-			p.wv.org[0][i] = mk4(O.x, O.y, O.z, ubits((i << 1) | 1u));
+			// (pt, pinhole camera: every primary ray starts at the camera position and entry i of the primary wave is path slot
+			// i — the shade kernel needs no origin record: 16 bytes less written here and read there per primary ray)
+			if (GEN != GEN_PT || p.cam.aperture != 0.0f)
+				p.wv.org[0][i] = mk4(O.x, O.y, O.z, ubits((i << 1) | 1u));
 			p.wv.dir[0][i] = mk4(D.x, D.y, D.z, 0.0f);
 		}
 	}
@@ -303,7 +315,9 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	}
 	if (active)
 	{
-		const f4 o4 = p.wv.org[b][i], d4 = p.wv.dir[b][i];
+		// (depth 0 behind a pinhole camera: no origin record was written — the origin is the camera, the slot is the entry)
+		const f4 o4 = (p.depth == 0 && p.cam.aperture == 0.0f) ? mk4(p.cam.pos.x, p.cam.pos.y, p.cam.pos.z, ubits((i << 1) | 1u)) : p.wv.org[b][i];
+		const f4 d4 = p.wv.dir[b][i];
 		const f4 h4 = (p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i];
 		const int hi = (p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst)[i];
 		PathIn in;
@@ -831,8 +845,10 @@ constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
 #define RT_STACK_DECL_N(DEPTH, NTHREADS)                                                     \
 	__shared__ uint32_t s_stack[(DEPTH) * (NTHREADS)];                                      \
 	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
+	__shared__ uint16_t s_trimap[(NTHREADS)];                                               \
 	uint32_t spill_[SPILL_STACK];                                                           \
 	Ctx ctx;                                                                                \
+	ctx.tri_map = s_trimap + (threadIdx.x & ~63u);                                          \
 	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
 	ctx.stk.stride = (NTHREADS);                                                            \
 	ctx.stk.spill = spill_;                                                                 \
@@ -943,6 +959,108 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 
 
 
+// ----------------------------------------------------------------------------------------------------------------
+// Wave-wide triangle phase of the persistent-lane kernels (RT_WAVE_TRIS).  In the while-while traversal a wave leaves the node
+// phase with some of its lanes holding a triangle leaf (1..4 triangles each) and Traverser::visit() lets every such lane test
+// its own: the loop runs as long as the longest leaf, with the lanes of shorter leaves, of instance switches and of unfinished
+// descents idle — 12 (bounce) to 19 (shadow) of 64 lanes on the incoherent waves, in what is a third of their instructions.
+// Here the wave pools the work: the (lane, triangle) pairs of all leaves in hand are numbered by a prefix sum over the leaf
+// sizes (four ballots of the size's bits + mbcnt), pair j goes to lane j — the OWNER's ray (origin, direction, current hit
+// distance) and leaf come across the wave with ds_bpermute_b32, the triangle's three vertices from memory as before — and the
+// results go back the same way: the owner takes the nearest accepted hit of its segment of lanes, the earliest on a tie. That
+// is exactly what its own loop would have produced (it accepts a triangle when t_min < t < the nearest so far; the minimum
+// over those accepted against the distance at the start of the leaf is the same triangle), so hit records are bit-identical.
+// A phase is ONE round: the owners whose pairs fit into 64 lanes; the others keep their leaf for the next phase.  Only a
+// 128-byte lane map per wave lives in LDS (pair -> owner lane and triangle number).
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef RT_WAVE_TRIS
+#define RT_WAVE_TRIS 1
+#endif
+__device__ __forceinline__ float wave_fetch(uint32_t src_lane_x4, float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)src_lane_x4, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ uint32_t wave_fetch(uint32_t src_lane_x4, uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane_x4, (int)v);
+}
+template <bool ANY, bool COUNT, bool WORLD>
+__device__ __forceinline__ void wave_triangle_phase(Traverser<ANY, COUNT, WORLD> &T, const SceneView &sc, const bool has_ray, volatile uint16_t *map,
+													const TravStack stk, TStat &st)
+{
+	static_assert(!RT_SPECULATE, "the wave-wide triangle phase has no held leaves");
+	const uint32_t lane = __lane_id();
+	const bool pending = has_ray && Traverser<ANY, COUNT, WORLD>::tri_leaf(T.cur);
+	if (__ballot(pending) == 0ull)
+		return;
+	// ONE round per phase: the owners whose pairs fit into 64 lanes are served, the others keep their leaf in hand and are
+	// first in line — by then with the leaves the next node steps bring — in the next phase: every round runs nearly full
+	// (a second round for the overflow of this one would run with a handful of lanes)
+	{
+		const uint32_t first = T.cur & ENTRY_FIRST_MASK;
+		const uint32_t cnt = pending ? ((T.cur >> 27) & 7u) + 1u : 0u; // 1..8
+		// exclusive prefix sum of the leaf sizes over the lanes
+		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u),
+								 b3 = __ballot((cnt & 8u) != 0u);
+		const uint32_t prefix = wave_prefix(b0) + 2u * wave_prefix(b1) + 4u * wave_prefix(b2) + 8u * wave_prefix(b3);
+		const bool in_round = pending && prefix + cnt <= 64u; // (prefixes grow with the lane: the owners of a round are a lane prefix)
+		// pair -> (owner lane, triangle number of the leaf); 0xFFFF: no pair for this lane
+		map[lane] = (uint16_t)0xFFFFu;
+		__builtin_amdgcn_wave_barrier();
+		if (in_round)
+			for (uint32_t k = 0; k < cnt; k++)
+				map[prefix + k] = (uint16_t)(lane | (k << 8));
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t e = map[lane];
+		const bool valid = e != 0xFFFFu;
+		const uint32_t owner4 = (e & 63u) << 2, k = (e >> 8) & 7u;
+		// the owner's ray and leaf (every lane executes the fetches: a disabled lane cannot be read from)
+		const f3 fo = mk3(wave_fetch(owner4, T.o.x), wave_fetch(owner4, T.o.y), wave_fetch(owner4, T.o.z));
+		const f3 fd = mk3(wave_fetch(owner4, T.d.x), wave_fetch(owner4, T.d.y), wave_fetch(owner4, T.d.z));
+		float ft = wave_fetch(owner4, T.hit.t);
+		const uint32_t ffirst = wave_fetch(owner4, first);
+		float ru = 0.0f, rv = 0.0f;
+		uint32_t rprim = 0u, rinst = 0u;
+		bool rhit = false;
+		if (valid)
+		{
+			const f4 *tv = sc.tri_verts + 3u * (ffirst + k);
+			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+			rhit = tri_test(fo, fd, T.t_min, ft, xyz(v0), xyz(v1), xyz(v2), ru, rv);
+			rprim = fbits(v0.w), rinst = fbits(v1.w);
+		}
+		if (COUNT)
+			st.tris += in_round ? cnt : 0u;
+		// back to the owners: the accepted hits of an owner's segment of lanes [prefix, prefix + cnt)
+		const unsigned long long hm = __ballot(rhit);
+		uint32_t seg = in_round ? (uint32_t)(hm >> prefix) & ((1u << cnt) - 1u) : 0u;
+		if (ANY)
+		{
+			if (seg)
+				T.hit.prim = 0, T.cur = ENTRY_DONE; // occluded: which triangle does not matter
+		}
+		else
+		{
+			// (iterations = the largest number of accepted hits in one segment: mostly one)
+			while (__ballot(seg != 0u) != 0ull)
+			{
+				const uint32_t kk = seg ? (uint32_t)__ffs((int)seg) - 1u : 0u;
+				const uint32_t src4 = ((prefix + kk) & 63u) << 2;
+				const float t2 = wave_fetch(src4, ft), u2 = wave_fetch(src4, ru), v2 = wave_fetch(src4, rv);
+				const uint32_t p2 = wave_fetch(src4, rprim), i2 = wave_fetch(src4, rinst);
+				if (seg && t2 < T.hit.t) // (segments are walked in triangle order: the earliest wins a tie, as in the lane's own loop)
+				{
+					T.hit.t = t2, T.hit.u = u2, T.hit.v = v2, T.hit.prim = (int)p2;
+					T.hit.inst = T.cur_inst >= 0 ? T.cur_inst : (int)i2;
+				}
+				seg &= seg - 1u;
+			}
+		}
+		if (in_round && !(ANY && T.cur == ENTRY_DONE))
+			T.cur = T.pop(stk);
+	}
+}
+
 // MODE: where a lane's next ray comes from — the extension-ray buffers of this depth, the shadow-ray buffers, or the
 // pt integrator's primary-ray generator (item = path slot; the ray is also stored for the shade kernel)
 enum
@@ -960,7 +1078,9 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	const uint32_t b = p.depth & 1u;
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
 	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
-	Traverser<ANY, COUNT> T;
+	// (the queue-fed waves re-read a ray's record on the rare instance switch instead of keeping the world-space ray)
+	constexpr bool WORLD = MODE == STREAM_PRIMARY_PT;
+	Traverser<ANY, COUNT, WORLD> T;
 	T.cur = ENTRY_DONE, T.held = ENTRY_DONE;
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
@@ -1025,7 +1145,8 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 						{
 							f3 O, D;
 							pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
-							p.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
+							if (p.cam.aperture != 0.0f) // (pinhole: no origin record, extend_item)
+								p.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
 							p.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
 							T.begin(p.sc, O, D, 1e-5f, 1e34f);
 							has_ray = true, ray = idx, nrays++;
@@ -1062,9 +1183,26 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 			continue; // (primary slots outside the image leave their lanes idle: take the next ones)
 		}
 		T.template descend<VOTE>(p.sc, ctx.stk, st);
+		const auto world = [&](f3 &O, f3 &D) {
+			if constexpr (WORLD)
+				O = T.O, D = T.D;
+			else
+			{
+				const f4 o4 = ray_o[ray], d4 = ray_d[ray];
+				O = xyz(o4), D = xyz(d4);
+			}
+		};
+#if RT_WAVE_TRIS
+		// instance switches stay with their lanes; the triangle leaves in hand are tested by the wave as a whole
+		if (has_ray && !Traverser<ANY, COUNT, WORLD>::tri_leaf(T.cur))
+			T.visit(p.sc, ctx.stk, st, world);
+		wave_triangle_phase(T, p.sc, has_ray, ctx.tri_map, ctx.stk, st);
+#endif
 		if (has_ray)
 		{
-			T.visit(p.sc, ctx.stk, st);
+#if !RT_WAVE_TRIS
+			T.visit(p.sc, ctx.stk, st, world);
+#endif
 			if (T.done())
 			{
 				if (ANY)
@@ -1090,7 +1228,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 }
 
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) k_trace_stream(const Params p)
+__global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAVES) __attribute__((amdgpu_num_vgpr(RT_TRACE_VGPRS))) k_trace_stream(const Params p)
 {
 	const uint32_t count = ANY ? connection_count(p.wv.counters, p.depth) : p.wv.counters->ext_n[p.depth];
 	if (count == 0u)
@@ -1137,9 +1275,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primar
 // a wave whose lanes disagree about a sign on some axis takes min / max per plane pair instead (MIXED).  Instances: the
 // transform is wave-uniform, every lane transforms its ray; the sentinel restores the world-space ray.
 // ----------------------------------------------------------------------------------------------------------------
-#ifndef RT_PACKET_FULL_SORT
-#define RT_PACKET_FULL_SORT 0 // 0: the nearest entered child first, the others in no particular order (3 of the 5 comparators)
-#endif
 #define RT_CONST_AS __attribute__((address_space(4)))
 typedef float pk_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t pk_v4u __attribute__((ext_vector_type(4)));
@@ -1303,7 +1438,8 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 					const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 					const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 					tk[k] = fmaxf(tmin, 0.0f);
-					m[k] = __ballot(tk[k] < fminf(tmax, hit.t));
+					// (min / max per plane pair turn the inverted box of an unused slot into a huge one: asked for by its entry)
+					m[k] = ent[k] != ENTRY_EMPTY ? __ballot(tk[k] < fminf(tmax, hit.t)) : 0ull;
 				}
 			}
 			if (COUNT)
@@ -1352,10 +1488,8 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			const pk_v4f r0 = sload4(ib, 0u), r1 = sload4(ib, 16u), r2 = sload4(ib, 32u);
 			const uint32_t root = sload1u(ib, (uint32_t)offsetof(Instance, root_entry));
 			stk.push(ENTRY_SENTINEL);
-			sp.enter(mk3(r0[0] * O.x + r0[1] * O.y + r0[2] * O.z + r0[3], r1[0] * O.x + r1[1] * O.y + r1[2] * O.z + r1[3],
-						 r2[0] * O.x + r2[1] * O.y + r2[2] * O.z + r2[3]),
-					 mk3(r0[0] * D.x + r0[1] * D.y + r0[2] * D.z, r1[0] * D.x + r1[1] * D.y + r1[2] * D.z,
-						 r2[0] * D.x + r2[1] * D.y + r2[2] * D.z),
+			const float m0[4] = {r0[0], r0[1], r0[2], r0[3]}, m1[4] = {r1[0], r1[1], r1[2], r1[3]}, m2[4] = {r2[0], r2[1], r2[2], r2[3]};
+			sp.enter(mk3(row_point_r(m0, O), row_point_r(m1, O), row_point_r(m2, O)), mk3(row_dir_r(m0, D), row_dir_r(m1, D), row_dir_r(m2, D)),
 					 act, nodes);
 			cur_inst = (int)ii;
 			cur = root;
@@ -1432,7 +1566,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 					if (active)
 					{
 						pt_primary_ray(q.cam, q.fr.W, q.fr.H, pr.x, pr.y, q.fr.sample_base + pr.sample, O, D);
-						q.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
+						if (q.cam.aperture != 0.0f) // (pinhole: no origin record, extend_item)
+							q.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
 						q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
 					}
 				}
@@ -1962,8 +2097,231 @@ void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uin
 	for (uint32_t r = 0; r < (total + RNG_RUN - 1) / RNG_RUN; r++)
 		rng_states_item(states, base_state, jump_table, total, r);
 }
+
+// ---- the packet form of the pt primary wave (device: trace_packet / k_primary_packet), one wave = 64 array entries ---------------
+// The same steps in the same order with the same arithmetic — ballots are loops, v_readlane / v_writelane are array accesses —
+// so that the CPU tier checks the algorithm (stack discipline, partial child order, mixed direction signs, instances) against
+// the per-lane traversal and the oracle.
+namespace packet_emu
+{
+constexpr int WAVE = 64;
+struct Space
+{
+	f3 o[WAVE], d[WAVE], id[WAVE], noid[WAVE];
+	uint32_t off_n[3], off_f[3];
+	bool mixed;
+	void enter(const f3 *o_, const f3 *d_, unsigned long long act)
+	{
+		unsigned long long mx = 0, my = 0, mz = 0;
+		for (int l = 0; l < WAVE; l++)
+		{
+			o[l] = o_[l], d[l] = d_[l];
+			id[l] = mk3(safe_rcp(d[l].x), safe_rcp(d[l].y), safe_rcp(d[l].z));
+			noid[l] = mk3(-(o[l].x * id[l].x), -(o[l].y * id[l].y), -(o[l].z * id[l].z));
+			mx |= (unsigned long long)(id[l].x < 0.0f) << l, my |= (unsigned long long)(id[l].y < 0.0f) << l, mz |= (unsigned long long)(id[l].z < 0.0f) << l;
+		}
+		mx &= act, my &= act, mz &= act;
+		mixed = (mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act);
+		off_n[0] = mx ? 48u : 0u, off_f[0] = mx ? 0u : 48u;
+		off_n[1] = my ? 64u : 16u, off_f[1] = my ? 16u : 64u;
+		off_n[2] = mz ? 80u : 32u, off_f[2] = mz ? 32u : 80u;
+	}
+};
+struct Stack
+{
+	uint32_t s0[WAVE];
+	uint32_t sp = 1u;
+	Stack()
+	{
+		for (int l = 0; l < WAVE; l++)
+			s0[l] = 0u;
+		s0[0] = ENTRY_DONE;
+	}
+	void push(uint32_t e) { s0[sp++ & 63u] = e; }
+	uint32_t pop() { return s0[--sp & 63u]; }
+	void push3(uint32_t ea, uint32_t na, uint32_t eb, uint32_t nb, uint32_t ec, uint32_t nc)
+	{
+		s0[sp & 63u] = ea, s0[(sp + na) & 63u] = eb, s0[(sp + na + nb) & 63u] = ec;
+		sp += na + nb + nc;
+	}
+};
+template <bool COUNT> void trace(const SceneView &sc, const bool *active, const f3 *O, const f3 *D, float t_min, Hit *hit, TStat &st)
+{
+	unsigned long long act = 0;
+	for (int l = 0; l < WAVE; l++)
+	{
+		act |= (unsigned long long)active[l] << l;
+		hit[l].t = active[l] ? hit[l].t : -3.0e38f;
+	}
+	if (act == 0ull)
+		return;
+	int ref_lane = 0;
+	while (!((act >> ref_lane) & 1ull))
+		ref_lane++;
+	uint32_t nact = 0;
+	for (int l = 0; l < WAVE; l++)
+		nact += active[l] ? 1u : 0u;
+	static thread_local Space sp;
+	sp.enter(O, D, act);
+	Stack stk;
+	int cur_inst = -1;
+	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	const char *const nodes = (const char *)sc.nodes4f;
+	for (;;)
+	{
+		while (!(cur & ENTRY_LEAF))
+		{
+			const Node4f &nd = *(const Node4f *)(nodes + ((size_t)(cur & ENTRY_INDEX_MASK) << 7));
+			float tk_ref[4];
+			unsigned long long m[4];
+			for (int k = 0; k < 4; k++)
+			{
+				m[k] = 0ull;
+				for (int l = 0; l < WAVE; l++)
+				{
+					float tmin, tmax;
+					if (!sp.mixed)
+					{
+						const float *nx = (const float *)((const char *)&nd + sp.off_n[0]), *ny = (const float *)((const char *)&nd + sp.off_n[1]);
+						const float *nz = (const float *)((const char *)&nd + sp.off_n[2]), *fx = (const float *)((const char *)&nd + sp.off_f[0]);
+						const float *fy = (const float *)((const char *)&nd + sp.off_f[1]), *fz = (const float *)((const char *)&nd + sp.off_f[2]);
+						tmin = fmaxf(fmaxf(fmaf(nx[k], sp.id[l].x, sp.noid[l].x), fmaf(ny[k], sp.id[l].y, sp.noid[l].y)), fmaf(nz[k], sp.id[l].z, sp.noid[l].z));
+						tmax = fminf(fminf(fmaf(fx[k], sp.id[l].x, sp.noid[l].x), fmaf(fy[k], sp.id[l].y, sp.noid[l].y)), fmaf(fz[k], sp.id[l].z, sp.noid[l].z));
+					}
+					else
+					{
+						const float ax = fmaf(nd.lo[0][k], sp.id[l].x, sp.noid[l].x), bx = fmaf(nd.hi[0][k], sp.id[l].x, sp.noid[l].x);
+						const float ay = fmaf(nd.lo[1][k], sp.id[l].y, sp.noid[l].y), by = fmaf(nd.hi[1][k], sp.id[l].y, sp.noid[l].y);
+						const float az = fmaf(nd.lo[2][k], sp.id[l].z, sp.noid[l].z), bz = fmaf(nd.hi[2][k], sp.id[l].z, sp.noid[l].z);
+						tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+						tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+					}
+					const float tk = fmaxf(tmin, 0.0f);
+					if (l == ref_lane)
+						tk_ref[k] = tk;
+					if (tk < fminf(tmax, hit[l].t))
+						m[k] |= 1ull << l;
+				}
+				if (sp.mixed && nd.entry[k] == ENTRY_EMPTY)
+					m[k] = 0ull;
+			}
+			if (COUNT)
+				st.inner += nact;
+			uint32_t kk[4], ee[4];
+			for (int k = 0; k < 4; k++)
+				kk[k] = m[k] ? fbits(tk_ref[k]) : 0xFFFFFFFFu, ee[k] = nd.entry[k];
+			auto pswap = [&](int a, int b) {
+				if (kk[b] < kk[a])
+				{
+					const uint32_t tk_ = kk[a], te_ = ee[a];
+					kk[a] = kk[b], ee[a] = ee[b], kk[b] = tk_, ee[b] = te_;
+				}
+			};
+			pswap(0, 1), pswap(2, 3), pswap(0, 2);
+#if RT_PACKET_FULL_SORT
+			pswap(1, 3), pswap(1, 2);
+#endif
+			stk.push3(ee[3], kk[3] != 0xFFFFFFFFu, ee[2], kk[2] != 0xFFFFFFFFu, ee[1], kk[1] != 0xFFFFFFFFu);
+			cur = kk[0] != 0xFFFFFFFFu ? ee[0] : stk.pop();
+		}
+		if (cur == ENTRY_DONE)
+			break;
+		if (cur == ENTRY_SENTINEL)
+		{
+			sp.enter(O, D, act);
+			cur_inst = -1;
+			cur = stk.pop();
+			continue;
+		}
+		if (cur & ENTRY_TLAS)
+		{
+			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
+			const Instance &in = sc.instances[ii];
+			stk.push(ENTRY_SENTINEL);
+			static thread_local f3 o2[WAVE], d2[WAVE];
+			for (int l = 0; l < WAVE; l++)
+			{
+				o2[l] = mk3(row_point_r(in.inv, O[l]), row_point_r(in.inv + 4, O[l]), row_point_r(in.inv + 8, O[l]));
+				d2[l] = mk3(row_dir_r(in.inv, D[l]), row_dir_r(in.inv + 4, D[l]), row_dir_r(in.inv + 8, D[l]));
+			}
+			sp.enter(o2, d2, act);
+			cur_inst = (int)ii;
+			cur = in.root_entry;
+			continue;
+		}
+		{
+			const uint32_t first = cur & ENTRY_FIRST_MASK, count = ((cur >> 27) & 7u) + 1u;
+			for (uint32_t i = 0; i < count; i++)
+			{
+				const f4 *tv = sc.tri_verts + 3u * (first + i);
+				const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+				if (COUNT)
+					st.tris += nact;
+				for (int l = 0; l < WAVE; l++)
+					if (tri_test(sp.o[l], sp.d[l], t_min, hit[l].t, xyz(v0), xyz(v1), xyz(v2), hit[l].u, hit[l].v))
+					{
+						hit[l].prim = (int)fbits(v0.w);
+						hit[l].inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);
+					}
+			}
+			cur = stk.pop();
+		}
+	}
+}
+template <bool COUNT> void primary(const Params &p, uint32_t count)
+{
+	TStat st;
+	st.inner = 0, st.tris = 0, st.lds = 0;
+	unsigned long long nrays = 0;
+	for (uint32_t base = 0; base < count; base += WAVE)
+	{
+		bool active[WAVE];
+		f3 O[WAVE], D[WAVE];
+		Hit h[WAVE];
+		for (int l = 0; l < WAVE; l++)
+		{
+			const uint32_t idx = base + (uint32_t)l;
+			active[l] = idx < count;
+			O[l] = mk3(0, 0, 0), D[l] = mk3(0, 0, 1);
+			if (active[l])
+			{
+				const PixelRef pr = slot_to_pixel(p.fr, idx);
+				active[l] = pr.valid;
+				if (active[l])
+				{
+					pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O[l], D[l]);
+					if (p.cam.aperture != 0.0f)
+						p.wv.org[0][idx] = mk4(O[l].x, O[l].y, O[l].z, ubits((idx << 1) | 1u));
+					p.wv.dir[0][idx] = mk4(D[l].x, D[l].y, D[l].z, 0.0f);
+				}
+			}
+			h[l].t = 1e34f, h[l].u = 0.0f, h[l].v = 0.0f, h[l].prim = -1, h[l].inst = -1;
+		}
+		trace<COUNT>(p.sc, active, O, D, 1e-5f, h, st);
+		for (int l = 0; l < WAVE; l++)
+			if (active[l])
+			{
+				const uint32_t idx = base + (uint32_t)l;
+				p.wv.hit0[idx] = mk4(h[l].t, h[l].u, h[l].v, ubits((uint32_t)h[l].prim));
+				p.wv.hit0_inst[idx] = h[l].inst;
+				nrays++;
+			}
+	}
+	if (COUNT)
+	{
+		WaveCounters *const wc = p.wv.counters;
+		wc->inner_extend += st.inner, wc->tris_extend += st.tris, wc->rays_extend += nrays;
+	}
+}
+} // namespace packet_emu
+
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
+	if (gen == GEN_PT && (p.refill & 8u))
+	{
+		count ? packet_emu::primary<true>(p, max_items) : packet_emu::primary<false>(p, max_items);
+		return;
+	}
 	Ctx ctx(p);
 	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : max_items;
 	for (uint32_t i = 0; i < n; i++)

@@ -51,6 +51,45 @@ RT_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi)
 RT_FN bool any_nan(f3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
 RT_FN float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
+// Arithmetic with a FIXED shape.  A compiler is free to contract a * b + c into one fma wherever it sees the pattern, and sees
+// it differently in every context a function is inlined into: the same ray against the same triangle then gives hit records
+// that differ in the last bit between two kernels (the packet form of the primary wave and the per-lane form; the wave-wide
+// triangle phase and a lane's own loop), between the device and the host emulation, and between those and the oracle.  The
+// functions whose results travel between kernels — the triangle test, the primary ray, the instance transform — therefore say
+// where they fuse: fmaf() where a fused multiply-add is meant, rounded() around every product that must be rounded on its own
+// (an empty asm hides it from the contraction pass of hipcc, g++ and gcc alike; it emits nothing).  oracle/rfw_oracle.c states
+// the same shapes, so that all three agree to the bit wherever the inputs do (the device's 1-ulp v_rcp_f32 aside).
+RT_FN float rounded(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("" : "+v"(x));
+#elif defined(__x86_64__)
+	asm("" : "+x"(x));
+#else
+	volatile float y = x;
+	x = y;
+#endif
+	return x;
+}
+RT_FN float dot_r(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, rounded(a.x * b.x))); }
+RT_FN f3 cross_r(f3 a, f3 b)
+{
+	return mk3(fmaf(a.y, b.z, -rounded(b.y * a.z)), fmaf(a.z, b.x, -rounded(b.z * a.x)), fmaf(a.x, b.y, -rounded(b.x * a.y)));
+}
+// p + a * s + b * t, each component two fused multiply-adds onto p
+RT_FN f3 madd2_r(f3 p, f3 a, float s, f3 b, float t)
+{
+	return mk3(fmaf(b.x, t, fmaf(a.x, s, p.x)), fmaf(b.y, t, fmaf(a.y, s, p.y)), fmaf(b.z, t, fmaf(a.z, s, p.z)));
+}
+RT_FN f3 normalize_r(f3 a)
+{
+	const float inv = 1.0f / sqrtf(dot_r(a, a));
+	return mk3(rounded(a.x * inv), rounded(a.y * inv), rounded(a.z * inv));
+}
+// one row of a 3x4 transform applied to a point (w = 1) / a direction (w = 0)
+RT_FN float row_point_r(const float *r, f3 p) { return fmaf(r[2], p.z, fmaf(r[1], p.y, rounded(r[0] * p.x))) + r[3]; }
+RT_FN float row_dir_r(const float *r, f3 d) { return fmaf(r[2], d.z, fmaf(r[1], d.y, rounded(r[0] * d.x))); }
+
 RT_FN uint32_t f2u_sat(float f)
 {
 	if (!(f > 0.0f))
@@ -263,11 +302,12 @@ RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x
 		const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
 		if ((r2 + r3) > 1.0f)
 			r2 = 1.0f - r2, r3 = 1.0f - r3;
-		const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
-		O = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
+		// (fixed-shape arithmetic from here on: see rounded())
+		const float xr = fmaf(x2, r3, rounded(x1 * r2)), yr = fmaf(y2, r3, rounded(y1 * r2));
+		O = madd2_r(cam.pos, cam.right, rounded(xr * cam.aperture), cam.up, rounded(yr * cam.aperture));
 	}
-	const float u = ((float)x + r0) * (1.0f / (float)W), v = ((float)y + r1) * (1.0f / (float)H);
-	D = normalize(((cam.p1 + cam.right * u) + cam.up * v) - O);
+	const float u = rounded(((float)x + r0) * (1.0f / (float)W)), v = rounded(((float)y + r1) * (1.0f / (float)H));
+	D = normalize_r(madd2_r(cam.p1, cam.right, u, cam.up, v) - O);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -293,7 +333,8 @@ constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 // (profiles/micro/gather_micro.hip: 9.6 TB/s chip-wide whatever the table size) and that rate bounds the traversal
 // kernels; the same rows from LDS cost 4 cycles per 64 lanes, and every ray walks through these nodes.
 #ifndef RT_LDS_NODES
-#define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth)
+#define RT_LDS_NODES 120 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth); 120: with the
+						 // 512-byte pair map of the wave-wide triangle phase the closest-hit kernels' LDS stays at 20 KiB = 8 workgroups per CU
 #endif
 constexpr uint32_t MAX_LDS_NODES = RT_LDS_NODES;
 constexpr uint32_t TOP_ROWS = 4; // a compressed node is exactly four rows (the emulation's `top` aliases the node table)
@@ -375,21 +416,22 @@ RT_FN float ub3(uint32_t x) { return (float)(x >> 24); }
 // Möller–Trumbore with the reference's rejections: |a| < 1e-6, u outside [0,1], v < 0, u+v > 1, t <= t_min, t >= t.
 RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo)
 {
+	// (fixed-shape arithmetic: see rounded())
 	const f3 e1 = p1 - p0, e2 = p2 - p0;
-	const f3 h = cross(d, e2);
-	const float a = dot(e1, h);
+	const f3 h = cross_r(d, e2);
+	const float a = dot_r(e1, h);
 	if (a > -1e-6f && a < 1e-6f)
 		return false;
 	const float f = fast_rcp(a);
 	const f3 s = o - p0;
-	const float u = f * dot(s, h);
+	const float u = rounded(f * dot_r(s, h));
 	if (u < 0.0f || u > 1.0f)
 		return false;
-	const f3 q = cross(s, e1);
-	const float v = f * dot(d, q);
+	const f3 q = cross_r(s, e1);
+	const float v = rounded(f * dot_r(d, q));
 	if (v < 0.0f || u + v > 1.0f)
 		return false;
-	const float tt = f * dot(e2, q);
+	const float tt = rounded(f * dot_r(e2, q));
 	if (tt > t_min && t > tt)
 	{
 		t = tt, uo = u, vo = v;
@@ -416,10 +458,19 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 0
 #endif
-template <bool ANY, bool COUNT>
-struct Traverser
+// WORLD = false: the lane does not keep the world-space ray beside the ray of the current space — the caller hands it to
+// visit() on the two occasions it is needed (entering and leaving an instance), e.g. by reading the ray record again (the
+// persistent-lane kernels: six registers less per lane, and instance switches are rare once static geometry is linked flat).
+template <bool WORLD> struct TraverserWorld
 {
-	f3 O, D;		 // world-space ray
+	f3 O, D; // world-space ray
+};
+template <> struct TraverserWorld<false>
+{
+};
+template <bool ANY, bool COUNT, bool WORLD = true>
+struct Traverser : TraverserWorld<WORLD>
+{
 	f3 o, d, id, oid; // ray in the current space (world, or the object space of cur_inst), 1/d, o/d
 	bool neg_x, neg_y, neg_z; // direction signs: which of a child's two planes per axis is the entry plane
 	int cur_inst;
@@ -442,22 +493,20 @@ struct Traverser
 
 	RT_FN void begin(const SceneView &sc, f3 O_, f3 D_, float t_min_, float t_max)
 	{
-		O = O_, D = D_, t_min = t_min_;
+		if constexpr (WORLD)
+			this->O = O_, this->D = D_;
+		t_min = t_min_;
 		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
 		cur_inst = -1, sp = 0, held = ENTRY_DONE;
-		enter_space(O, D);
+		enter_space(O_, D_);
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
 	}
 	// the ray in the object space of an instance (3x4 inverse, direction NOT renormalised so that t is shared:
 	// top_level_bvh.cpp:104-168)
-	RT_FN void enter_instance(const Instance &in)
+	RT_FN void enter_instance(const Instance &in, f3 O, f3 D)
 	{
-		enter_space(mk3(in.inv[0] * O.x + in.inv[1] * O.y + in.inv[2] * O.z + in.inv[3],
-						in.inv[4] * O.x + in.inv[5] * O.y + in.inv[6] * O.z + in.inv[7],
-						in.inv[8] * O.x + in.inv[9] * O.y + in.inv[10] * O.z + in.inv[11]),
-					mk3(in.inv[0] * D.x + in.inv[1] * D.y + in.inv[2] * D.z,
-						in.inv[4] * D.x + in.inv[5] * D.y + in.inv[6] * D.z,
-						in.inv[8] * D.x + in.inv[9] * D.y + in.inv[10] * D.z));
+		enter_space(mk3(row_point_r(in.inv, O), row_point_r(in.inv + 4, O), row_point_r(in.inv + 8, O)),
+					mk3(row_dir_r(in.inv, D), row_dir_r(in.inv + 4, D), row_dir_r(in.inv + 8, D)));
 	}
 	RT_FN bool done() const { return cur == ENTRY_DONE && (!RT_SPECULATE || held == ENTRY_DONE); }
 	// a triangle leaf (not a top-level leaf, the sentinel or ENTRY_DONE, which all carry the ENTRY_TLAS bit)
@@ -659,6 +708,12 @@ struct Traverser
 	// phase 2: the leaf in hand — enter an instance (top-level leaf) or test the triangles, then fetch the next entry
 	RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st)
 	{
+		static_assert(WORLD, "a traverser without the world-space ray is told it: visit(sc, stk, st, world)");
+		visit(sc, stk, st, [this](f3 &O_, f3 &D_) { O_ = this->O, D_ = this->D; });
+	}
+	// world(O, D): the world-space ray of this lane (asked for when an instance is entered or left)
+	template <typename F> RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st, F world)
+	{
 		uint32_t leaf = cur;
 		const bool from_held = RT_SPECULATE && held != ENTRY_DONE;
 		if (from_held)
@@ -668,6 +723,8 @@ struct Traverser
 		else if (cur == ENTRY_SENTINEL)
 		{
 			// leaving an instance: back to the world-space ray
+			f3 O, D;
+			world(O, D);
 			enter_space(O, D);
 			cur_inst = -1;
 			cur = pop(stk);
@@ -679,7 +736,9 @@ struct Traverser
 			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
 			const Instance &in = sc.instances[ii];
 			push(stk, ENTRY_SENTINEL);
-			enter_instance(in);
+			f3 O, D;
+			world(O, D);
+			enter_instance(in, O, D);
 			cur_inst = (int)ii;
 			cur = in.root_entry;
 			return;

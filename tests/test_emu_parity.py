@@ -468,3 +468,62 @@ def _gated_depth0_connections(pkg, make_ctx, make_oracle, w, h):
 
 def test_skipped_depth0_connections_leave_no_stale_terms(pkg, make_emu, make_oracle):
     _gated_depth0_connections(pkg, make_emu, make_oracle, 48, 32)
+
+
+PACKET_CASES = ["cornell_instances", "terrain", "axis_camera_mixed_signs", "lens", "scaled_atrium"]
+
+
+@pytest.mark.parametrize("case", PACKET_CASES)
+def test_packet_form_of_the_primary_wave(pkg, make_emu, make_oracle, case):
+    packet_form_of_the_primary_wave(pkg, make_emu, make_oracle, case, 96, 64)
+
+
+def packet_form_of_the_primary_wave(pkg, make_emu, make_oracle, case, w, h):
+    """refill bit 3: the pt primary wave walks the tree once per wave (kernels.hip: trace_packet; here its array-of-64-lanes
+    restatement of the same steps): every ray still gets exactly its closest hit — primary hit records bit-equal to the
+    per-lane traversal, images bit-equal, for every sample-group size (a wave = 64 / g pixels x g samples), with instances
+    (the wave-uniform instance switch), with a camera looking down an axis (lanes of one wave disagree about direction signs:
+    the min / max plane-pair path and its unused-slot rule) and with a lens (origins differ per lane).
+    (make_emu: the context under test — the host emulation here, librfwhip.so on the GPU in tests/test_parity_gpu.py.)"""
+    if case == "cornell_instances":
+        scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+    elif case == "terrain":
+        scene = pkg.scenes.terrain(n=40, width=w, height_px=h)
+    elif case == "axis_camera_mixed_signs":
+        scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+        x, y, z = scene.camera.position
+        scene.camera.look_at((0.0, y, z), (0.0, y, 0.0))  # straight down +z: d.x and d.y change sign inside the centre tiles
+    elif case == "lens":
+        scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+        scene.camera.aperture = 0.08
+    else:
+        scene = pkg.scenes.atrium(w, h, columns=4, tex_size=16)
+    out = {}
+    for refill in (7, 15):
+        for g in (1, 8, 64):
+            c = make_emu()
+            c.init(w, h)
+            scene.upload(c)
+            for k, v in {"integrator": "pt", "spp": 64 if g == 64 else 8, "max_depth": 2, "refill": refill, "sample_group": g}.items():
+                c.set_setting(k, v)
+            c.render_frame(scene.camera, pkg.RESET)
+            st = c.get_stats()
+            out[(refill, g)] = (c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount))
+    for g in (1, 8, 64):
+        (ia, ha, ca), (ib, hb, cb) = out[(7, g)], out[(15, g)]
+        for k in ha:
+            assert np.array_equal(ha[k], hb[k]), (case, g, k, int((ha[k] != hb[k]).sum()))
+        assert ca == cb, (case, g, ca, cb)
+        assert np.array_equal(ia, ib), (case, g)
+    assert (out[(15, 1)][1]["prim"] >= 0).mean() > 0.3
+    # ... and against the oracle's own traversal (its BVH2, its instancing loop), one sample per pixel
+    hits = []
+    for c, extra in ((make_emu(), {"refill": 15}), (make_oracle(), {})):
+        c.init(w, h)
+        scene.upload(c)
+        for k, v in dict({"integrator": "pt", "spp": 1, "max_depth": 2}, **extra).items():
+            c.set_setting(k, v)
+        c.render_frame(scene.camera, pkg.RESET)
+        hits.append(c.primary_hits())
+    a, b = hits
+    assert (a["prim"] != b["prim"]).mean() <= 5e-4 and (a["inst"] != b["inst"]).mean() <= 5e-4

@@ -413,7 +413,9 @@ def test_bench_workload_path_traced_image_vs_oracle(pkg, make_hip, make_oracle):
     decided in the last bit, and sin/cos/rcp differ in the last bit between libm and the GPU.  Stated tolerance: >= 97 % of
     the pixels agree to 1e-3 (every decision of all 8 paths fell the same way), the rest are pixels where a path flipped
     (at most 1.5 % beyond 3e-2); nothing is biased: image mean within 1e-3, 8x8-block means within 0.5 % on average, and
-    the per-depth wave sizes within 2e-4."""
+    the per-depth wave sizes within 1.5e-3: about 2 % of the million paths re-decide somewhere (the flipped pixels above), each
+    a coin toss for the depth-2 count, so two renders differ there by a standard deviation of ~30 of 95 000 = 3e-4 — the bound
+    is five of them (2e-4 had held by luck: one change of operation order in the triangle test and the count moved by 41)."""
     scene = pkg.scenes.terrain(n=708, width=480, height_px=270)
     hip, ref = _pair(pkg, make_hip, make_oracle, scene, 480, 270, {"integrator": "pt", "spp": 8, "max_depth": 2})
     a, b = hip.framebuffer(), ref.framebuffer()
@@ -428,7 +430,8 @@ def test_bench_workload_path_traced_image_vs_oracle(pkg, make_hip, make_oracle):
     sa, sb = hip.get_stats(), ref.get_stats()
     for name in ("primaryCount", "secondaryCount", "deepCount", "shadowCount"):
         x, y = getattr(sa, name), getattr(sb, name)
-        assert abs(x - y) <= 2e-4 * y, (name, x, y)
+        assert abs(x - y) <= 1.5e-3 * y, (name, x, y)
+    assert sa.primaryCount == sb.primaryCount
 
 
 def test_bench_workload_flips_isolated_gpu_arithmetic_vs_restatement(pkg, make_hip, make_emu, make_oracle):
@@ -573,3 +576,12 @@ def test_skipped_depth0_connections_leave_no_stale_terms_on_the_gpu(pkg, make_hi
     the slots left to it — at a size where the persistent-lane kernels run (test_emu_parity.py has the scene)."""
     from test_emu_parity import _gated_depth0_connections
     _gated_depth0_connections(pkg, make_hip, make_oracle, 480, 272)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cornell_instances", "terrain", "axis_camera_mixed_signs", "lens", "scaled_atrium"])
+def test_packet_form_of_the_primary_wave_on_the_gpu(pkg, make_hip, make_oracle, case):
+    """k_primary_packet (wave-uniform traversal: scalar node fetches, one stack per wave) against the per-lane kernels on the
+    MI355X: primary hit records, wave counts and images bit-equal for sample groups of 1, 8 and 64; hits against the oracle."""
+    from test_emu_parity import packet_form_of_the_primary_wave
+    packet_form_of_the_primary_wave(pkg, make_hip, make_oracle, case, 480, 270)

@@ -46,8 +46,11 @@ for name, scene, s, g in (("terrain%d" % grid, pkg.scenes.terrain(n=grid, width=
         scene = last
     last = scene
     res = {}
-    for refill in (7, 15):
+    for refill in (0, 7, 15):
         res[refill] = run(scene, refill, s, g)
+    print(name, "one-ray-per-lane kernels vs persistent lanes: image max diff %.3g, differing pixels %d, stats %s / %s" % (
+        float(np.abs(res[0][1] - res[7][1]).max()), int((np.abs(res[0][1] - res[7][1]).max(-1) > 0).sum()),
+        [res[0][2].secondaryCount, res[0][2].deepCount, res[0][2].shadowCount], [res[7][2].secondaryCount, res[7][2].deepCount, res[7][2].shadowCount]), flush=True)
     (h7, i7, s7, t7), (h15, i15, s15, t15) = res[7], res[15]
     same = {k: bool(np.array_equal(h7[k], h15[k])) for k in h7} if isinstance(h7, dict) else None
     if isinstance(h7, dict):
