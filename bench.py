@@ -112,14 +112,21 @@ def parse():
                          "triangles) under the same protocol, e.g. for its 8-GPU strip split")
     ap.add_argument("--integrator", default="pt", choices=["pt", "parity"])
     ap.add_argument("--max-depth", type=int, default=2)
-    ap.add_argument("--refill", type=int, default=7, help="persistent-lane traversal: bit 0 bounce waves, bit 1 shadow waves, bit 2 primary wave")
+    ap.add_argument("--refill", type=int, default=15, help="persistent-lane traversal: bit 0 bounce waves, bit 1 shadow waves, bit 2 primary wave, "
+                                                             "bit 3 the primary wave in packet form (wave-uniform traversal)")
     ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches (HIP streams) per render call")
     ap.add_argument("--overlap", type=int, default=-1, help="connection waves on a second stream per sub-batch: 0 / 1 / -1 = by launch size")
     ap.add_argument("--lds-nodes", type=int, default=-1,
                     help="top-of-tree 4-wide nodes kept in LDS by the traversal kernels (-1: kernel capacity, 0: off)")
     ap.add_argument("--gather", default="comm", choices=["comm", "torch"],
-                    help="N > 1: comm = rfwhip_comm_* (host C++ -> RCCL send / recv below the C ABI, the default); torch = "
-                         "torch.distributed.gather of the local strips + rfwhip_deinterleave_stream (the round-2 path)")
+                    help="N > 1: comm = rfwhip_comm_* (host C++ -> RCCL send / recv below the C ABI, the default — a failure to set it "
+                         "up is an ERROR, never a silent change of path); torch = torch.distributed.gather of the local strips + "
+                         "rfwhip_deinterleave_stream, only when asked for (the round-2 path)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "group"],
+                    help="N > 1: ranks = one process per GPU under torch.distributed.run (the driver's launch); group = ONE process, one "
+                         "host thread, rfwhip_group_* over --gpus devices — the plugin's host model (RFW/system/src/rfw/app.cpp:3-26); "
+                         "run it as plain `python bench.py --gpus N --mode group`")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"], help="--mode group: transport of the gather")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="N > 1, --gather torch: 1 = stream-ordered present/gather/de-interleave overlapping the next step's "
                          "kernels; 0 = host-synchronous gather per step (reports gather_ms_per_step)")
@@ -147,8 +154,66 @@ def load_stage_counters(path, scene_name, spp, streams):
     return pm, pm.get("csrc_hash") == csrc_hash()
 
 
+def main_group(args):
+    """--mode group: one process, one host thread, rfwhip_group_* over args.gpus devices (render on every device, ONE gather per
+    step issued by the library, nothing blocks the host in between) — the plugin's host model, measured under the bench protocol."""
+    import torch
+    from __graft_entry__ import load_package
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--mode group is ONE process: run `python bench.py --gpus N --mode group` without torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rendercore has no CPU path")
+    one_device = os.environ.get("RFWHIP_BENCH_ONE_DEVICE") == "1"  # development aid: n contexts on GPU 0, peer transport
+    n = args.gpus
+    if not one_device and torch.cuda.device_count() < n:
+        raise SystemExit("--gpus %d --mode group: only %d device(s) visible" % (n, torch.cuda.device_count()))
+    pkg = load_package()
+    scene = (pkg.scenes.atrium(args.width, args.height) if args.workload == "atrium" else
+             pkg.scenes.terrain(n=args.grid, width=args.width, height_px=args.height))
+    g = pkg.render_group([0] * n if one_device else list(range(n)), "peer" if one_device else args.transport)
+    g.init(args.width, args.height)
+    scene.upload(g)
+    for k, v in (("integrator", args.integrator), ("spp", args.spp), ("max_depth", args.max_depth), ("refill", args.refill),
+                 ("streams", args.streams), ("lds_nodes", args.lds_nodes), ("overlap", args.overlap)):
+        g.set_setting(k, v)
+    extra = {}
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        g.set_setting(k, v)
+        extra[k] = v
+    if args.set:
+        g.update()
+
+    def step(first):
+        g.render_async(scene.camera, pkg.RESET if first else pkg.CONVERGE)
+        g.gather()
+    for k in range(args.warmup):
+        step(k == 0)
+    g.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k == 0)
+    g.wait()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    img = g.framebuffer()
+    out = {"metric": "Msamples/sec at 1920x1080, 1M-tri scene; 1/2/4/8-GPU tile scaling", "value": round(float(args.width) * args.height * args.spp * args.steps / elapsed / 1e6, 3),
+           "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s: %d triangles, %dx%d, %s integrator depth %d, %d spp per step" % (scene.name, scene.triangle_count(), args.width, args.height, args.integrator, args.max_depth, args.spp),
+                      "parallelism": "ONE process / one host thread drives %d contexts (rfwhip_group_*): image strips of 8 rows interleaved over the ranks, one gather per step into rank 0's HBM" % n,
+                      "gather": "group:%s%s" % (g.transport, " (all contexts on device 0: development aid, the number means nothing)" if one_device else ""),
+                      "spp_per_step": args.spp, "streams": args.streams, "settings": extra or None, "csrc_hash": csrc_hash()},
+           "roofline": None, "cpu_baseline": None, "image_mean": float(img[..., :3].mean())}
+    print(json.dumps(out))
+    g.destroy()
+
+
 def main():
     args = parse()
+    if args.mode == "group":
+        return main_group(args)
     import numpy as np
     import torch
     from __graft_entry__ import load_package
@@ -226,17 +291,11 @@ def main():
                 idbuf.copy_(torch.from_numpy(np.frombuffer(pkg.comm_unique_id(), dtype=np.uint8).copy()))
             dist.broadcast(idbuf, src=0)
             comm = pkg.RenderComm(ctx, idbuf.cpu().numpy().tobytes())
-        except Exception as e:  # loudly recorded, never silent: config.gather says which path produced the number
-            comm = None
-            gather_mode = "torch (rfwhip_comm_create failed: %s)" % str(e)[:200]
-            ok = torch.tensor([0], device="cpu" if one_device else dev)
-        else:
-            ok = torch.tensor([1], device="cpu" if one_device else dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
-        if int(ok.item()) == 0 and comm is not None:
-            comm.destroy()
-            comm = None
-            gather_mode = "torch (rfwhip_comm_create failed on another rank)"
+        except Exception as e:
+            # a SCALE number must come from host C++ -> RCCL; another path is taken only when asked for (--gather torch)
+            raise SystemExit("bench.py: rfwhip_comm_create failed on rank %d (%s) — the library's RCCL gather is the N > 1 path; "
+                             "run with --gather torch to measure the torch.distributed gather instead, or RFWHIP_TRANSPORT=peer "
+                             "with --mode group to take RCCL out of the picture" % (rank, str(e)[:300]))
     local_fb = gathered_flat = gathered = chain_stream = None
     if world > 1 and comm is None:
         local_fb = torch.empty((local_rows, W, 4), dtype=torch.float32, device=dev)

@@ -842,13 +842,20 @@ struct ChunkQueue
 #define RT_TRACE_BLOCK 256
 #endif
 constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
+#if RT_WAVE_TRIS
+#define RT_TRIMAP_DECL(NTHREADS) __shared__ uint16_t s_trimap[(NTHREADS)];
+#define RT_TRIMAP_SET ctx.tri_map = s_trimap + (threadIdx.x & ~63u);
+#else
+#define RT_TRIMAP_DECL(NTHREADS)
+#define RT_TRIMAP_SET
+#endif
 #define RT_STACK_DECL_N(DEPTH, NTHREADS)                                                     \
 	__shared__ uint32_t s_stack[(DEPTH) * (NTHREADS)];                                      \
 	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
-	__shared__ uint16_t s_trimap[(NTHREADS)];                                               \
+	RT_TRIMAP_DECL(NTHREADS)                                                                \
 	uint32_t spill_[SPILL_STACK];                                                           \
 	Ctx ctx;                                                                                \
-	ctx.tri_map = s_trimap + (threadIdx.x & ~63u);                                          \
+	RT_TRIMAP_SET                                                                           \
 	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
 	ctx.stk.stride = (NTHREADS);                                                            \
 	ctx.stk.spill = spill_;                                                                 \
@@ -973,8 +980,16 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 // A phase is ONE round: the owners whose pairs fit into 64 lanes; the others keep their leaf for the next phase.  Only a
 // 128-byte lane map per wave lives in LDS (pair -> owner lane and triangle number).
 // ----------------------------------------------------------------------------------------------------------------
+// Measured on the MI355X (terrain_1002k, 256 spp per step) and OFF: bit-identical images and wave counts (tools/dev/packet_probe.py
+// compares against the one-ray-per-lane kernels), but the bounce wave takes 6.80 instead of 6.37 ms and the shadow wave 8.79 instead
+// of 8.04 ms per 64-spp sub-batch, 4070 against 4236 Msamples/s (vote thresholds 16 / 24 / 32 / 40: 3997 / 4067 / 4090 / 4070; a
+// second round for the overflow of a phase instead of carrying it over: 4101 against 4213).  What the pooling saves — leaves hold
+// 1..4 triangles, so a lane's own loop runs three to four iterations at 12-19 lanes — it spends again on getting the work to the
+// lanes and back: four ballots and eight mbcnt for the prefix sum, the scatter of the pair map and its read-back through LDS,
+// eight ds_bpermute_b32 for the foreign ray and five per accepted hit for the way back, each a dependent LDS round trip in
+// front of the vertex fetch that the lane's own loop issues straight away.
 #ifndef RT_WAVE_TRIS
-#define RT_WAVE_TRIS 1
+#define RT_WAVE_TRIS 0
 #endif
 __device__ __forceinline__ float wave_fetch(uint32_t src_lane_x4, float v)
 {
@@ -1932,9 +1947,13 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 		else
 			RT_EXT(GEN_RANGED, false);
 	}
-	else if (gen == GEN_PT && (p.refill & 8u))
+	else if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= RT_PRIMARY_STREAM_MIN))
 	{
-		// packet form of the primary wave: no LDS, one wave = one 64-slot group at a time
+		// packet form of the primary wave: no LDS, one wave = one 64-slot group at a time.  MI355X, 1080p terrain, 64 spp per
+		// launch, primary wave per-lane / packet by sample-group size: 1: 9.33 / 9.07 ms, 4: 9.08 / 6.60, 8: 8.87 / 6.39, 16: 8.79 /
+		// 5.52, 32: 8.45 / 5.15, 64: 7.27 / 4.92 — a wave of one pixel's samples reaches the same few leaves, a wave that is an 8x8
+		// tile of different pixels reaches 64 different ones and every lane tests them all.  Small launches of single samples (1-spp
+		// frames: 0.37 against 0.57 ms) keep the one-ray-per-lane kernel with its tile-row-to-XCD dealing.
 		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
 		if (count)
 			hipLaunchKernelGGL((k_primary_packet<true>), gt, bt, 0, st, p, max_items);
@@ -2317,7 +2336,7 @@ template <bool COUNT> void primary(const Params &p, uint32_t count)
 
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
-	if (gen == GEN_PT && (p.refill & 8u))
+	if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= (16u << 20))) // (the device's rule)
 	{
 		count ? packet_emu::primary<true>(p, max_items) : packet_emu::primary<false>(p, max_items);
 		return;

@@ -397,7 +397,7 @@ struct rfwhip_context
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
-	int refill = 7; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave;
+	int refill = 15; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave;
 					// bit 3: the pt primary wave in packet form (wave-uniform traversal, kernels.hip: trace_packet)
 	bool packet_ok = false; // the scene's trees fit the packet kernel's stack and its 32-bit node offsets
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams

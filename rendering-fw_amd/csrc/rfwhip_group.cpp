@@ -26,6 +26,7 @@
 #include <vector>
 
 #if !defined(RFWHIP_HOST_EMULATION)
+#include <stdlib.h>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -173,10 +174,17 @@ struct Rccl
 		if (tried)
 			return false;
 		tried = true;
-		const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		// RFWHIP_RCCL_LIBRARY: another library with the same eight entry points (tests/stub/rccl_stub.cpp walks the RCCL
+		// branch's enqueue order on one device; a site with its own RCCL build points here too)
+		const char *override_lib = getenv("RFWHIP_RCCL_LIBRARY");
+		const char *names[] = {override_lib ? override_lib : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 		for (const char *n : names)
+		{
 			if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
 				break;
+			if (override_lib) // the named library or nothing: no silent change of transport implementation
+				break;
+		}
 		if (!lib)
 			return false;
 #define GR_SYM(F, N) F = (decltype(F))dlsym(lib, N)
@@ -530,6 +538,10 @@ int resolve_transport(int transport, bool distinct_devices, int *out)
 		return rfwhip_internal_set_error(RFWHIP_ERR_UNSUPPORTED, "the host-emulation build has no RCCL");
 	*out = RFWHIP_TRANSPORT_PEER;
 #else
+	// (RFWHIP_RCCL_SHARED_DEVICE=1: for a stand-in library that can serve several ranks on one device — the stub of the tests)
+	const char *shared = getenv("RFWHIP_RCCL_SHARED_DEVICE");
+	if (shared && shared[0] == '1' && getenv("RFWHIP_RCCL_LIBRARY"))
+		distinct_devices = true;
 	if (transport == RFWHIP_TRANSPORT_RCCL && !distinct_devices)
 		return rfwhip_internal_set_error(RFWHIP_ERR_INVALID_ARGUMENT, "RCCL needs one device per rank (a device is listed twice)");
 	if (transport == RFWHIP_TRANSPORT_RCCL && !g_rccl.load())

@@ -333,8 +333,8 @@ constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 // (profiles/micro/gather_micro.hip: 9.6 TB/s chip-wide whatever the table size) and that rate bounds the traversal
 // kernels; the same rows from LDS cost 4 cycles per 64 lanes, and every ray walks through these nodes.
 #ifndef RT_LDS_NODES
-#define RT_LDS_NODES 120 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth); 120: with the
-						 // 512-byte pair map of the wave-wide triangle phase the closest-hit kernels' LDS stays at 20 KiB = 8 workgroups per CU
+#define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth); with RT_WAVE_TRIS
+						 // build with 120: the 512-byte pair map must fit into the same 20 KiB = 8 workgroups per CU
 #endif
 constexpr uint32_t MAX_LDS_NODES = RT_LDS_NODES;
 constexpr uint32_t TOP_ROWS = 4; // a compressed node is exactly four rows (the emulation's `top` aliases the node table)

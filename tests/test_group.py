@@ -223,12 +223,98 @@ def test_group_over_rccl_needs_two_devices(pkg, make_hip):
     g.destroy()
 
 
+_STUB_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from __graft_entry__ import load_package
+pkg = load_package()
+n, w, h, frames = %(n)d, 480, 270, 5
+scene = pkg.scenes.terrain(n=24, width=w, height_px=h)
+settings = {"integrator": "pt", "spp": 2, "max_depth": 2}
+ref = pkg.RenderContext(device=0)
+ref.init(w, h); scene.upload(ref)
+g = pkg.render_group([0] * n, "rccl")
+assert g.transport == "rccl", g.transport
+g.init(w, h); scene.upload(g)
+for k, v in settings.items():
+    ref.set_setting(k, v); g.set_setting(k, v)
+for f in range(frames):
+    ref.render_async(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+ref.wait()
+for f in range(frames):  # nothing blocks the host between the frames and their gathers
+    g.render_async(scene.camera, pkg.RESET if f == 0 else pkg.CONVERGE)
+    g.gather()
+g.wait()
+assert np.array_equal(g.framebuffer(), ref.framebuffer())  # (framebuffer(): one more gather)
+g.destroy()
+print("STUB-OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4])
+def test_rccl_branch_enqueue_order_through_a_stub_transport(pkg, tmp_path, n):
+    """The RCCL branch of rfwhip_group.cpp has never met a second device in this repository's life.  What CAN be checked on one
+    device is everything on this side of the library boundary: the calls it makes, in which order, on which streams.  A stand-in
+    for librccl.so (tests/stub/rccl_stub.cpp: same entry points, sends matched with receives at ncclGroupEnd, copies ordered
+    between the two streams the way the real transport orders them) is loaded through RFWHIP_RCCL_LIBRARY; n ranks on device 0
+    render pipelined frames; the image must be the single context's, and the log must read, per gather: ONE group, one send per
+    non-root rank to peer 0 on that rank's own stream with the strip chunk's size, n - 1 receives on rank 0 from peers 1..n-1,
+    all on ONE stream, no call outside a group."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    stub_src = os.path.join(ROOT, "tests", "stub", "rccl_stub.cpp")
+    stub = os.path.join(ROOT, "tests", "stub", "librccl_stub.so")
+    if not os.path.exists(stub) or os.path.getmtime(stub) < os.path.getmtime(stub_src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-fPIC", "-shared", "-std=c++17", stub_src, "-o", stub], check=True)
+    log = tmp_path / "rccl_calls.log"
+    env = dict(os.environ, RFWHIP_RCCL_LIBRARY=stub, RFWHIP_RCCL_SHARED_DEVICE="1", RFWHIP_RCCL_STUB_LOG=str(log))
+    r = subprocess.run([sys.executable, "-c", _STUB_SCRIPT % {"root": ROOT, "n": n}], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "STUB-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [l.split() for l in log.read_text().splitlines()]
+    assert not [l for l in lines if l[0] == "error"], lines
+    # communicator set-up: one group holding every rank's init
+    assert [l[0] for l in lines[:n + 3]] == ["unique_id", "group_start"] + ["comm_init"] * n + ["group_end"]
+    assert sorted(int(l[2]) for l in lines[2:2 + n]) == list(range(n))
+    body = lines[n + 3:]
+    gathers = 5 + 1  # five pipelined frames + framebuffer()'s own gather
+    per = 2 * (n - 1) + 2
+    assert len(body) == gathers * per, (len(body), gathers, per)
+    chunk = None
+    root_stream, rank_stream = None, {}
+    for k in range(gathers):
+        blk = body[k * per:(k + 1) * per]
+        assert blk[0][0] == "group_start" and blk[-1][:3] == ["group_end", "ops", str(2 * (n - 1))], blk
+        sends = [l for l in blk if l[0] == "send"]
+        recvs = [l for l in blk if l[0] == "recv"]
+        assert sorted(int(l[2]) for l in sends) == list(range(1, n)) and all(l[4] == "0" for l in sends)
+        assert all(l[2] == "0" for l in recvs) and sorted(int(l[4]) for l in recvs) == list(range(1, n))
+        for l in sends + recvs:
+            chunk = chunk or l[6]
+            assert l[6] == chunk  # every transfer is one strip chunk: local_rows x width x 16 bytes
+        for l in sends:
+            assert rank_stream.setdefault(l[2], l[8]) == l[8]  # a rank's sends always ride the same (its own) stream
+        for l in recvs:
+            root_stream = root_stream or l[8]
+            assert l[8] == root_stream
+    assert len(set(rank_stream.values()) | {root_stream}) == n  # n distinct gather streams
+    # (chunk size: 8-row strips dealt to n ranks, padded)
+    strips = (270 + 7) // 8
+    rows = ((strips + n - 1) // n) * 8
+    assert int(chunk) == rows * 480 * 16, (chunk, rows)
+
+
 @pytest.mark.gpu
 def test_two_process_comm_gather_needs_two_devices(pkg):
     """rfwhip_comm_* end to end, one process per device: `bench.py --gpus 2` under torch.distributed.run (RCCL send / recv issued
-    by librfwhip.so).  Needs >= 2 visible devices; on one device the same launch is walked through with
-    RFWHIP_BENCH_ONE_DEVICE=1 + RFWHIP_BENCH_TRY_COMM=1: RCCL refuses the duplicate device and bench.py must fall back to the
-    torch gather LOUDLY (config.gather says so) and still produce the right image mean."""
+    by librfwhip.so).  Needs >= 2 visible devices.  On one device the same launch is walked through with
+    RFWHIP_BENCH_ONE_DEVICE=1: with RFWHIP_BENCH_TRY_COMM=1 RCCL refuses the duplicate device and bench.py must STOP with an error
+    (a number from another path is never reported as the library's gather); with the torch gather asked for explicitly the two
+    ranks run and produce the single-rank image mean."""
     import json
     import os
     import subprocess
@@ -237,24 +323,36 @@ def test_two_process_comm_gather_needs_two_devices(pkg):
     from conftest import ROOT
     two = torch.cuda.device_count() >= 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if not two:
-        env.update(RFWHIP_BENCH_ONE_DEVICE="1", RFWHIP_BENCH_TRY_COMM="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8",
-           "--width", "480", "--height", "270", "--grid", "64", "--no-roofline", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    base = ["--steps", "2", "--warmup", "1", "--spp", "8", "--width", "480", "--height", "270", "--grid", "64", "--no-roofline", "--no-cpu-baseline"]
+
+    def launch(extra_env, extra_args, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + base + extra_args
+        return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(env, **extra_env), cwd=ROOT)
     if two:
+        r = launch({}, [], 29533)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert d["config"]["gather"] == "comm", d["config"]["gather"]
     else:
-        assert d["config"]["gather"].startswith("torch (rfwhip_comm_create failed"), d["config"]["gather"]
+        r = launch({"RFWHIP_BENCH_ONE_DEVICE": "1", "RFWHIP_BENCH_TRY_COMM": "1"}, [], 29533)
+        assert r.returncode != 0 and "rfwhip_comm_create failed" in (r.stderr + r.stdout), (r.returncode, r.stderr[-1500:])
+        r = launch({"RFWHIP_BENCH_ONE_DEVICE": "1"}, ["--gather", "torch"], 29534)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["config"]["gather"] == "torch", d["config"]["gather"]
+    assert d["n_gpus"] == 2 and d["value"] > 0
     # the same two steps on one rank: the strip split does not change the image
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", "8", "--width", "480",
-                          "--height", "270", "--grid", "64", "--no-roofline", "--no-cpu-baseline"], stdout=subprocess.PIPE,
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert abs(d["image_mean"] - d1["image_mean"]) <= 1e-6 * abs(d1["image_mean"]), (d["image_mean"], d1["image_mean"])
+    # --mode group: ONE process drives the ranks through rfwhip_group_* (the plugin's host model)
+    genv = dict(env) if two else dict(env, RFWHIP_BENCH_ONE_DEVICE="1")
+    grp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "group"] + base, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600, env=genv, cwd=ROOT)
+    assert grp.returncode == 0, grp.stderr[-2000:]
+    dg = json.loads([l for l in grp.stdout.splitlines() if l.startswith("{")][-1])
+    assert dg["n_gpus"] == 2 and dg["config"]["gather"].startswith("group:" + ("rccl" if two else "peer")), dg["config"]["gather"]
+    assert abs(dg["image_mean"] - d1["image_mean"]) <= 1e-6 * abs(d1["image_mean"]), (dg["image_mean"], d1["image_mean"])
