@@ -262,7 +262,11 @@ void rfwo_xor128_jump(uint32_t state[4], uint64_t draws)
 }
 
 /* bvh_tree.cpp:166-196.  u,v are the weights of p1 and p2 (Embree convention used by Context.cpp:210-211). */
-static inline int tri_test(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, v3 p2, float *u_out, float *v_out)
+/* tie != 0 (closest-hit queries): of two triangles hit at bit-identical distance the lower primitive id wins — a total order on
+ * (t, prim), so that the hit does not depend on the order a tree happens to present the triangles in (the reference keeps the
+ * first it reaches; the product serves the same rays from several traversals and trees: csrc/rt_core.h, tri_test). */
+static inline int tri_test_tie(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, v3 p2, float *u_out, float *v_out, int tie, uint32_t prim,
+							   uint32_t cur_prim)
 {
 	/* (fixed-shape arithmetic: rfw_oracle_math.h, rounded()) */
 	const v3 e1 = vsub(p1, p0), e2 = vsub(p2, p0);
@@ -280,7 +284,7 @@ static inline int tri_test(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, 
 	if (v < 0.0f || u + v > 1.0f)
 		return 0;
 	const float tt = rounded(f * vdot_r(e2, q));
-	if (tt > t_min && *t > tt)
+	if (tt > t_min && (*t > tt || (tie && *t == tt && prim < cur_prim)))
 	{
 		*t = tt;
 		*u_out = u;
@@ -288,6 +292,10 @@ static inline int tri_test(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, 
 		return 1;
 	}
 	return 0;
+}
+static inline int tri_test(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, v3 p2, float *u_out, float *v_out)
+{
+	return tri_test_tie(org, dir, t_min, t, p0, p1, p2, u_out, v_out, 0, 0u, 0u);
 }
 int rfwo_intersect_triangle(const float org[3], const float dir[3], float t_min, float *t, const float p0[3],
 							const float p1[3], const float p2[3], float *u, float *v)
@@ -521,7 +529,7 @@ static int blas_closest(const omesh *m, v3 o, v3 d, float t_min, float *t, int *
 			{
 				const uint32_t p = m->prims[node->left_first + i];
 				st->tris++;
-				if (tri_test(o, d, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v))
+				if (tri_test_tie(o, d, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, 1, p, (uint32_t)*prim))
 					valid = 1, *prim = (int)p;
 			}
 		}
@@ -617,7 +625,7 @@ static int scene_closest(const rfwo_context *c, v3 o, v3 d, float t_min, float *
 			for (size_t p = 0; p < m->triCount; p++)
 			{
 				st->tris++;
-				if (tri_test(lo, ld, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v))
+				if (tri_test_tie(lo, ld, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, 1, (uint32_t)p, (uint32_t)*prim))
 					hit = 1, *inst = (int)i, *prim = (int)p;
 			}
 	}

@@ -1033,6 +1033,7 @@ __device__ __forceinline__ void wave_triangle_phase(Traverser<ANY, COUNT, WORLD>
 		const f3 fo = mk3(wave_fetch(owner4, T.o.x), wave_fetch(owner4, T.o.y), wave_fetch(owner4, T.o.z));
 		const f3 fd = mk3(wave_fetch(owner4, T.d.x), wave_fetch(owner4, T.d.y), wave_fetch(owner4, T.d.z));
 		float ft = wave_fetch(owner4, T.hit.t);
+		const uint32_t fprim = ANY ? 0u : wave_fetch(owner4, (uint32_t)T.hit.prim);
 		const uint32_t ffirst = wave_fetch(owner4, first);
 		float ru = 0.0f, rv = 0.0f;
 		uint32_t rprim = 0u, rinst = 0u;
@@ -1041,8 +1042,8 @@ __device__ __forceinline__ void wave_triangle_phase(Traverser<ANY, COUNT, WORLD>
 		{
 			const f4 *tv = sc.tri_verts + 3u * (ffirst + k);
 			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-			rhit = tri_test(fo, fd, T.t_min, ft, xyz(v0), xyz(v1), xyz(v2), ru, rv);
 			rprim = fbits(v0.w), rinst = fbits(v1.w);
+			rhit = tri_test<!ANY>(fo, fd, T.t_min, ft, xyz(v0), xyz(v1), xyz(v2), ru, rv, rprim, fprim);
 		}
 		if (COUNT)
 			st.tris += in_round ? cnt : 0u;
@@ -1063,7 +1064,7 @@ __device__ __forceinline__ void wave_triangle_phase(Traverser<ANY, COUNT, WORLD>
 				const uint32_t src4 = ((prefix + kk) & 63u) << 2;
 				const float t2 = wave_fetch(src4, ft), u2 = wave_fetch(src4, ru), v2 = wave_fetch(src4, rv);
 				const uint32_t p2 = wave_fetch(src4, rprim), i2 = wave_fetch(src4, rinst);
-				if (seg && t2 < T.hit.t) // (segments are walked in triangle order: the earliest wins a tie, as in the lane's own loop)
+				if (seg && (t2 < T.hit.t || (t2 == T.hit.t && p2 < (uint32_t)T.hit.prim))) // (tri_test's total order on (t, prim))
 				{
 					T.hit.t = t2, T.hit.u = u2, T.hit.v = v2, T.hit.prim = (int)p2;
 					T.hit.inst = T.cur_inst >= 0 ? T.cur_inst : (int)i2;
@@ -1519,7 +1520,8 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
 				if (COUNT)
 					st.tris += active ? 1u : 0u;
-				if (tri_test(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v))
+				if (tri_test<true>(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v,
+								   fbits(v0[3]), (uint32_t)hit.prim))
 				{
 					hit.prim = (int)fbits(v0[3]);
 					hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
@@ -2277,7 +2279,7 @@ template <bool COUNT> void trace(const SceneView &sc, const bool *active, const 
 				if (COUNT)
 					st.tris += nact;
 				for (int l = 0; l < WAVE; l++)
-					if (tri_test(sp.o[l], sp.d[l], t_min, hit[l].t, xyz(v0), xyz(v1), xyz(v2), hit[l].u, hit[l].v))
+					if (tri_test<true>(sp.o[l], sp.d[l], t_min, hit[l].t, xyz(v0), xyz(v1), xyz(v2), hit[l].u, hit[l].v, fbits(v0.w), (uint32_t)hit[l].prim))
 					{
 						hit[l].prim = (int)fbits(v0.w);
 						hit[l].inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);

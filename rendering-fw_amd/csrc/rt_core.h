@@ -414,7 +414,14 @@ RT_FN float ub2(uint32_t x) { return (float)((x >> 16) & 255u); }
 RT_FN float ub3(uint32_t x) { return (float)(x >> 24); }
 
 // Möller–Trumbore with the reference's rejections: |a| < 1e-6, u outside [0,1], v < 0, u+v > 1, t <= t_min, t >= t.
-RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo)
+// TIE (closest-hit queries): of two triangles hit at BIT-IDENTICAL distance the one with the lower primitive id is the hit.  The
+// reference keeps whichever its traversal reaches first (strict t > tt, bvh_tree.cpp:166-196) — an answer that depends on the
+// shape of its tree; here several traversals serve the same rays (one ray per lane, persistent lanes, the packet form of the
+// primary wave; host-built and device-built trees), and a ray exactly on an edge shared by two triangles must not get a
+// different triangle — normal, material — from each of them: with a total order on (t, prim) the hit record is a function of
+// the ray and the scene alone.  (About one primary ray in a million on the terrain; occlusion queries have no such question.)
+template <bool TIE = false>
+RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo, uint32_t prim = 0u, uint32_t cur_prim = 0u)
 {
 	// (fixed-shape arithmetic: see rounded())
 	const f3 e1 = p1 - p0, e2 = p2 - p0;
@@ -432,7 +439,10 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 	if (v < 0.0f || u + v > 1.0f)
 		return false;
 	const float tt = rounded(f * dot_r(e2, q));
-	if (tt > t_min && t > tt)
+	bool nearer = t > tt;
+	if (TIE)
+		nearer = nearer || (t == tt && prim < cur_prim);
+	if (tt > t_min && nearer)
 	{
 		t = tt, uo = u, vo = v;
 		return true;
@@ -756,7 +766,7 @@ struct Traverser : TraverserWorld<WORLD>
 			if (COUNT)
 				st.tris++;
 #endif
-			if (tri_test(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v))
+			if (tri_test<!ANY>(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v, fbits(v0.w), (uint32_t)hit.prim))
 			{
 				hit.prim = (int)fbits(v0.w);
 				// (outside every instance: the triangle belongs to an instance that was linked into the top-level tree directly,
