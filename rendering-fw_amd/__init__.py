@@ -14,5 +14,6 @@ from .abi import CONVERGE, RESET
 from .camera import Camera
 from .context import LIB_PATH, RenderComm, RenderContext, comm_unique_id, load_library, render_group
 from .build import build as build_native
+from .build import build_strict
 
-__all__ = ["abi", "scenes", "gltf", "obj", "Camera", "RenderContext", "load_library", "render_group", "RenderComm", "comm_unique_id", "LIB_PATH", "build_native", "RESET", "CONVERGE"]
+__all__ = ["abi", "scenes", "gltf", "obj", "Camera", "RenderContext", "load_library", "render_group", "RenderComm", "comm_unique_id", "LIB_PATH", "build_native", "build_strict", "RESET", "CONVERGE"]

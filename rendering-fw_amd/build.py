@@ -66,6 +66,24 @@ def build(force=False, verbose=False):
     return outs
 
 
+def build_strict(force=False, verbose=False):
+    """The VALIDATION build (csrc/rt_strict_math.h): the same sources with -DRT_STRICT_MATH -ffp-contract=off into
+    tests/_strict/librfwhip_strict.so — test infrastructure (tests/test_strict_gpu.py compares it bit for bit with the host
+    emulation built the same way); never loaded by the product.  Built here so that it travels to the GPU box with the tree."""
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "_strict")
+    out = os.path.join(out_dir, "librfwhip_strict.so")
+    if not force and not _stale(out, _deps()):
+        return out
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in CORE_SOURCES:
+        obj = os.path.join(out_dir, src + ".o")
+        _run([HIPCC] + COMMON + ["-DRT_STRICT_MATH", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj], verbose)
+        objs.append(obj)
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-lpthread", "-ldl"], verbose)
+    return out
+
+
 def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -119,6 +119,33 @@ RT_FN float ubits(uint32_t u)
 	return c.f;
 }
 
+// The transcendental functions the path tracer calls.  Shipped build: the platform's (device math library / v_sin_f32 and
+// v_cos_f32 in sincos_turns / glibc on the host).  RT_STRICT_MATH (the validation build, rt_strict_math.h): one float
+// implementation shared by device and host, so that the two agree to the bit.
+} // namespace rt
+#if defined(RT_STRICT_MATH)
+#include "rt_strict_math.h"
+#endif
+namespace rt
+{
+#if defined(RT_STRICT_MATH)
+RT_FN float m_sinf(float x) { return strict::sin_(x); }
+RT_FN float m_cosf(float x) { return strict::cos_(x); }
+RT_FN float m_expf(float x) { return strict::exp_(x); }
+RT_FN float m_logf(float x) { return strict::log_(x); }
+RT_FN float m_log2f(float x) { return strict::log2_(x); }
+RT_FN float m_atan2f(float y, float x) { return strict::atan2_(y, x); }
+RT_FN float m_acosf(float x) { return strict::acos_(x); }
+#else
+RT_FN float m_sinf(float x) { return sinf(x); }
+RT_FN float m_cosf(float x) { return cosf(x); }
+RT_FN float m_expf(float x) { return expf(x); }
+RT_FN float m_logf(float x) { return logf(x); }
+RT_FN float m_log2f(float x) { return log2f(x); }
+RT_FN float m_atan2f(float y, float x) { return atan2f(y, x); }
+RT_FN float m_acosf(float x) { return acosf(x); }
+#endif
+
 RT_FN float half_to_float(uint16_t h)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -237,8 +264,8 @@ RT_FN void parity_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32
 		const float blade = (float)(int)(r0 * 9);
 		r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
 		const float piOver4point5 = 3.14159265359f / 4.5f;
-		const float x1 = cosf(blade * piOver4point5), y1 = sinf(blade * piOver4point5);
-		const float x2 = cosf((blade + 1.0f) * piOver4point5), y2 = sinf((blade + 1.0f) * piOver4point5);
+		const float x1 = m_cosf(blade * piOver4point5), y1 = m_sinf(blade * piOver4point5);
+		const float x2 = m_cosf((blade + 1.0f) * piOver4point5), y2 = m_sinf((blade + 1.0f) * piOver4point5);
 		if ((r2 + r3) > 1.0f)
 			r2 = 1.0f - r2, r3 = 1.0f - r3;
 		const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
@@ -298,8 +325,8 @@ RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x
 		r2 = (r2 - blade * (1.0f / 9.0f)) * 9.0f;
 		const float piOver4point5 = 3.14159265359f / 4.5f;
 		// __sincosf(a, &x1, &y1): x1 = sin, y1 = cos (Kernels.cu:407-408)
-		const float x1 = sinf(blade * piOver4point5), y1 = cosf(blade * piOver4point5);
-		const float x2 = sinf((blade + 1.0f) * piOver4point5), y2 = cosf((blade + 1.0f) * piOver4point5);
+		const float x1 = m_sinf(blade * piOver4point5), y1 = m_cosf(blade * piOver4point5);
+		const float x2 = m_sinf((blade + 1.0f) * piOver4point5), y2 = m_cosf((blade + 1.0f) * piOver4point5);
 		if ((r2 + r3) > 1.0f)
 			r2 = 1.0f - r2, r3 = 1.0f - r3;
 		// (fixed-shape arithmetic from here on: see rounded())
@@ -360,7 +387,7 @@ RT_FN float safe_rcp(float d)
 
 RT_FN float fast_rcp(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_STRICT_MATH)
 	return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
 #else
 	return 1.0f / x;
@@ -896,8 +923,8 @@ RT_FN f3 parity_sky(const SceneView &sc, f3 D)
 {
 	if (!sc.sky_w || !sc.sky_h)
 		return mk3(0, 0, 0);
-	const float ux = 0.5f * (1.0f + atan2f(D.x, -D.z) * RT_INV_PI);
-	const float uy = acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI;
+	const float ux = 0.5f * (1.0f + m_atan2f(D.x, -D.z) * RT_INV_PI);
+	const float uy = m_acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI;
 	uint32_t px = f2u_sat(ux * (float)(sc.sky_w - 1)), py = f2u_sat(uy * (float)(sc.sky_h - 1));
 	if (px >= sc.sky_w)
 		px = sc.sky_w - 1;
@@ -910,8 +937,8 @@ RT_FN f3 pt_sky(const SceneView &sc, f3 D)
 {
 	if (!sc.sky_w || !sc.sky_h)
 		return mk3(0, 0, 0);
-	const uint32_t u = f2u_sat((float)sc.sky_w * 0.5f * (1.0f + atan2f(D.x, -D.z) * RT_INV_PI));
-	const uint32_t v = f2u_sat((float)sc.sky_h * acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI);
+	const uint32_t u = f2u_sat((float)sc.sky_w * 0.5f * (1.0f + m_atan2f(D.x, -D.z) * RT_INV_PI));
+	const uint32_t v = f2u_sat((float)sc.sky_h * m_acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI);
 	const unsigned long long idx = (unsigned long long)u + (unsigned long long)v * sc.sky_w;
 	if (idx < (unsigned long long)sc.sky_w * sc.sky_h)
 		return xyz(sc.sky[idx]);
@@ -1044,7 +1071,7 @@ RT_FN float gtr1(float NDotH, float a)
 		return RT_INVPI;
 	const float a2 = a * a;
 	const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-	return (a2 - 1.0f) / (RT_PI * logf(a2) * t);
+	return (a2 - 1.0f) / (RT_PI * m_logf(a2) * t);
 }
 RT_FN float gtr2(float NDotH, float a)
 {
@@ -1176,17 +1203,19 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 	}
 	const f3 fin = lerp3(brdf, bsdf, TRANSMISSION);
 	if (backfacing)
-		return fin * mk3(expf(-sd.absorption.x * t), expf(-sd.absorption.y * t), expf(-sd.absorption.z * t));
+		return fin * mk3(m_expf(-sd.absorption.x * t), m_expf(-sd.absorption.y * t), m_expf(-sd.absorption.z * t));
 	return fin;
 }
 // sin / cos of 2*pi*frac.  On the GPU v_sin_f32 / v_cos_f32 take their argument in turns — one instruction each instead
 // of a range-reduced polynomial; |error| ~1e-6, well inside the path tracer's tolerance.
 RT_FN void sincos_turns(float frac, float &s, float &c)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(RT_STRICT_MATH)
+	strict::sincos_turns(frac, s, c);
+#elif defined(__HIP_DEVICE_COMPILE__)
 	s = __builtin_amdgcn_sinf(frac), c = __builtin_amdgcn_cosf(frac);
 #else
-	s = sinf(frac * RT_TWOPI), c = cosf(frac * RT_TWOPI);
+	s = m_sinf(frac * RT_TWOPI), c = m_cosf(frac * RT_TWOPI);
 #endif
 }
 RT_FN f3 reflect_dir(f3 I, f3 N) { return I - N * (dot(N, I) * 2.0f); }
@@ -1577,7 +1606,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 		const float tu = bw0 * tu4.x + bw1 * tu4.y + bw2 * tu4.z;
 		const float tv = bw0 * tv4.x + bw1 * tv4.y + bw2 * tv4.z;
 		const float coneWidth = cam.spread_angle * h.t;
-		const float lambda = ex.y + log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, N))));
+		const float lambda = ex.y + m_log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, N))));
 		// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
 #define RT_LAYER(K) \
 	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \

@@ -40,12 +40,17 @@ def test_traversal_1m_triangles(pkg, make_hip, make_oracle, terrain):
     rng = np.random.default_rng(5)
     o, d = _rays(rng, 300000, 48.0)
     a, b = core.trace_rays(o, d), ref.trace_rays(o, d)
-    assert (a["prim"] != b["prim"]).mean() <= 2e-3 and (a["inst"] != b["inst"]).mean() <= 2e-3
+    # Product and oracle state the triangle test in the same fixed shape (csrc/rt_core.h: rounded()) with the same total order on
+    # (t, prim); the ONE operation that differs is the reciprocal of the determinant (v_rcp_f32, 1 ulp, against an IEEE division).
+    # Measured on the MI355X: no ray of the 300 000 gets another triangle, 90 % of the hit records are bit-equal, the rest differ
+    # by one unit in the last place of t, u or v (round 3 had to allow 5e-3 on u and v: the compilers had contracted the cross
+    # products of the two implementations differently).
+    assert (a["prim"] != b["prim"]).mean() <= 1e-5 and (a["inst"] != b["inst"]).mean() <= 1e-5
     same = (a["prim"] == b["prim"]) & (a["prim"] >= 0)
     assert same.sum() > 0.5 * len(same)
-    assert (np.abs(a["t"][same] - b["t"][same]) <= 1e-4 + 2e-5 * np.abs(b["t"][same])).all()
-    # barycentrics of 0.14-unit triangles seen from ~100 units: the cross products cancel to ~1e-3 in fp32
-    assert np.abs(a["u"][same] - b["u"][same]).max() <= 5e-3 and np.abs(a["v"][same] - b["v"][same]).max() <= 5e-3
+    assert (np.abs(a["t"][same] - b["t"][same]) <= 5e-7 * np.abs(b["t"][same])).all()
+    assert np.abs(a["u"][same] - b["u"][same]).max() <= 3e-7 and np.abs(a["v"][same] - b["v"][same]).max() <= 3e-7
+    assert (a["t"][same] == b["t"][same]).mean() >= 0.8
 
 
 def test_accumulation_and_subbatch_independence(pkg, make_hip, terrain):
