@@ -1262,6 +1262,32 @@ __global__ void __launch_bounds__(TRACE_BLOCK, ANY ? RT_ANY_WAVES : RT_TRACE_WAV
 		clock_out(p.wv.counters, p.depth);
 }
 
+// Extension rays of depth d + 1 and shadow rays of depth d in ONE launch: both queues are complete when the shade kernel of
+// depth d has finished, and as two launches each ends in its own tail — a few long rays keep a handful of waves busy while
+// the rest of the chip waits for the kernel boundary.  A wave walks the extension queue first (the next shade kernel waits
+// for those hits) and moves on to the shadow queue when the extension queue has run dry, so the waves that finish early fill
+// the other queue's work instead of idling: one tail per depth instead of two, and 4 launches less per frame of depth 2.
+// Registers and LDS are those of the closest-hit kernel (the occlusion traversal uses the first 8 levels of its stack).
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) __attribute__((amdgpu_num_vgpr(RT_TRACE_VGPRS))) k_trace_fused(const Params pe, const Params pa)
+{
+	const uint32_t count_e = pe.wv.counters->ext_n[pe.depth];
+	const uint32_t count_a = connection_count(pa.wv.counters, pa.depth);
+	if (count_a == 0u && pa.depth == 0 && pa.wv.rad_nee)
+		for (uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x, n = pa.wv.counters->shadow_n[0]; i < n; i += gridDim.x * TRACE_BLOCK)
+			connect_skip_item(pa, i);
+	if (count_e == 0u && count_a == 0u)
+		return;
+	clock_in(pe.wv.counters, pe.depth);
+	const Params &p = pe; // (the stack declaration reads the LDS node range from `p`)
+	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
+	if (count_e)
+		stream_rays<STREAM_EXT, COUNT>(pe, count_e, ctx);
+	clock_out(pe.wv.counters, pe.depth);
+	if (count_a)
+		stream_rays<STREAM_ANY, COUNT>(pa, count_a, ctx);
+}
+
 // the pt integrator's primary wave in the same persistent-lane form: a lane generates its next primary ray itself
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primary_stream(const Params p, const uint32_t count)
@@ -2024,6 +2050,16 @@ void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
 		hipLaunchKernelGGL((k_connect<false>), g, b, 0, (hipStream_t)s, p);
 }
 
+void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s)
+{
+	const dim3 g(persistent_grid(max_items));
+	const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
+	if (count)
+		hipLaunchKernelGGL((k_trace_fused<true>), gt, bt, 0, (hipStream_t)s, pe, pa);
+	else
+		hipLaunchKernelGGL((k_trace_fused<false>), gt, bt, 0, (hipStream_t)s, pe, pa);
+}
+
 void launch_resolve(const Params &p, stream_t s)
 {
 	hipLaunchKernelGGL(k_resolve, dim3(persistent_grid(p.fr.W * p.fr.local_rows)), dim3(BLOCK), 0, (hipStream_t)s, p);
@@ -2381,6 +2417,11 @@ void launch_connect(const Params &p, bool count, uint32_t, stream_t)
 			connect_skip_item(p, i);
 	for (uint32_t i = 0; i < n; i++)
 		count ? connect_item<true>(p, i, true, ctx) : connect_item<false>(p, i, true, ctx);
+}
+void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s)
+{
+	launch_extend(pe, GEN_BUFFER, count, max_items, s);
+	launch_connect(pa, count, max_items, s);
 }
 void launch_resolve(const Params &p, stream_t)
 {

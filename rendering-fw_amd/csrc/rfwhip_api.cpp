@@ -407,6 +407,7 @@ struct rfwhip_context
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample;
 						   // 64 = a wave is ONE pixel: primary wave 3.67 instead of 4.01 ms per 32 spp, depth-0 shadow wave -7 %)
 	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
+	int fuse = 1;	  // extension rays of depth d + 1 and shadow rays of depth d in one launch (kernels.hip: k_trace_fused)
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
 	// scene (host side)
@@ -1852,7 +1853,9 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	// call: 1.56 -> 1.43 ms).  When the caller pipelines its calls, the ring of buffer sets already keeps up to four launch
 	// chains in flight and the extra kernels only evict each other's working sets (1 spp: 1.17 ms without, 1.38 ms with the
 	// side stream; 16 spp: 13.2 / 14.1 ms), and the same holds beside other sub-batches (4 sub-batches, 128 spp: -9 %).
-	const bool side = connect && (c->overlap == 1 || (c->overlap < 0 && subs == 1 && !pipelined));
+	// extension rays of depth d + 1 and shadow rays of depth d in one launch (both in persistent-lane form): one tail per depth
+	const bool fused = connect && c->fuse != 0 && (c->refill & 3) == 3 && c->overlap != 1;
+	const bool side = connect && !fused && (c->overlap == 1 || (c->overlap < 0 && subs == 1 && !pipelined));
 	rtk::Params base;
 	fill_params(c, cam, base);
 	set_sample_group(base.fr, sgroup_log2);
@@ -1913,6 +1916,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		}
 		else
 		{
+			rtk::Params pa = p; // fused: the connection wave of the previous depth, launched together with this depth's extension wave
+			bool pa_pending = false;
 			for (int d = 0; d <= c->max_depth; d++)
 			{
 				p.depth = (uint32_t)d;
@@ -1922,7 +1927,11 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				p.wv.sh_org = c->d_sh_org[d & 1].as<f4>() + off, p.wv.sh_dir = c->d_sh_dir[d & 1].as<f4>() + off;
 				p.wv.sh_rad = c->d_sh_rad[d & 1].as<f4>() + off;
 				StageTimer te(c, KF_EXTEND, d, s);
-				rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+				if (pa_pending)
+					rtk::launch_trace_fused(p, pa, count, n, s); // extension rays of depth d + shadow rays of depth d - 1
+				else
+					rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+				pa_pending = false;
 				te.stop();
 				if (side && d >= 2 && d < c->max_depth) // connect(d - 2) read the buffers shade(d) is about to write
 					RF_TRY(dm::stream_wait_event(s, c->ev_conn[i][d - 2]));
@@ -1934,6 +1943,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				// (CUDART/src/Context.cpp:109-120): the shade kernel does not emit them, and no wave is launched for them.
 				if (connect && d < c->max_depth)
 				{
+					if (fused)
+					{
+						pa = p, pa.group = 16u, pa.queue = queue++;
+						pa_pending = true; // (d < max_depth: the next depth's extension wave takes it along)
+						continue;
+					}
 					if (side)
 					{
 						RF_TRY(dm::event_record(c->ev_shade[i][d], s));
@@ -2218,7 +2233,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2284,6 +2299,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
 		c->refill = atoi(value) & 15;
+	else if (k == "fuse")
+		c->fuse = atoi(value) != 0;
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);
@@ -2355,6 +2372,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->lds_nodes);
 	else if (k == "refill")
 		snprintf(value, cap, "%d", c->refill);
+	else if (k == "fuse")
+		snprintf(value, cap, "%d", c->fuse);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "sub_batch_paths")
