@@ -39,6 +39,7 @@ namespace rtk
 {
 
 constexpr int BLOCK = 256;
+constexpr int TEX_RECORD = 7; // rt::TexShade as floats: colour, shading normal, flags
 constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (static_assert in rfwhip_api.cpp)
 // minimum waves per SIMD the register allocator must leave room for in the traversal kernels.  Swept on MI355X with
 // the final kernels: 4 / 5 / 6 / 7 / 8 -> 1863 / 1910 / 1923 / 1864 / 1863 Msamples/s (the 85-register budget of 6 makes
@@ -62,7 +63,7 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #define RT_ANY_WAVES 8 // occlusion kernels (fewer registers, less LDS)
 #endif
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 4
+#define RT_SHADE_WAVES 5 // the textured shade kernel, since its texture layers run as a pre-pass (4 waves at 128 registers before)
 #endif
 // packet form of the primary wave (trace_packet): 0 = the nearest entered child first, the others in no particular order (3 of
 // the 5 comparators of the sorting network); 1 = all entered children by distance
@@ -84,6 +85,7 @@ struct Ctx
 	TravStack stk;
 	float *pot = nullptr; // this lane's column of the light-potential cache (shade kernel)
 	volatile uint16_t *tri_map = nullptr; // this WAVE's 64 entries of the triangle phase's pair map (wave_triangle_phase)
+	volatile float *tex = nullptr;		  // this lane's column of the texture pre-pass records (textured shade kernel): tex[k * BLOCK]
 
 	// Block-wise slot allocation of the shade kernel's two output queues (rt_types.h: QUEUE_BLOCK).  Wave-uniform state.
 	struct OutQueue
@@ -133,6 +135,8 @@ struct Ctx
 	uint32_t lds[LDS_STACK_MAX], spill[SPILL_STACK];
 	float potbuf[POT_CACHE];
 	float *pot;
+	float texbuf[TEX_RECORD];
+	volatile float *tex = texbuf; // (emulation: the pre-pass record of the item in hand, stride 1)
 	uint32_t overflow_sink = 0;
 	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0, stk.overflow = &overflow_sink, stk.stride = 1; }
 	explicit Ctx(const Params &p) : Ctx()
@@ -296,6 +300,39 @@ RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	}
 }
 
+// The texture layers of path entry i (a valid entry: a hit of the wave's queue, or a miss, which has none) as a PRE-PASS: only
+// the direction and the hit record are read, the result — colour, shading normal, alpha flag (rt_core.h: TexShade) — goes into
+// the lane's record (LDS on the device).  What the trilinear fetches hold in registers is gone before the BSDF and the light
+// sampling need theirs: the textured shade kernel fits 96 registers = 5 waves per SIMD instead of 128 = 4.
+#if defined(RT_DEVICE_BUILD)
+constexpr int TEX_STRIDE = BLOCK;
+#else
+constexpr int TEX_STRIDE = 1;
+#endif
+template <bool TEX> RT_FN void shade_tex_prepass_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+{
+	if (!TEX)
+		return;
+	f3 tc = mk3(0, 0, 0), tn = mk3(0, 0, 1);
+	uint32_t tf = 0u;
+	if (active)
+	{
+		const uint32_t b = p.depth & 1u;
+		const f4 d4 = p.wv.dir[b][i];
+		const f4 h4 = (p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i];
+		Hit h;
+		h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = 0;
+		if (h.prim >= 0)
+		{
+			h.inst = (p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst)[i];
+			pt_texture_prepass(p.sc, p.cam, xyz(d4), h, tc, tn, tf);
+		}
+	}
+	ctx.tex[0] = tc.x, ctx.tex[TEX_STRIDE] = tc.y, ctx.tex[2 * TEX_STRIDE] = tc.z;
+	ctx.tex[3 * TEX_STRIDE] = tn.x, ctx.tex[4 * TEX_STRIDE] = tn.y, ctx.tex[5 * TEX_STRIDE] = tn.z;
+	ctx.tex[6 * TEX_STRIDE] = ubits(tf);
+}
+
 template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 {
 	const uint32_t b = p.depth & 1u, nb = b ^ 1u;
@@ -346,7 +383,21 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 				WaveCounters *c = p.wv.counters;
 				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
 			}
-			pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
+			if (TEX)
+			{
+				// the texture layers ran as a pre-pass of this batch (shade_tex_prepass_item; the device kernel calls it for the whole
+				// wave before this function, the emulation right here): their result comes back from the lane's record
+#if !defined(RT_DEVICE_BUILD)
+				shade_tex_prepass_item<TEX>(p, i, true, ctx);
+#endif
+				TexShade tx;
+				tx.color = mk3(ctx.tex[0], ctx.tex[TEX_STRIDE], ctx.tex[2 * TEX_STRIDE]);
+				tx.iN = mk3(ctx.tex[3 * TEX_STRIDE], ctx.tex[4 * TEX_STRIDE], ctx.tex[5 * TEX_STRIDE]);
+				tx.flags = fbits(ctx.tex[6 * TEX_STRIDE]);
+				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, &tx);
+			}
+			else
+				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
 			write_rad = true;
 		}
 	}
@@ -1660,6 +1711,8 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
 	ctx.stk.overflow = nullptr, ctx.stk.stride = 0;
 	ctx.pot = s_pot + threadIdx.x;
+	__shared__ float s_tex[TEX ? TEX_RECORD * BLOCK : 1];
+	ctx.tex = s_tex + (TEX ? threadIdx.x : 0);
 	const uint32_t count = p.wv.counters->ext_n[p.depth];
 	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by lane
 	// on the bounce waves.  Every WAVE keeps its own queue of hit paths in LDS: it walks 64-path chunks, shades a chunk's
@@ -1719,6 +1772,11 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		else
 			break;
 		__builtin_amdgcn_wave_barrier();
+		if (TEX)
+		{
+			shade_tex_prepass_item<TEX>(p, idx, act, ctx);
+			__builtin_amdgcn_wave_barrier();
+		}
 		shade_pt_item<TEX>(p, idx, act, ctx);
 	}
 	// what is left of this wave's last queue blocks becomes void entries; the ray counts go to the statistics

@@ -1562,11 +1562,123 @@ struct ShadeOut
 	f4 eo, ed, et; // extension ray: origin|slot<<1|flags, dir|packedN, throughput|pdf
 };
 
+// What the texture layers of a hit come to (getShadingData.h:141-206): the colour after the diffuse layers, the shading normal
+// after the normal-map layers, and whether the alpha test lets the path through.  Computed by pt_textures() — in the textured
+// shade kernel as a PRE-PASS of every queued hit whose result goes through LDS (kernels.hip: shade_pt_item), so that the
+// registers of the trilinear fetches (eight texels, their weights, the descriptors) are free again before the BSDF and the
+// light sampling need theirs; pt_shade() picks the record up.  The values themselves take no other path: same functions, same
+// order, same bits as the fetches inside pt_shade() (the form the host emulation and rfwhip_kat use).
+struct TexShade
+{
+	f3 color, iN;
+	uint32_t flags; // TEXSHADE_*
+};
+constexpr uint32_t TEXSHADE_VALID = 1u, TEXSHADE_ALPHA_SKIP = 2u;
+
+// the surface at a hit: shading record, material, barycentric weights, geometric / shading normal in world space, tangent frame
+struct Surface
+{
+	f4 tu4, tv4, ex;
+	const MaterialRec *mat;
+	const Instance *inst;
+	uint32_t mflags;
+	float bw0, bw1, bw2;
+	f3 N, iN, Tg, Bt;
+};
+RT_FN void pt_surface(const SceneView &sc, const Hit &h, Surface &sf)
+{
+	sf.inst = &sc.instances[h.inst];
+	const TriShade &ts = sc.tri_shade[sf.inst->shade_base + (uint32_t)h.prim];
+	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
+	sf.tu4 = ts.tu, sf.tv4 = ts.tv, sf.ex = ts.ex;
+	sf.mat = &sc.materials[fbits(sf.tv4.w)];
+	sf.mflags = sf.mat->flags;
+	// getShadingData.h:100-217 (its u,v,w weight vertex 0,1,2)
+	sf.bw0 = 1.0f - h.u - h.v, sf.bw1 = h.u, sf.bw2 = h.v;
+	f3 N = mk3(n0.w, n1.w, n2.w), iN = N;
+	if (mat_flag(sf.mflags, MF_SMOOTH_NORMALS))
+		iN = normalize((xyz(n0) * sf.bw0 + xyz(n1) * sf.bw1) + xyz(n2) * sf.bw2);
+	sf.N = normalize(mul_normal(*sf.inst, N));
+	sf.iN = normalize(mul_normal(*sf.inst, iN));
+	create_tangent_space(sf.iN, sf.Tg, sf.Bt);
+}
+RT_FN bool pt_has_textures(const SceneView &sc, const Surface &sf)
+{
+	return mat_flag(sf.mflags, MF_DIFFUSE_MAP) && sf.mat->map[0].addr < sc.texture_count;
+}
+// the texture layers of a textured hit: color = the material's colour on entry
+RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, const Surface &sf, f3 &color, f3 &iN, bool &alpha_skip)
+{
+	const MaterialRec &mat = *sf.mat;
+	const uint32_t mflags = sf.mflags;
+	const float tu = sf.bw0 * sf.tu4.x + sf.bw1 * sf.tu4.y + sf.bw2 * sf.tu4.z;
+	const float tv = sf.bw0 * sf.tv4.x + sf.bw1 * sf.tv4.y + sf.bw2 * sf.tv4.z;
+	const float coneWidth = cam.spread_angle * t;
+	const float lambda = sf.ex.y + m_log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, sf.N))));
+	// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
+#define RT_LAYER(K) \
+	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \
+					half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),         \
+					half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), mat.map[K].width, \
+					mat.map[K].height)
+#define RT_NORMAL_LAYER(K) \
+	((xyz(fetch_texel(sc, sc.textures[mat.map[K].addr],                                                \
+					  half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),       \
+					  half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), 0u,   \
+					  mat.map[K].width > 0 ? mat.map[K].width : 1, mat.map[K].height > 0 ? mat.map[K].height : 1)) - \
+	  mk3(0.5f, 0.5f, 0.5f)) *                                                                         \
+	 2.0f)
+	const f4 texel = RT_LAYER(0);
+	if (mat_flag(mflags, MF_ALPHA) && texel.w < 0.5f)
+		alpha_skip = true; // getShadingData.h:145-149: nothing else of the surface is evaluated
+	else
+	{
+		color = color * xyz(texel);
+		// second and third layers are additive (getShadingData.h:153-166)
+		if (mat_flag(mflags, MF_2ND_DIFFUSE_MAP) && mat.map[1].addr < sc.texture_count)
+			color = color + xyz(RT_LAYER(1));
+		if (mat_flag(mflags, MF_3RD_DIFFUSE_MAP) && mat.map[2].addr < sc.texture_count)
+			color = color + xyz(RT_LAYER(2));
+		// normal mapping, level 0 only (getShadingData.h:169-200); the third layer reads the descriptor of the
+		// second one there (:189-196) — kept.  The tangent frame stays the one of the unperturbed normal.
+		if (mat_flag(mflags, MF_NORMAL_MAP) && mat.map[3].addr < sc.texture_count)
+		{
+			f3 sn = RT_NORMAL_LAYER(3);
+			if (mat_flag(mflags, MF_2ND_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
+				sn = sn + RT_NORMAL_LAYER(4);
+			if (mat_flag(mflags, MF_3RD_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
+				sn = sn + RT_NORMAL_LAYER(4);
+			sn = normalize(sn);
+			iN = normalize((sf.Tg * sn.x + sf.Bt * sn.y) + iN * sn.z); // tangentToWorld, tools.h:214
+		}
+		// getShadingData.h:150 and :206 both multiply by the texel
+		color = color * xyz(texel);
+	}
+#undef RT_LAYER
+#undef RT_NORMAL_LAYER
+}
+// the pre-pass: the record of one hit (flags = 0: untextured, nothing to pick up)
+RT_FN void pt_texture_prepass(const SceneView &sc, const CamView &cam, f3 D, const Hit &h, f3 &color, f3 &iN, uint32_t &flags)
+{
+	flags = 0u, color = mk3(0, 0, 0), iN = mk3(0, 0, 1);
+	if (h.prim < 0)
+		return;
+	Surface sf;
+	pt_surface(sc, h, sf);
+	if (!pt_has_textures(sc, sf))
+		return;
+	bool alpha_skip = false;
+	color = material_color(*sf.mat), iN = sf.iN;
+	pt_textures(sc, cam, D, h.t, sf, color, iN, alpha_skip);
+	flags = TEXSHADE_VALID | (alpha_skip ? TEXSHADE_ALPHA_SKIP : 0u);
+}
+
 // TEX = false: the scene has no material with a texture or normal map (the host knows: rfwhip_set_materials) — the texture
 // layers, their descriptors and the level-of-detail arithmetic are compiled out, which frees a fifth of the registers.
+// tex: the pre-pass's record of this hit (TEX only; null: the layers are fetched here).
 template <bool TEX>
 RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
-					ShadeOut &out, float *pot_cache)
+					ShadeOut &out, float *pot_cache, const TexShade *tex = nullptr)
 {
 	out.radiance = mk3(0, 0, 0);
 	out.emit_shadow = false, out.emit_ext = false;
@@ -1581,74 +1693,25 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 		return;
 	}
 	const f3 I = O + D * h.t;
-	const Instance &inst = sc.instances[h.inst];
-	const TriShade &ts = sc.tri_shade[inst.shade_base + (uint32_t)h.prim];
-	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, tu4 = ts.tu, tv4 = ts.tv, ex = ts.ex;
-	const MaterialRec &mat = sc.materials[fbits(tv4.w)];
-	const uint32_t mflags = mat.flags;
-	// getShadingData.h:100-217 (its u,v,w weight vertex 0,1,2)
-	const float bw0 = 1.0f - h.u - h.v, bw1 = h.u, bw2 = h.v;
+	Surface sf;
+	pt_surface(sc, h, sf);
+	const MaterialRec &mat = *sf.mat;
+	const f4 tu4 = sf.tu4, ex = sf.ex;
 	Shading sd;
 	sd.color = material_color(mat);
 	sd.absorption = mk3(half_to_float(mat.transmittance[0]), half_to_float(mat.transmittance[1]),
 						half_to_float(mat.transmittance[2]));
 	sd.p0 = mat.parameters[0], sd.p1 = mat.parameters[1], sd.p2 = mat.parameters[2];
-	f3 N = mk3(n0.w, n1.w, n2.w), iN = N;
-	if (mat_flag(mflags, MF_SMOOTH_NORMALS))
-		iN = normalize((xyz(n0) * bw0 + xyz(n1) * bw1) + xyz(n2) * bw2);
-	N = normalize(mul_normal(inst, N));
-	iN = normalize(mul_normal(inst, iN));
-	f3 Tg, Bt;
-	create_tangent_space(iN, Tg, Bt);
+	f3 N = sf.N, iN = sf.iN;
+	const f3 Tg = sf.Tg, Bt = sf.Bt;
 	bool alpha_skip = false;
-	if (TEX && mat_flag(mflags, MF_DIFFUSE_MAP) && mat.map[0].addr < sc.texture_count)
+	if (TEX && tex)
 	{
-		const float tu = bw0 * tu4.x + bw1 * tu4.y + bw2 * tu4.z;
-		const float tv = bw0 * tv4.x + bw1 * tv4.y + bw2 * tv4.z;
-		const float coneWidth = cam.spread_angle * h.t;
-		const float lambda = ex.y + m_log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, N))));
-		// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
-#define RT_LAYER(K) \
-	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \
-					half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),         \
-					half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), mat.map[K].width, \
-					mat.map[K].height)
-#define RT_NORMAL_LAYER(K) \
-	((xyz(fetch_texel(sc, sc.textures[mat.map[K].addr],                                                \
-					  half_to_float(mat.map[K].uscale) * (half_to_float(mat.map[K].uoffs) + tu),       \
-					  half_to_float(mat.map[K].vscale) * (half_to_float(mat.map[K].voffs) + tv), 0u,   \
-					  mat.map[K].width > 0 ? mat.map[K].width : 1, mat.map[K].height > 0 ? mat.map[K].height : 1)) - \
-	  mk3(0.5f, 0.5f, 0.5f)) *                                                                         \
-	 2.0f)
-		const f4 texel = RT_LAYER(0);
-		if (mat_flag(mflags, MF_ALPHA) && texel.w < 0.5f)
-			alpha_skip = true; // getShadingData.h:145-149: nothing else of the surface is evaluated
-		else
-		{
-			sd.color = sd.color * xyz(texel);
-			// second and third layers are additive (getShadingData.h:153-166)
-			if (mat_flag(mflags, MF_2ND_DIFFUSE_MAP) && mat.map[1].addr < sc.texture_count)
-				sd.color = sd.color + xyz(RT_LAYER(1));
-			if (mat_flag(mflags, MF_3RD_DIFFUSE_MAP) && mat.map[2].addr < sc.texture_count)
-				sd.color = sd.color + xyz(RT_LAYER(2));
-			// normal mapping, level 0 only (getShadingData.h:169-200); the third layer reads the descriptor of the
-			// second one there (:189-196) — kept.  The tangent frame stays the one of the unperturbed normal.
-			if (mat_flag(mflags, MF_NORMAL_MAP) && mat.map[3].addr < sc.texture_count)
-			{
-				f3 sn = RT_NORMAL_LAYER(3);
-				if (mat_flag(mflags, MF_2ND_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
-					sn = sn + RT_NORMAL_LAYER(4);
-				if (mat_flag(mflags, MF_3RD_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
-					sn = sn + RT_NORMAL_LAYER(4);
-				sn = normalize(sn);
-				iN = normalize((Tg * sn.x + Bt * sn.y) + iN * sn.z); // tangentToWorld, tools.h:214
-			}
-			// getShadingData.h:150 and :206 both multiply by the texel
-			sd.color = sd.color * xyz(texel);
-		}
-#undef RT_LAYER
-#undef RT_NORMAL_LAYER
+		if (tex->flags & TEXSHADE_VALID)
+			sd.color = tex->color, iN = tex->iN, alpha_skip = (tex->flags & TEXSHADE_ALPHA_SKIP) != 0u;
 	}
+	else if (TEX && pt_has_textures(sc, sf))
+		pt_textures(sc, cam, D, h.t, sf, sd.color, iN, alpha_skip);
 	// alpha pass-through (Kernels.cu:633-647): the path continues behind the surface, state untouched
 	if (alpha_skip)
 	{
