@@ -47,7 +47,7 @@ LANE_LOADS_PEAK = 600.0e9
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 NODE_BYTES = 64.0  # rt::Node4c: four 16-byte rows (csrc/rt_types.h) — also SURVEY §8(d)'s "64 B per popped inner node"
 NODE_ROWS = 4.0
-STAGE_KERNELS = {"primary": "k_primary_stream<false>", "bounce": "k_trace_stream<false, false>",
+STAGE_KERNELS = {"primary": "k_primary_packet<false>", "bounce": "k_trace_stream<false, false>",
                  "shadow": "k_trace_stream<true, false>", "shade": "k_shade_pt<false>"}
 
 
@@ -405,36 +405,26 @@ def main():
                                                  "tris_shadow", "shaded", "lds_extend", "lds_shadow")}
         prim = {k: float(cnt0[k]) for k in ("rays_extend", "inner_extend", "tris_extend", "lds_extend")}
         bounce = {k: per_step[k] - prim[k] for k in prim}
-        algo_primary = prim["rays_extend"] * (32 + 32 + 16) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
-        algo_bounce = bounce["rays_extend"] * (32 + 16) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
-        # shadow: 48 B ray in + traversal (the 32 B read-modify-write of the radiance of an unoccluded ray is not counted: the
-        # kernels keep no count of them — a lower bound)
+        # ---- algorithmic bytes per step, stage by stage ---------------------------------------------------------
+        # primary: 16 B direction + 20 B hit record written per ray (pinhole camera: no origin record), traversal per RAY;
+        # bounce: 32 B ray in + 20 B hit out; shadow: 48 B ray in (the 32 B read-modify-write of an unoccluded ray's radiance is
+        # not counted: no count of them is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
+        algo_primary = prim["rays_extend"] * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
+        algo_bounce = bounce["rays_extend"] * (32 + 20) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
         algo_shadow = per_step["rays_shadow"] * 48 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
-        # shade: path state in (origin, direction, hit 16 + 4 B; throughput from depth 1 on), 96 + 48 B gathered per shaded
-        # hit, <= 48 B per emitted shadow / extension ray, 16 B radiance per path (+ 16 B connection radiance at depth 0)
-        paths_in = per_step["rays_extend"]
-        algo_shade = (paths_in * (32 + 20 + 16) + bounce["rays_extend"] * 16 + primaries * 16 + per_step["shaded"] * (96 + 48) +
-                      per_step["rays_shadow"] * 48 + bounce["rays_extend"] * 48)
-        algo_extend = algo_primary + algo_bounce
+        # shade: depth-0 entries read direction + hit record (36 B) and write 16 B radiance (+ 16 B for the connection term of a
+        # path that emits no shadow ray); deeper entries read origin, direction, throughput, hit record (68 B); a shaded hit gathers
+        # its 96 B shading record and 48 B of material; 48 B per emitted shadow ray, 48 B per emitted extension ray
+        algo_shade = (prim["rays_extend"] * (36 + 16) + max(0.0, prim["rays_extend"] - per_step["rays_shadow"]) * 16 +
+                      bounce["rays_extend"] * 68 + per_step["shaded"] * (96 + 48) + per_step["rays_shadow"] * 48 + bounce["rays_extend"] * 48)
 
-        # one render call launches the extend kernel (max_depth + 1) x sub-batches times; the sub-batches run on their own
-        # HIP streams, so launches of different sub-batches overlap and each launch's duration is stretched by the share of
-        # the chip it gets.  Reported: bytes and duration of the average launch as it ran (what rocprofv3 shows), and the
-        # mean number of kernels in flight (sum of all kernel durations / wall time) beside it.
-        launches_per_step = ext_launches / max(1, args.steps)
-        bytes_per_launch = algo_extend / max(1.0, launches_per_step)
-        ms_events = ext_ms / max(1, ext_launches)
-        ms_device = clock["extend_ticks"] * 1e-5 / max(1, clock["extend_launches_timed"])
-        ms_per_launch = ms_device if clock["extend_launches_timed"] else ms_events
-        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
-        concurrency = busy_ms / (elapsed * 1e3) if elapsed > 0 else 1.0
-
-        # every stage alone on the chip: one sub-batch's worth of samples on one stream, hipEvents around each launch
+        # ---- every stage alone on the chip: one sub-batch's worth of samples on one stream, hipEvents around each launch.  The
+        # extension and shadow queues of a depth normally share ONE launch (k_trace_fused); for this table they are launched apart
         ctx.set_setting("streams", 1)
         ctx.set_setting("spp", sub_spp)
         ctx.set_setting("stage_timing", 1)
-        ctx.set_setting("overlap", 0)  # (no connection wave beside the next depth's stages: every launch has the chip to itself)
+        ctx.set_setting("overlap", 0)
+        ctx.set_setting("fuse", 0)
         ctx.render_frame(scene.camera, pkg.RESET)
         ser_frames, acc = 3, {}
         for k in range(ser_frames):
@@ -445,93 +435,128 @@ def main():
         ctx.set_setting("streams", args.streams)
         ctx.set_setting("spp", args.spp)
         ctx.set_setting("overlap", args.overlap)
+        ctx.set_setting("fuse", int(extra.get("fuse", 1)))
         ser = {"primary": acc["primaryTime"], "bounce": acc["secondaryTime"] + acc["deepTime"], "shadow": acc["shadowTime"],
-               "shade": acc["shadeTime"]}
+               "shade": acc["shadeTime"], "resolve": acc["finalizeTime"]}
         frac_of_step = 1.0 / subs  # one sub-batch = 1 / subs of a step's samples
         algo = {"primary": algo_primary * frac_of_step, "bounce": algo_bounce * frac_of_step,
                 "shadow": algo_shadow * frac_of_step, "shade": algo_shade * frac_of_step}
         launches = {"primary": 1, "bounce": args.max_depth, "shadow": args.max_depth, "shade": args.max_depth + 1}
+        # what binds a stage: the traversal kernels issue VALU instructions nearly every cycle at half-full waves while the BVH is
+        # served from LDS / L1 / L2 / the Infinity Cache (their algorithmic byte rate exceeds the HBM peak: "cache_served"); the
+        # shade kernel streams the path state and is the one stage whose time is HBM bytes
+        bound = {"primary": "valu", "bounce": "valu", "shadow": "valu", "shade": "hbm"}
         pm, fresh = load_stage_counters(args.stage_json, scene.name, args.spp, args.streams)
         source = None
         if pm:
             source = {"file": os.path.relpath(args.stage_json, ROOT), "tag": pm.get("tag"), "csrc_hash": pm.get("csrc_hash"),
-                      "matches_running_sources": fresh}
+                      "matches_running_sources": fresh, "valu_busy_calibration": pm.get("valu_busy_calibration")}
         stages = []
+        chip_hbm_bytes_per_step = 0.0 if (pm and fresh) else None
         for name in ("primary", "bounce", "shadow", "shade"):
             s_ms = ser[name]
-            ent = {"stage": name, "kernel": STAGE_KERNELS[name], "launches_per_sub_batch": launches[name],
+            a_gbs = algo[name] / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None
+            ent = {"stage": name, "kernel": STAGE_KERNELS[name], "bound": bound[name], "launches_per_sub_batch": launches[name],
                    "serialised_ms_per_sub_batch": round(s_ms, 4),
                    "algorithmic_bytes_per_sub_batch": algo[name],
-                   "algorithmic_gbs": round(algo[name] / (s_ms * 1e-3) / 1e9, 1) if s_ms > 0 else None,
-                   "algorithmic_frac_of_hbm_peak": round(algo[name] / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if s_ms > 0 else None}
+                   "algorithmic_gbs": round(a_gbs, 1) if a_gbs else None,
+                   "algorithmic_frac_of_hbm_peak": round(a_gbs / HBM_PEAK_GBS, 4) if a_gbs else None,
+                   # above 1: the bytes the algorithm asks for are served by the caches, not by HBM (see counter_hbm_* for HBM)
+                   "cache_served": bool(a_gbs and a_gbs > HBM_PEAK_GBS)}
             k = pm["kernels"].get(STAGE_KERNELS[name]) if (pm and fresh) else None
             if k:
                 n = launches[name]
                 hbm, insts = k.get("hbm_bytes_per_dispatch"), k.get("sq_insts_valu_per_dispatch")
                 lanes = k.get("valu_lanes_per_instruction")
                 pm_ms = k.get("avg_dispatch_us", 0.0) * 1e-3 * n  # the same dispatches under the (serialising) PMC passes
+                if hbm and chip_hbm_bytes_per_step is not None:
+                    chip_hbm_bytes_per_step += hbm * n * subs
+                rate = insts * n / (pm_ms * 1e-3) if (insts and pm_ms > 0) else None
                 ent.update({
                     "counter_hbm_bytes_per_sub_batch": hbm * n if hbm else None,
                     "counter_hbm_gbs": round(hbm * n / (pm_ms * 1e-3) / 1e9, 1) if (hbm and pm_ms > 0) else None,
                     "counter_hbm_frac_of_peak": round(hbm * n / (pm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (hbm and pm_ms > 0) else None,
+                    "counter_over_algorithmic_bytes": round(hbm * n / algo[name], 3) if (hbm and algo[name] > 0) else None,
                     "counter_ms_per_sub_batch": round(pm_ms, 4),
                     "valu_wave_insts_per_sub_batch": insts * n if insts else None,
                     "valu_lanes_active_of_64": lanes,
-                    # issue fraction: wave-instructions over the guide's 2-cycle issue rate; lane-weighted: x lanes / 64 = the
-                    # share of the chip's f32 lane-slots that did work
-                    "valu_issue_frac": round(insts * n / (pm_ms * 1e-3) / VALU_ISSUE_PEAK, 4) if (insts and pm_ms > 0) else None,
-                    "valu_lane_weighted_frac": round(insts * n / (pm_ms * 1e-3) / VALU_ISSUE_PEAK * lanes / 64.0, 4) if (insts and lanes and pm_ms > 0) else None,
-                    # the counters' own answer: share of SIMD cycles a VALU instruction was executing (SQ_ACTIVE_INST_VALU in
-                    # quad-cycles over GRBM_GUI_ACTIVE x CUs x SIMDs) and the cycles one wave64 instruction of this mix occupied
-                    "valu_busy_frac": k.get("valu_busy_frac"),
+                    # wave-instructions per second against BOTH ceilings: the guide's (a wave64 instruction every 2 cycles per SIMD:
+                    # what v_fma_f32 reaches, profiles/micro/valu_calib.hip) and the 4-cycle rate at which this part issues compares,
+                    # selects, conversions and min / max (profiles/micro/valu_micro.hip) — the traversal mix is mostly those
+                    "valu_issue_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK, 4) if rate else None,
+                    "valu_issue_frac_of_4_cycle_rate": round(rate / (VALU_ISSUE_PEAK / 2), 4) if rate else None,
+                    "valu_lane_weighted_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK * lanes / 64.0, 4) if (rate and lanes) else None,
+                    # share of SIMD cycles a VALU instruction was executing, calibrated: the raw counter ratio over the ratio a pure
+                    # v_fma_f32 kernel at 8 waves per SIMD reads under the same pass (None without a calibration run)
+                    "valu_busy_frac": k.get("valu_busy_frac"), "valu_busy_raw_ratio": k.get("valu_busy_raw_ratio"),
                     "valu_cycles_per_instruction": k.get("valu_cycles_per_instruction"),
                 })
             else:
                 ent.update({"counter_hbm_bytes_per_sub_batch": None, "valu_wave_insts_per_sub_batch": None, "valu_lanes_active_of_64": None,
-                            "valu_issue_frac": None, "valu_lane_weighted_frac": None, "valu_busy_frac": None})
+                            "valu_issue_frac_of_2_cycle_rate": None, "valu_busy_frac": None})
             stages.append(ent)
+        kres = pm["kernels"].get("k_resolve") if (pm and fresh) else None
+        if kres and kres.get("hbm_bytes_per_dispatch") and chip_hbm_bytes_per_step is not None:
+            chip_hbm_bytes_per_step += kres["hbm_bytes_per_dispatch"]
 
-        # traffic of the headline (extend) launch from the same counters: primary + bounce dispatches, per launch
-        traffic = None
-        if pm and fresh:
-            kp, kb = pm["kernels"].get(STAGE_KERNELS["primary"]), pm["kernels"].get(STAGE_KERNELS["bounce"])
-            if kp and kb and kp.get("hbm_bytes_per_dispatch") and kb.get("hbm_bytes_per_dispatch"):
-                traffic = int((kp["hbm_bytes_per_dispatch"] + args.max_depth * kb["hbm_bytes_per_dispatch"]) / (1 + args.max_depth))
-        lane_loads = (NODE_ROWS * (per_step["inner_extend"] - per_step["lds_extend"]) + 3.0 * per_step["tris_extend"] + 2.0 * per_step["rays_extend"])
-        ser_extend_ms = (ser["primary"] + ser["bounce"]) / (1 + args.max_depth)  # per launch
-        ser_s = ser_extend_ms * 1e-3
+        # ---- the headline: the largest kernel by time — the shade kernel — against the HBM roofline ------------------------------
+        # achieved = algorithmic bytes per launch / mean duration of a launch, hipEvents on the launch's own stream, measured live in
+        # this process with every launch ALONE on the chip (the serialised leg above: one 64-spp sub-batch per call on one stream,
+        # the host waiting per frame) — the roofline of the kernel.  Inside the timed region four sub-batches are in flight: a launch
+        # shares the chip, its duration stretches with the company it has, and the durations of a step add up to more than the
+        # step; those figures are reported beside it (`in_timed_region`), and the chip as a whole below (`chip`).
+        shade_ms_total, shade_launches = kernel_times["shade"]
+        launches_per_step = shade_launches / max(1, args.steps)
+        bytes_per_launch = algo_shade / max(1.0, launches_per_step)
+        ms_in_region = shade_ms_total / max(1, shade_launches)
+        ms_per_launch = ser["shade"] / (args.max_depth + 1)
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        kshade = pm["kernels"].get(STAGE_KERNELS["shade"]) if (pm and fresh) else None
+        traffic = int(kshade["hbm_bytes_per_dispatch"]) if (kshade and kshade.get("hbm_bytes_per_dispatch")) else None
+        busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
+        step_ms = elapsed / args.steps * 1e3
+        kernel_share = {k: round(v / max(1e-9, sum(ser.values())), 4) for k, v in ser.items()}
         roofline = {
-            "bound": "hbm", "kernel": "extend stage: k_primary_stream<false> (depth 0) + k_trace_stream<false,false> (depth >= 1)",
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": ms_per_launch,
-            "ms_per_launch_clock": "device (first workgroup in .. last workgroup out)" if clock["extend_launches_timed"] else "hip events",
-            "ms_per_launch_hip_events": ms_events,
-            "achieved_hip_events": round(bytes_per_launch / (ms_events * 1e-3) / 1e9, 2) if ms_events > 0 else None,
-            "launches_timed": ext_launches, "launches_timed_device_clock": clock["extend_launches_timed"], "launches_per_step": launches_per_step,
-            "kernels_in_flight": round(concurrency, 3),
+            "bound": "hbm", "kernel": "k_shade_pt<false> — the largest kernel by time (%.0f %% of a sub-batch's serialised kernel time)" % (100 * kernel_share["shade"]),
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_source": source,
+            "traffic_frac_of_peak": round(traffic / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and ms_per_launch > 0) else None,
+            "traffic_over_algorithmic": round(traffic / bytes_per_launch, 3) if traffic else None,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": round(ms_per_launch, 4),
+            "ms_per_launch_clock": "hip events on the launch's stream; %d-spp sub-batch, every launch alone on the chip (streams=1, host waits per frame), this process" % sub_spp,
+            "launches_per_step": launches_per_step,
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
+            "in_timed_region": {"ms_per_launch": round(ms_in_region, 4), "launches_timed": shade_launches,
+                                "achieved": round(bytes_per_launch / (ms_in_region * 1e-3) / 1e9, 2) if ms_in_region > 0 else None,
+                                "frac": round(bytes_per_launch / (ms_in_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_in_region > 0 else None,
+                                "kernels_in_flight": round(busy_ms / (elapsed * 1e3), 3) if elapsed > 0 else None,
+                                "note": "%d sub-batches in flight: the launch shares the chip (what rocprofv3 --kernel-trace of the default command shows)" % subs},
+            # both must hold for the headline to be physical: the kernel's launches of a step fit into the step, and the bytes it
+            # is billed for do not exceed what HBM can deliver in that time
+            "cross_checks": {
+                "kernel_ms_per_step": round(ms_per_launch * launches_per_step, 3), "ms_per_step": round(step_ms, 3),
+                "kernel_time_fits_step": bool(ms_per_launch * launches_per_step <= step_ms),
+                "algorithmic_gbs_over_the_step": round(algo_shade / (step_ms * 1e-3) / 1e9, 1),
+                "algorithmic_rate_below_peak": bool(algo_shade / (step_ms * 1e-3) / 1e9 <= HBM_PEAK_GBS),
+                "all_stages_ms_per_step": round(sum(ser.values()) * subs, 3),
+                "all_stages_over_step": round(sum(ser.values()) * subs / step_ms, 3)},
+            # the whole chip over the timed region: HBM bytes of every kernel of a step by the counters / the step time
+            "chip": {"counter_hbm_bytes_per_step": chip_hbm_bytes_per_step,
+                     "counter_hbm_gbs": round(chip_hbm_bytes_per_step / (step_ms * 1e-3) / 1e9, 1) if chip_hbm_bytes_per_step else None,
+                     "counter_hbm_frac_of_peak": round(chip_hbm_bytes_per_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chip_hbm_bytes_per_step else None,
+                     "binding_ceiling": "VALU issue: a step is %.1f G wave-instructions of mostly 4-cycle operations on 1024 SIMDs" % (
+                         sum((e.get("valu_wave_insts_per_sub_batch") or 0) for e in stages) * subs / 1e9) if (pm and fresh) else None},
             "per_ray": {"inner_nodes": per_step["inner_extend"] / max(1, per_step["rays_extend"]),
-                        "inner_nodes_from_lds": per_step["lds_extend"] / max(1, per_step["rays_extend"]),
                         "triangle_tests": per_step["tris_extend"] / max(1, per_step["rays_extend"]),
+                        "primary_inner_nodes": prim["inner_extend"] / max(1, prim["rays_extend"]),
+                        "primary_triangle_tests": prim["tris_extend"] / max(1, prim["rays_extend"]),
                         "rays_per_sample": per_step["rays_extend"] / max(1.0, primaries),
                         "shadow_rays_per_sample": per_step["rays_shadow"] / max(1.0, primaries),
                         "shadow_inner_nodes": per_step["inner_shadow"] / max(1, per_step["rays_shadow"]),
-                        "shadow_triangle_tests": per_step["tris_shadow"] / max(1, per_step["rays_shadow"])},
-            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
-            # The algorithmic byte rate is NOT an HBM rate: the BVH (42 MB of 4-wide nodes + 48 MB of vertices) is served by
-            # the LDS node cache, the vector L1s, the L2s and the Infinity Cache, so it exceeds the HBM peak once a launch has
-            # the chip to itself (a fraction above 1 here says "cache-served", not "faster than the memory").
-            "serialised": {
-                "ms_per_launch": round(ser_extend_ms, 4), "spp_per_launch": sub_spp,
-                "achieved": round(bytes_per_launch / ser_s / 1e9, 2) if ser_s > 0 else None,
-                "frac": round(bytes_per_launch / ser_s / 1e9 / HBM_PEAK_GBS, 5) if ser_s > 0 else None,
-                "l1_lane_load_frac": round(lane_loads / max(1.0, launches_per_step) / ser_s / LANE_LOADS_PEAK, 5) if ser_s > 0 else None,
-                "l1_lane_load_peak_g_per_s": LANE_LOADS_PEAK / 1e9,
-                "sub_batch_ms_total": round(sum(ser.values()), 4),
-                "binding_ceiling": "VALU: the traversal kernels keep the SIMDs' VALUs busy 0.85-1.0 of the time (`stages[].valu_busy_frac`) at 34-50 of 64 lanes; HBM is not: see counter_hbm_frac_of_peak",
-            },
+                        "shadow_triangle_tests": per_step["tris_shadow"] / max(1, per_step["rays_shadow"]),
+                        "shaded_hits_per_sample": per_step["shaded"] / max(1.0, primaries)},
+            "serialised_kernel_share": kernel_share, "sub_batch_ms_total": round(sum(ser.values()), 4),
             "valu_issue_peak_g_per_s": VALU_ISSUE_PEAK / 1e9,
-            "valu_issue_peak_note": "guide: wave64 VALU issues over 2 cycles per SIMD-32; the counters put this instruction mix at 4.0 cycles per instruction (`stages[].valu_cycles_per_instruction`; profiles/micro/valu_micro.hip: compares / selects / conversions at ~half the guide's rate), so valu_issue_frac ~ 0.5 is a saturated SIMD: valu_busy_frac is the figure to read",
             "stages": stages,
         }
         if args.stage_rates:
@@ -542,6 +567,32 @@ def main():
                            "primary": rate(prim["rays_extend"] * f, ser["primary"]), "bounce": rate(bounce["rays_extend"] * f, ser["bounce"]),
                            "shadow": rate(per_step["rays_shadow"] * f, ser["shadow"]),
                            "stage_ms": {k: round(v, 3) for k, v in acc.items()}}
+
+    # ---- the configuration the reference actually runs: BLUENOISE 1 (context/settings.h:12, Kernels.cu:391-394, :712-719) --------
+    # the primary rays' jitter and the depth-0 light samples come from the blue-noise table instead of the hash RNG.  Timed with a
+    # table of the reference's LAYOUT filled with our own numbers (scenes.synthetic_blue_noise: the published table belongs to
+    # the reference tree and reaches the core through rfwhip_set_blue_noise) — same fetches, same arithmetic, other values.
+    bluenoise = None
+    if not args.no_roofline and rank == 0 and world == 1 and args.integrator == "pt":
+        ctx.set_blue_noise(pkg.scenes.synthetic_blue_noise())
+        ctx.set_setting("sampler", "bluenoise")
+        ctx.set_setting("stage_timing", 0)
+        bn_steps = max(2, min(args.steps, 4))
+        ctx.render_async(scene.camera, pkg.RESET)
+        ctx.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(bn_steps):
+            ctx.render_async(scene.camera, pkg.CONVERGE)
+        ctx.wait()
+        torch.cuda.synchronize()
+        bn_ms = (time.perf_counter() - t0) / bn_steps * 1e3
+        ctx.set_setting("sampler", "hash")
+        ctx.set_setting("stage_timing", 1)
+        bluenoise = {"value": round(float(W) * H * args.spp / (bn_ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(bn_ms, 4), "steps": bn_steps,
+                     "over_hash_sampler": round((float(W) * H * args.spp / (bn_ms * 1e-3) / 1e6) / value, 4),
+                     "note": "sampler=bluenoise (the reference's BLUENOISE 1 branch) with a synthetic table of the reference's layout; "
+                             "the headline runs the reference's own hash-RNG branch (`#else`)"}
 
     # ---- CPU baselines: the oracle (a port, not the reference build) on this box's host cores ---------------------------
     cpu_baseline, parity, cpu_parity = None, None, None
@@ -646,7 +697,7 @@ def main():
                        "pipeline": int(args.pipeline) if (world > 1 and comm is None) else None,
                        "spp_per_step": args.spp, "streams": args.streams, "settings": extra or None,
                        "sample_group": int(ctx.get_setting("sample_group")), "csrc_hash": csrc_hash()},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_parity": cpu_parity,
+            "roofline": roofline, "sampler_bluenoise": bluenoise, "cpu_baseline": cpu_baseline, "cpu_baseline_parity": cpu_parity,
             # per-pixel RGB L2 between the GPU image and the oracle image of the same sample indices (None when the CPU leg is off)
             "parity_vs_cpu_baseline": parity,
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_times.items()},

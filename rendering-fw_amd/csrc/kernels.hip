@@ -63,7 +63,16 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #define RT_ANY_WAVES 8 // occlusion kernels (fewer registers, less LDS)
 #endif
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 5 // the textured shade kernel, since its texture layers run as a pre-pass (4 waves at 128 registers before)
+#define RT_SHADE_WAVES 4 // the textured shade kernel: 128 registers
+#endif
+// Texture layers of a batch of hits as a pre-pass whose result goes through LDS (shade_tex_prepass_item), so that the registers of
+// the trilinear fetches are free before the BSDF needs its own — round 3's verdict asked for it.  Measured on the MI355X (atrium,
+// 256 spp per step) and OFF: with the pre-pass the kernel does fit 96 registers = 5 waves per SIMD, but it still spills 17 dwords
+// around the BSDF and repeats the surface set-up (shading record, material, normals, tangent frame) in both passes: 2274
+// Msamples/s at 5 waves and 2371 at 4 (shade 27.6 / 23.1 ms per 64-spp sub-batch) against 2498 with the layers fetched inside
+// pt_shade at 4 waves (20.2 ms).  Bit-identical images either way (same functions, same order).
+#ifndef RT_TEX_PREPASS
+#define RT_TEX_PREPASS 0
 #endif
 // packet form of the primary wave (trace_packet): 0 = the nearest entered child first, the others in no particular order (3 of
 // the 5 comparators of the sorting network); 1 = all entered children by distance
@@ -383,7 +392,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 				WaveCounters *c = p.wv.counters;
 				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
 			}
-			if (TEX)
+			if (TEX && RT_TEX_PREPASS)
 			{
 				// the texture layers ran as a pre-pass of this batch (shade_tex_prepass_item; the device kernel calls it for the whole
 				// wave before this function, the emulation right here): their result comes back from the lane's record
@@ -406,10 +415,14 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		// depth 0 initialises the slot (no clear pass); later depths accumulate.  One path per slot => no race.
 		if (p.depth == 0)
 		{
-			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, 1.0f);
+			// A path that ends here — a sky miss, an emitter, nothing to continue with — never gets a connection term: its slot of
+			// rad_nee is neither initialised nor read; alpha -1 tells the resolve (|alpha| is the alpha: the pt integrator's is 1).
+			// 16 bytes less written here and 16 less read there for every such path (two in five on the terrain).
+			const bool ends = p.wv.rad_nee && !out.emit_shadow && !out.emit_ext;
+			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, ends ? -1.0f : 1.0f);
 			// the connection wave of depth 0 STORES its slot's first term (connect_store), so only the paths that emit no shadow
-			// ray here initialise theirs: 16 bytes less written per connecting path, in the one kernel that is short of bytes
-			if (p.wv.rad_nee && !out.emit_shadow)
+			// ray here but go on initialise theirs: 16 bytes less written per connecting path, in the one kernel that is short of bytes
+			if (p.wv.rad_nee && !out.emit_shadow && out.emit_ext)
 				p.wv.rad_nee[slot] = mk4(0, 0, 0, 0);
 		}
 		else if (out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
@@ -623,23 +636,26 @@ RT_FN void resolve_item(const Params &p, uint32_t li)
 		const unsigned long long base = pixel_to_slot(p.fr, tile, pix, s0);
 		const f4 *const r = p.wv.rad + base, *const q = p.wv.rad_nee ? p.wv.rad_nee + base : nullptr;
 		uint32_t i = 0;
+		// (alpha < 0: a path that ended at depth 0 — no connection record was written for it, shade_pt_item)
 		for (; i + 8u <= g; i += 8u)
 		{
 			f4 rv[8], qv[8];
 			for (int k = 0; k < 8; k++)
-				rv[k] = r[i + k], qv[k] = q ? q[i + k] : mk4(0, 0, 0, 0);
+				rv[k] = r[i + k];
+			for (int k = 0; k < 8; k++)
+				qv[k] = (q && !(rv[k].w < 0.0f)) ? q[i + k] : mk4(0, 0, 0, 0);
 			for (int k = 0; k < 8; k++)
 			{
-				a.x += rv[k].x, a.y += rv[k].y, a.z += rv[k].z, a.w += rv[k].w;
-				if (q)
+				a.x += rv[k].x, a.y += rv[k].y, a.z += rv[k].z, a.w += fabsf(rv[k].w);
+				if (q && !(rv[k].w < 0.0f))
 					a.x += qv[k].x, a.y += qv[k].y, a.z += qv[k].z;
 			}
 		}
 		for (; i < g; i++)
 		{
 			const f4 rv = r[i];
-			a.x += rv.x, a.y += rv.y, a.z += rv.z, a.w += rv.w;
-			if (q)
+			a.x += rv.x, a.y += rv.y, a.z += rv.z, a.w += fabsf(rv.w);
+			if (q && !(rv.w < 0.0f))
 			{
 				const f4 qv = q[i];
 				a.x += qv.x, a.y += qv.y, a.z += qv.z;
@@ -1492,6 +1508,13 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 	PacketStack stk;
 	int cur_inst = -1;
 	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	if (COUNT && active && cur != ENTRY_DONE) // (the root: popped by every ray)
+	{
+		if (!(cur & ENTRY_LEAF))
+			st.inner++;
+		else if (!(cur & ENTRY_TLAS))
+			st.tris += ((cur >> 27) & 7u) + 1u;
+	}
 	for (;;)
 	{
 		while (!(cur & ENTRY_LEAF))
@@ -1536,7 +1559,20 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 				}
 			}
 			if (COUNT)
-				st.inner += active ? 1u : 0u;
+			{
+				// statistics per RAY, as its own traversal of this tree would count them: a lane counts the children IT enters (an inner
+				// node popped later, or the triangles of a leaf tested later), not every node the wave walks for its neighbours
+				const unsigned long long me = 1ull << __lane_id();
+				for (int k = 0; k < 4; k++)
+					if (m[k] & me)
+					{
+						const uint32_t e = ent[k];
+						if (!(e & ENTRY_LEAF))
+							st.inner++;
+						else if (!(e & ENTRY_TLAS))
+							st.tris += ((e >> 27) & 7u) + 1u;
+					}
+			}
 			// the nearest child some lane enters comes next, the other entered children go on the stack (scalar unit)
 			uint32_t k0 = packet_key(tk[0], m[0], ref_lane), k1 = packet_key(tk[1], m[1], ref_lane);
 			uint32_t k2 = packet_key(tk[2], m[2], ref_lane), k3 = packet_key(tk[3], m[3], ref_lane);
@@ -1595,8 +1631,6 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			for (uint32_t i = 0; i < count; i++)
 			{
 				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
-				if (COUNT)
-					st.tris += active ? 1u : 0u;
 				if (tri_test<true>(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v,
 								   fbits(v0[3]), (uint32_t)hit.prim))
 				{
@@ -1772,7 +1806,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		else
 			break;
 		__builtin_amdgcn_wave_barrier();
-		if (TEX)
+		if (TEX && RT_TEX_PREPASS)
 		{
 			shade_tex_prepass_item<TEX>(p, idx, act, ctx);
 			__builtin_amdgcn_wave_barrier();
@@ -2281,6 +2315,13 @@ template <bool COUNT> void trace(const SceneView &sc, const bool *active, const 
 	Stack stk;
 	int cur_inst = -1;
 	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
+	if (COUNT && cur != ENTRY_DONE)
+	{
+		if (!(cur & ENTRY_LEAF))
+			st.inner += nact;
+		else if (!(cur & ENTRY_TLAS))
+			st.tris += nact * (((cur >> 27) & 7u) + 1u);
+	}
 	const char *const nodes = (const char *)sc.nodes4f;
 	for (;;)
 	{
@@ -2321,7 +2362,17 @@ template <bool COUNT> void trace(const SceneView &sc, const bool *active, const 
 					m[k] = 0ull;
 			}
 			if (COUNT)
-				st.inner += nact;
+				for (int k = 0; k < 4; k++) // per ray: the children IT enters (device: trace_packet)
+				{
+					const uint32_t e = nd.entry[k];
+					uint32_t n = 0;
+					for (int l = 0; l < WAVE; l++)
+						n += (uint32_t)((m[k] >> l) & 1ull);
+					if (!(e & ENTRY_LEAF))
+						st.inner += n;
+					else if (!(e & ENTRY_TLAS))
+						st.tris += n * (((e >> 27) & 7u) + 1u);
+				}
 			uint32_t kk[4], ee[4];
 			for (int k = 0; k < 4; k++)
 				kk[k] = m[k] ? fbits(tk_ref[k]) : 0xFFFFFFFFu, ee[k] = nd.entry[k];
@@ -2370,8 +2421,6 @@ template <bool COUNT> void trace(const SceneView &sc, const bool *active, const 
 			{
 				const f4 *tv = sc.tri_verts + 3u * (first + i);
 				const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-				if (COUNT)
-					st.tris += nact;
 				for (int l = 0; l < WAVE; l++)
 					if (tri_test<true>(sp.o[l], sp.d[l], t_min, hit[l].t, xyz(v0), xyz(v1), xyz(v2), hit[l].u, hit[l].v, fbits(v0.w), (uint32_t)hit[l].prim))
 					{

@@ -5,6 +5,8 @@
 #   gpurun_out/<tag>_pmc_{fetch,write,tcc,tcp,sq_issue,sq_lanes}.md   one rocprofv3 --pmc pass each (no trace flags)
 #   gpurun_out/<tag>_traffic_extend.json HBM / L2 bytes per extend launch derived from the passes (-> profiles/traffic_extend.json)
 #   gpurun_out/<tag>_stage_counters.json per-kernel counters + the csrc hash they belong to (-> profiles/stage_counters.json, read by bench.py)
+# (the counter passes run with fuse=0: extension and shadow rays of a depth in their own launches, so that every stage has its
+#  own kernel name to attribute counters to; the bench line and the kernel trace run the default, fused form)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
 mkdir -p $R/gpurun_out
@@ -12,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() { # name counters...
   name=$1; shift
   d=$R/gpurun_out/${tag}_pmc_$name; rm -rf $d
-  (cd $R && timeout 1200 rocprofv3 --pmc "$@" -d $d -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $d.log 2>&1)
+  (cd $R && timeout 1200 rocprofv3 --pmc "$@" -d $d -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --set fuse=0 > $d.log 2>&1)
   db=$(find $d -name "*.db" | head -1)
   (cd $R && python profiles/summarize.py pmc $db > gpurun_out/${tag}_pmc_$name.md; head -6 gpurun_out/${tag}_pmc_$name.md)
   echo $db
