@@ -221,7 +221,11 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  (hides kernel tails when launches are small); "0": in order on the sub-batch's stream; "-1" (default):
  *                  chosen by the size of the render call
  *   sub_batch_paths = a render call's spp are cut into concurrent sub-batches only if each gets at least this many path
- *                  slots and there are four of them (default 50000000: 1080p from 128 spp per call)
+ *                  slots and there are four of them (default 50000000: 1080p from 128 spp per call).  A call below the
+ *                  threshold stays ONE sub-batch and rotates through the ring (below) — whose depth in turn depends on the
+ *                  device's FREE memory (232 B of path state + 32 B of radiance per slot and ring entry: 1080p at 64 spp =
+ *                  35 GB per entry; the ring falls back 3 -> 2 -> 1 before the call fails), so what this setting does to
+ *                  throughput depends on how much HBM the rest of the process holds
  *   sample_group = slot layout: up to this many samples of a pixel sit side by side in one wave (power of two <= 64,
  *                  default 64 = a wave is one pixel; the largest such group that divides every sub-batch of a call is
  *                  used: 32 for a 128-spp call cut into four sub-batches; 1 = a wave is one 8x8 tile of one sample).
@@ -240,6 +244,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  form — a wave walks the tree once for the rays of its 64 slots (scalar node fetches, one stack per wave;
  *                  used when the samples of a pixel sit side by side, sample_group >= 2, or the launch is large, and only
  *                  for scenes whose trees fit its 61-entry stack; hit records are those of the per-lane kernels)
+ *   fuse         = "1" (default): the extension rays of depth d + 1 and the shadow rays of depth d share ONE launch (both
+ *                  queues are complete when the shade stage of depth d has finished; one kernel tail per depth instead of
+ *                  two: 1-spp frames 1.34 -> 1.21 ms); "0": a launch each.  Never changes the image
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

@@ -617,7 +617,52 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t 
 	for (uint32_t q = t; q < (uint32_t)WORK_QUEUES * 8u; q += nt)
 		work[q] = 0u;
 	if (t == 0u)
+		c->probe_valid = 0u, c->stack_overflow = 0u, c->primary_exit = 0u;
+}
+
+// The pt primary wave re-arms the counters of its call ITSELF (Params::arm), so that a launch chain does not begin with a
+// one-workgroup kernel that — small as it is — waits for a slot among the persistent grids of the chains in flight (1.07 ms on
+// average in round 3's concurrent trace, at the head of every chain):
+//   primary_arm_begin  workgroup 0, on entry: everything the LATER stages of this call read or add to — ext / shadow counts, the
+//                      queue heads of the later launches, probe and overflow flags, the clocks of the deeper extend launches —
+//                      nothing the primary wave itself touches, so no other workgroup needs to wait for it;
+//   primary_arm_end    the LAST workgroup to leave (one atomic per workgroup): what the primary wave itself used — its queue
+//                      head(s), its clock — ready for the next call on this set of counters.
+// The host launches k_init_counters only for a set that is not in this state (first use, after a parity frame or rfwhip_trace_rays).
+RT_FN void primary_arm_begin_item(WaveCounters *c, uint32_t primary_count, uint32_t own_queue, uint32_t t, uint32_t nt)
+{
+	for (uint32_t d = t; d < (uint32_t)MAX_DEPTH_SLOTS; d += nt)
+	{
+		c->ext[d] = c->ext_n[d] = d == 0u ? primary_count : 0u, c->shadow[d] = c->shadow_n[d] = 0u;
+		if (d != 0u)
+		{
+			if (c->t_last[d] > c->t_first[d]) // fold the previous call's extend-stage clock
+			{
+#if defined(__HIP_DEVICE_COMPILE__)
+				atomicAdd(&c->ext_ticks, c->t_last[d] - c->t_first[d]);
+				atomicAdd(&c->ext_timed, 1u);
+#else
+				c->ext_ticks += c->t_last[d] - c->t_first[d], c->ext_timed++;
+#endif
+			}
+			c->t_first[d] = ~0ull, c->t_last[d] = 0ull;
+		}
+	}
+	uint32_t *const work = &c->work[0][0];
+	for (uint32_t q = t; q < (uint32_t)WORK_QUEUES * 8u; q += nt)
+		if (q / 8u != own_queue)
+			work[q] = 0u;
+	if (t == 0u)
 		c->probe_valid = 0u, c->stack_overflow = 0u;
+}
+RT_FN void primary_arm_end_item(WaveCounters *c, uint32_t own_queue)
+{
+	if (c->t_last[0] > c->t_first[0])
+		c->ext_ticks += c->t_last[0] - c->t_first[0], c->ext_timed++;
+	c->t_first[0] = ~0ull, c->t_last[0] = 0ull;
+	for (uint32_t x = 0; x < 8u; x++)
+		c->work[own_queue][x] = 0u;
+	c->primary_exit = 0u;
 }
 
 // One pixel: its samples in sample order whatever the slot layout (rt_core.h: sample groups) — the image is independent of
@@ -960,9 +1005,41 @@ __device__ __forceinline__ void clock_out(WaveCounters *wc, uint32_t depth)
 		atomicMax(&wc->t_last[depth], (unsigned long long)wall_clock64());
 }
 
+// Params::arm (pt primary kernels): see primary_arm_begin_item
+__device__ __forceinline__ void primary_arm_begin(const Params &p, uint32_t primary_count)
+{
+	if (p.arm && blockIdx.x == 0)
+		primary_arm_begin_item(p.wv.counters, primary_count, p.queue, threadIdx.x, blockDim.x);
+}
+__device__ __forceinline__ void primary_arm_end(const Params &p)
+{
+	if (!p.arm)
+		return;
+	__syncthreads(); // (every wave of this workgroup is done with the queue)
+	if (threadIdx.x == 0)
+	{
+		WaveCounters *const wc = p.wv.counters;
+		__threadfence();
+		if (atomicAdd(&wc->primary_exit, 1u) == gridDim.x - 1u)
+		{
+			// the last workgroup out: every other one has made its clock_out and its last queue access before its increment
+			__threadfence();
+			const unsigned long long t1 = atomicMax(&wc->t_last[0], 0ull), t0 = atomicMin(&wc->t_first[0], ~0ull);
+			if (t1 > t0)
+				atomicAdd(&wc->ext_ticks, t1 - t0), atomicAdd(&wc->ext_timed, 1u);
+			atomicExch(&wc->t_first[0], ~0ull), atomicExch(&wc->t_last[0], 0ull);
+			for (uint32_t x = 0; x < 8u; x++)
+				atomicExch(&wc->work[p.queue][x], 0u);
+			atomicExch(&wc->primary_exit, 0u);
+		}
+	}
+}
+
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
+	if (GEN == GEN_PT)
+		primary_arm_begin(p, fixed_count);
 	clock_in(p.wv.counters, p.depth);
 	RT_STACK_DECL_CLOSEST
 	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : fixed_count;
@@ -975,6 +1052,8 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 			extend_item<GEN, COUNT>(p, i, i < count, ctx);
 	}
 	clock_out(p.wv.counters, p.depth);
+	if (GEN == GEN_PT)
+		primary_arm_end(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1359,10 +1438,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) __attribute__((am
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primary_stream(const Params p, const uint32_t count)
 {
+	primary_arm_begin(p, count);
 	clock_in(p.wv.counters, 0);
 	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
 	stream_rays<STREAM_PRIMARY_PT, COUNT>(p, count, ctx);
 	clock_out(p.wv.counters, 0);
+	primary_arm_end(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1663,6 +1744,7 @@ __device__ __forceinline__ const Params &fresh_params()
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet(const Params p, const uint32_t count)
 {
+	primary_arm_begin(p, count);
 	clock_in(p.wv.counters, 0);
 	uint32_t *const head = &p.wv.counters->work[p.queue][0];
 	const uint32_t lane = __lane_id();
@@ -1721,6 +1803,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 		ctx.add64(&wc->rays_extend, nrays);
 	}
 	clock_out(p.wv.counters, 0);
+	primary_arm_end(p);
 }
 
 template <bool COUNT>
@@ -2481,9 +2564,13 @@ template <bool COUNT> void primary(const Params &p, uint32_t count)
 
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
+	if (gen == GEN_PT && p.arm)
+		primary_arm_begin_item(p.wv.counters, max_items, p.queue, 0u, 1u);
 	if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= (16u << 20))) // (the device's rule)
 	{
 		count ? packet_emu::primary<true>(p, max_items) : packet_emu::primary<false>(p, max_items);
+		if (p.arm)
+			primary_arm_end_item(p.wv.counters, p.queue);
 		return;
 	}
 	Ctx ctx(p);
@@ -2499,6 +2586,8 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 		else
 			count ? extend_item<GEN_PARITY, true>(p, i, true, ctx) : extend_item<GEN_PARITY, false>(p, i, true, ctx);
 	}
+	if (gen == GEN_PT && p.arm)
+		primary_arm_end_item(p.wv.counters, p.queue);
 }
 void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t)
 {

@@ -399,6 +399,7 @@ struct rfwhip_context
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
 	int refill = 15; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave;
 					// bit 3: the pt primary wave in packet form (wave-uniform traversal, kernels.hip: trace_packet)
+	bool counters_armed[MAX_SUB] = {}; // the set of wave counters is as a pt launch chain leaves it: its next primary kernel re-arms it
 	bool packet_ok = false; // the scene's trees fit the packet kernel's stack and its 32-bit node offsets
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
@@ -1900,7 +1901,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		p.fr.spp = spp_i;
 		p.fr.sample_base = c->samples_done + s_begin;
 		const uint32_t n = c->fr.slots * spp_i;
-		rtk::launch_init_counters(p.wv.counters, n, s);
+		// pt: the primary kernel re-arms the counters itself (kernels.hip: primary_arm_begin) once the set is in the state such a
+		// chain leaves it in; the explicit launch is for a set's first use, and after a parity frame or rfwhip_trace_rays
+		p.arm = (c->integrator == 1 && c->counters_armed[i]) ? 1u : 0u;
+		if (!p.arm)
+			rtk::launch_init_counters(p.wv.counters, n, s);
+		c->counters_armed[i] = c->integrator == 1;
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
 		if (c->integrator == 0)
@@ -2539,6 +2545,7 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 	RF_TRY(dm::h2d(c->d_dir2[1].p, d4.data(), n * sizeof(f4), s));
 	rtk::Params p;
 	fill_params(c, nullptr, p);
+	c->counters_armed[0] = false; // (this launch leaves its queue head used: the next frame's chain re-arms explicitly)
 	rtk::launch_init_counters(p.wv.counters, 0, s);
 	rtk::launch_set_ext_count(p.wv.counters, 1, (uint32_t)n, s);
 	p.depth = 1, p.queue = 0, p.group = 16;
