@@ -294,8 +294,8 @@ def main():
         except Exception as e:
             # a SCALE number must come from host C++ -> RCCL; another path is taken only when asked for (--gather torch)
             raise SystemExit("bench.py: rfwhip_comm_create failed on rank %d (%s) — the library's RCCL gather is the N > 1 path; "
-                             "run with --gather torch to measure the torch.distributed gather instead, or RFWHIP_TRANSPORT=peer "
-                             "with --mode group to take RCCL out of the picture" % (rank, str(e)[:300]))
+                             "run with --gather torch to measure the torch.distributed gather instead, or --mode group --transport peer "
+                             "to take RCCL out of the picture" % (rank, str(e)[:300]))
     local_fb = gathered_flat = gathered = chain_stream = None
     if world > 1 and comm is None:
         local_fb = torch.empty((local_rows, W, 4), dtype=torch.float32, device=dev)

@@ -1008,12 +1008,12 @@ __device__ __forceinline__ void clock_out(WaveCounters *wc, uint32_t depth)
 // Params::arm (pt primary kernels): see primary_arm_begin_item
 __device__ __forceinline__ void primary_arm_begin(const Params &p, uint32_t primary_count)
 {
-	if (p.arm && blockIdx.x == 0)
+	if ((p.arm & 1u) && blockIdx.x == 0)
 		primary_arm_begin_item(p.wv.counters, primary_count, p.queue, threadIdx.x, blockDim.x);
 }
 __device__ __forceinline__ void primary_arm_end(const Params &p)
 {
-	if (!p.arm)
+	if (!(p.arm & 2u))
 		return;
 	__syncthreads(); // (every wave of this workgroup is done with the queue)
 	if (threadIdx.x == 0)
@@ -2564,12 +2564,12 @@ template <bool COUNT> void primary(const Params &p, uint32_t count)
 
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
 {
-	if (gen == GEN_PT && p.arm)
+	if (gen == GEN_PT && (p.arm & 1u))
 		primary_arm_begin_item(p.wv.counters, max_items, p.queue, 0u, 1u);
 	if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= (16u << 20))) // (the device's rule)
 	{
 		count ? packet_emu::primary<true>(p, max_items) : packet_emu::primary<false>(p, max_items);
-		if (p.arm)
+		if (p.arm & 2u)
 			primary_arm_end_item(p.wv.counters, p.queue);
 		return;
 	}
@@ -2586,7 +2586,7 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 		else
 			count ? extend_item<GEN_PARITY, true>(p, i, true, ctx) : extend_item<GEN_PARITY, false>(p, i, true, ctx);
 	}
-	if (gen == GEN_PT && p.arm)
+	if (gen == GEN_PT && (p.arm & 2u))
 		primary_arm_end_item(p.wv.counters, p.queue);
 }
 void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t)

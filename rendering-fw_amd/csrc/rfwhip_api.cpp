@@ -1903,8 +1903,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		const uint32_t n = c->fr.slots * spp_i;
 		// pt: the primary kernel re-arms the counters itself (kernels.hip: primary_arm_begin) once the set is in the state such a
 		// chain leaves it in; the explicit launch is for a set's first use, and after a parity frame or rfwhip_trace_rays
-		p.arm = (c->integrator == 1 && c->counters_armed[i]) ? 1u : 0u;
-		if (!p.arm)
+		p.arm = c->integrator == 1 ? (c->counters_armed[i] ? 3u : 2u) : 0u; // (bit 1: every pt primary leaves the set armed)
+		if (!(p.arm & 1u))
 			rtk::launch_init_counters(p.wv.counters, n, s);
 		c->counters_armed[i] = c->integrator == 1;
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
