@@ -247,6 +247,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   fuse         = "1" (default): the extension rays of depth d + 1 and the shadow rays of depth d share ONE launch (both
  *                  queues are complete when the shade stage of depth d has finished; one kernel tail per depth instead of
  *                  two: 1-spp frames 1.34 -> 1.21 ms); "0": a launch each.  Never changes the image
+ *   arm          = "0" (default): a launch chain starts with the one-workgroup kernel that re-arms the call's device counters;
+ *                  "1": the pt primary kernel does that itself (measured slower for small frames: DESIGN.md §4)
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

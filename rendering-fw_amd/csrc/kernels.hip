@@ -620,9 +620,9 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t 
 		c->probe_valid = 0u, c->stack_overflow = 0u, c->primary_exit = 0u;
 }
 
-// The pt primary wave re-arms the counters of its call ITSELF (Params::arm), so that a launch chain does not begin with a
-// one-workgroup kernel that — small as it is — waits for a slot among the persistent grids of the chains in flight (1.07 ms on
-// average in round 3's concurrent trace, at the head of every chain):
+// The pt primary wave can re-arm the counters of its call ITSELF (Params::arm, setting `arm`; measured and OFF by default, see
+// rfwhip_api.cpp), so that a launch chain does not begin with a one-workgroup kernel that — small as it is — waits for a slot
+// among the persistent grids of the chains in flight (1.07 ms on average in round 3's concurrent trace, at the head of every chain):
 //   primary_arm_begin  workgroup 0, on entry: everything the LATER stages of this call read or add to — ext / shadow counts, the
 //                      queue heads of the later launches, probe and overflow flags, the clocks of the deeper extend launches —
 //                      nothing the primary wave itself touches, so no other workgroup needs to wait for it;

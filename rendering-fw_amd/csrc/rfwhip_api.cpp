@@ -408,6 +408,10 @@ struct rfwhip_context
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample;
 						   // 64 = a wave is ONE pixel: primary wave 3.67 instead of 4.01 ms per 32 spp, depth-0 shadow wave -7 %)
 	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
+	int arm = 0;	  // 1: the pt primary kernel re-arms its call's counters itself instead of a k_init_counters launch at the head of the
+					  // chain (kernels.hip: primary_arm_*).  Measured on the MI355X, same box, and OFF: 1-spp frames 1.25 against 1.20 ms,
+					  // 8 spp per step 5.00 against 4.89 ms, 256 spp per step equal — the workgroup barrier + atomic every workgroup
+					  // pays on leaving the primary kernel costs more than the 3-us kernel it replaces
 	int fuse = 1;	  // extension rays of depth d + 1 and shadow rays of depth d in one launch (kernels.hip: k_trace_fused)
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
@@ -1903,10 +1907,10 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		const uint32_t n = c->fr.slots * spp_i;
 		// pt: the primary kernel re-arms the counters itself (kernels.hip: primary_arm_begin) once the set is in the state such a
 		// chain leaves it in; the explicit launch is for a set's first use, and after a parity frame or rfwhip_trace_rays
-		p.arm = c->integrator == 1 ? (c->counters_armed[i] ? 3u : 2u) : 0u; // (bit 1: every pt primary leaves the set armed)
+		p.arm = (c->integrator == 1 && c->arm) ? (c->counters_armed[i] ? 3u : 2u) : 0u; // (bit 1: every pt primary leaves the set armed)
 		if (!(p.arm & 1u))
 			rtk::launch_init_counters(p.wv.counters, n, s);
-		c->counters_armed[i] = c->integrator == 1;
+		c->counters_armed[i] = c->integrator == 1 && c->arm;
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
 		if (c->integrator == 0)
@@ -2239,7 +2243,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse", "arm"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2307,6 +2311,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->refill = atoi(value) & 15;
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
+	else if (k == "arm")
+		c->arm = atoi(value) != 0;
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);
@@ -2380,6 +2386,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->refill);
 	else if (k == "fuse")
 		snprintf(value, cap, "%d", c->fuse);
+	else if (k == "arm")
+		snprintf(value, cap, "%d", c->arm);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "sub_batch_paths")
