@@ -450,7 +450,7 @@ def main():
         source = None
         if pm:
             source = {"file": os.path.relpath(args.stage_json, ROOT), "tag": pm.get("tag"), "csrc_hash": pm.get("csrc_hash"),
-                      "matches_running_sources": fresh, "valu_busy_calibration": pm.get("valu_busy_calibration")}
+                      "matches_running_sources": fresh, "valu_busy_validation": pm.get("valu_busy_validation")}
         stages = []
         chip_hbm_bytes_per_step = 0.0 if (pm and fresh) else None
         for name in ("primary", "bounce", "shadow", "shade"):
@@ -481,15 +481,16 @@ def main():
                     "valu_wave_insts_per_sub_batch": insts * n if insts else None,
                     "valu_lanes_active_of_64": lanes,
                     # wave-instructions per second against BOTH ceilings: the guide's (a wave64 instruction every 2 cycles per SIMD:
-                    # what v_fma_f32 reaches, profiles/micro/valu_calib.hip) and the 4-cycle rate at which this part issues compares,
-                    # selects, conversions and min / max (profiles/micro/valu_micro.hip) — the traversal mix is mostly those
+                    # what v_fma / v_mul / v_add_f32 reach, profiles/micro/valu_calib.hip) and the 4-cycle rate at which this part issues
+                    # compares, selects, conversions and min / max (profiles/micro/valu_micro.hip).  A mix of both can exceed 1.0 of the
+                    # 4-cycle rate — it is a ceiling for a mix WITHOUT 2-cycle instructions; valu_busy_frac weights the classes
                     "valu_issue_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK, 4) if rate else None,
                     "valu_issue_frac_of_4_cycle_rate": round(rate / (VALU_ISSUE_PEAK / 2), 4) if rate else None,
                     "valu_lane_weighted_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK * lanes / 64.0, 4) if (rate and lanes) else None,
-                    # share of SIMD cycles a VALU instruction was executing, calibrated: the raw counter ratio over the ratio a pure
-                    # v_fma_f32 kernel at 8 waves per SIMD reads under the same pass (None without a calibration run)
-                    "valu_busy_frac": k.get("valu_busy_frac"), "valu_busy_raw_ratio": k.get("valu_busy_raw_ratio"),
-                    "valu_cycles_per_instruction": k.get("valu_cycles_per_instruction"),
+                    # share of SIMD cycles a VALU instruction occupied, by instruction class: (2 x (FMA + MUL + ADD_F32) + 16 x transcendentals
+                    # + 4 x the rest) / SIMD cycles (profiles/summarize.py; validated on a pure v_fma_f32 kernel: traffic_source.valu_busy_validation)
+                    "valu_busy_frac": k.get("valu_busy_frac"), "valu_2_cycle_share": k.get("valu_2_cycle_share"),
+                    "valu_transcendental_share": k.get("valu_transcendental_share"),
                 })
             else:
                 ent.update({"counter_hbm_bytes_per_sub_batch": None, "valu_wave_insts_per_sub_batch": None, "valu_lanes_active_of_64": None,

@@ -1,10 +1,11 @@
-// valu_calib.hip — calibration of the "share of SIMD cycles a VALU instruction was executing" figure (profiles/summarize.py:
-// valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE x CUs x SIMDs)).  Derived from two counters of different blocks
-// and clocks, the raw ratio came out above 1 for the traversal kernels (1.10 in round 3), which a fraction cannot be.  This
-// kernel IS a saturated VALU by construction — 8 waves per SIMD on every CU, each issuing nothing but independent v_fma_f32 —
-// so its raw ratio under the same rocprofv3 --pmc pass is what "1.0" reads as on this part; tools/evidence.sh divides every
-// kernel's raw ratio by it (stage_counters.json records the factor).  It also prints the wave-instruction rate it reached
-// against the clock, i.e. how many cycles a wave64 v_fma_f32 occupies a SIMD (the guide's 2 vs the counters' 4).
+// valu_calib.hip — validation of the VALU-time model of profiles/summarize.py (valu_busy_frac).  Round 3 had derived "the share
+// of SIMD cycles a VALU instruction was executing" as SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE x CUs x SIMDs) and read 1.10 for
+// a traversal kernel — which a fraction cannot be: SQ_ACTIVE_INST_VALU turned out to equal SQ_INSTS_VALU on this part (it counts
+// instructions, the "x 4 cycles" was an assumption), and v_fma / v_mul / v_add_f32 occupy a SIMD for 2 cycles, not 4.  The model
+// now weights the instruction classes the counters distinguish: 2 cycles for FMA / MUL / ADD_F32, 16 for transcendentals, 4 for
+// the rest.  This kernel IS a saturated VALU by construction — 8 waves per SIMD on every CU, each issuing nothing but independent
+// v_fma_f32 — so under the same rocprofv3 --pmc pass the model must read ~1.0 for it (tools/evidence.sh records what it reads in
+// stage_counters.json: valu_busy_validation).  It also prints the wave-instruction rate it reached against the nominal clock.
 // build: hipcc --offload-arch=gfx950 -O3 valu_calib.hip -o valu_calib ; run: ./valu_calib
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,9 +13,12 @@
 #include <stdlib.h>
 
 constexpr int ITER = 40000;
-#define FMA8                                                                                                         \
-	a0 = __builtin_fmaf(a0, m, c), a1 = __builtin_fmaf(a1, m, c), a2 = __builtin_fmaf(a2, m, c), a3 = __builtin_fmaf(a3, m, c), \
-	a4 = __builtin_fmaf(a4, m, c), a5 = __builtin_fmaf(a5, m, c), a6 = __builtin_fmaf(a6, m, c), a7 = __builtin_fmaf(a7, m, c);
+// (inline asm: written in C the compiler pairs independent fmas into v_pk_fma_f32 and the kernel measures something else)
+#define FMA8                                                                                                                                   \
+	asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"          \
+				 "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"               \
+				 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                                            \
+				 : "v"(m), "v"(c));
 
 __global__ __launch_bounds__(256, 8) void k_calib_fma(float *out, float seed)
 {

@@ -93,10 +93,20 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
             disp.setdefault(k, {})[counter] = n
             dur.setdefault(k, []).append(d / 1e3)
     out = {"workload": workload, "spp": int(spp), "streams": int(streams), "tag": tag, "csrc_hash": csrc_hash, "kernels": {}}
-    # calibration (profiles/micro/valu_calib.hip under the same counters): the raw busy ratio of a kernel that is nothing but
-    # independent v_fma_f32 at 8 waves per SIMD on every CU — what a saturated VALU reads as
-    calib = None
+    # VALU-time model: cycles a wave64 instruction occupies its SIMD by class — v_fma / v_mul / v_add_f32: 2 (what
+    # profiles/micro/valu_calib.hip and tools/dev/micro/sdwa_micro.hip measure: 2.3-2.6 nominal clocks per instruction), transcendentals
+    # 16 (quarter rate), everything else — compares, selects, conversions, min / max, integer — 4.  SIMD cycles = GRBM_GUI_ACTIVE
+    # (summed over the 8 XCDs) x 32 CUs x 4 SIMDs.  (Round 3's SQ_ACTIVE_INST_VALU x 4 exceeded 1: that counter equals SQ_INSTS_VALU here.)
+    def model(t):
+        if not (t.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_INSTS_VALU" in t and "SQ_INSTS_VALU_FMA_F32" in t):
+            return None
+        fast = t.get("SQ_INSTS_VALU_FMA_F32", 0.0) + t.get("SQ_INSTS_VALU_MUL_F32", 0.0) + t.get("SQ_INSTS_VALU_ADD_F32", 0.0)
+        trans = t.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        slow = max(0.0, t["SQ_INSTS_VALU"] - fast - trans)
+        return (2.0 * fast + 16.0 * trans + 4.0 * slow) / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), fast / t["SQ_INSTS_VALU"], trans / t["SQ_INSTS_VALU"]
+    # validation: the model on a kernel that is nothing but independent v_fma_f32 at 8 waves per SIMD (must read ~1)
     import os
+    calib = None
     cal_db = os.environ.get("VALU_CALIB_DB")
     if cal_db and os.path.exists(cal_db):
         ct = {}
@@ -104,12 +114,13 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
                 "select kernel_name, counter_name, sum(value) from counters_collection group by kernel_name, counter_name"):
             if "k_calib_fma" in name:
                 ct[counter] = total
-        if ct.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_ACTIVE_INST_VALU" in ct:
-            calib = {"kernel": "k_calib_fma (profiles/micro/valu_calib.hip)",
-                     "raw_busy_ratio": round(ct["SQ_ACTIVE_INST_VALU"] * 4.0 / (ct["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), 4),
-                     "cycles_per_instruction": round(4.0 * ct["SQ_ACTIVE_INST_VALU"] / ct["SQ_INSTS_VALU"], 3) if ct.get("SQ_INSTS_VALU") else None,
-                     "lanes_per_instruction": round(ct["SQ_THREAD_CYCLES_VALU"] / ct["SQ_ACTIVE_INST_VALU"], 2) if ct.get("SQ_THREAD_CYCLES_VALU") else None}
-    out["valu_busy_calibration"] = calib
+        ct.setdefault("SQ_INSTS_VALU_MUL_F32", 0.0), ct.setdefault("SQ_INSTS_VALU_ADD_F32", 0.0), ct.setdefault("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        mv = model(ct)
+        if mv:
+            calib = {"kernel": "k_calib_fma (profiles/micro/valu_calib.hip): independent v_fma_f32 only, 8 waves per SIMD, every CU",
+                     "valu_busy_frac_by_the_model": round(mv[0], 4), "fma_share_of_valu_instructions": round(mv[1], 4),
+                     "lanes_per_instruction": round(ct["SQ_THREAD_CYCLES_VALU"] / ct["SQ_ACTIVE_INST_VALU"], 2) if ct.get("SQ_ACTIVE_INST_VALU") else None}
+    out["valu_busy_validation"] = calib
     for k, t in tot.items():
         if not k.startswith("k_"):
             continue
@@ -126,20 +137,19 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
             e["valu_lanes_per_instruction"] = round(t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"], 2)
         # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs of 32 CUs x 4 SIMDs
         if "SQ_ACTIVE_INST_VALU" in t and t.get("GRBM_GUI_ACTIVE", 0) > 0:
-            raw = t["SQ_ACTIVE_INST_VALU"] * 4.0 / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0)
-            e["valu_busy_raw_ratio"] = round(raw, 4)
-            # (None without a calibration run: the raw ratio alone exceeded 1 in round 3 and is not reported as a fraction)
-            e["valu_busy_frac"] = round(raw / calib["raw_busy_ratio"], 4) if calib and calib["raw_busy_ratio"] > 0 else None
-            if t.get("SQ_INSTS_VALU", 0) > 0 and disp[k].get("SQ_INSTS_VALU") == disp[k].get("SQ_ACTIVE_INST_VALU"):
-                e["valu_cycles_per_instruction"] = round(4.0 * t["SQ_ACTIVE_INST_VALU"] / t["SQ_INSTS_VALU"], 2)
+            mv = model(t)  # (needs the instruction-class pass and GRBM_GUI_ACTIVE of the same kernel)
+            e["valu_busy_frac"] = round(mv[0], 4) if mv else None
+            if mv:
+                e["valu_2_cycle_share"] = round(mv[1], 4)
+                e["valu_transcendental_share"] = round(mv[2], 4)
         if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t and t["SQ_WAVE_CYCLES"] > 0:
             e["wave_cycles_waiting_frac"] = round(t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"], 4)
         out["kernels"][k] = e
     out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                          "--no-roofline` (tools/evidence.sh); per dispatch averages; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
-                         "l2 bytes = TCC_REQ_sum x 128; valu_busy_raw_ratio = SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs); "
-                         "valu_busy_frac = that ratio over the ratio a pure v_fma_f32 kernel at 8 waves per SIMD reads under the same pass "
-                         "(valu_busy_calibration): the share of SIMD cycles a VALU instruction was executing; csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
+                         "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = (2 x (FMA + MUL + ADD_F32) + 16 x TRANS_F32 + 4 x the other VALU instructions) / "
+                         "(GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs): the share of SIMD cycles a VALU instruction occupied, by instruction class "
+                         "(valu_busy_validation: the same model on a pure v_fma_f32 kernel); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
     print(json.dumps(out, indent=1))
 
 
