@@ -284,7 +284,16 @@ def main():
 
     # ---- N > 1, --gather comm: the library's own RCCL gather (rfwhip_comm_*); torch only ships the communicator id -------
     comm = None
+    rccl_library = None
     if world > 1 and args.gather == "comm":
+        # ONE RCCL in the process: torch.distributed has loaded the librccl.so its wheel bundles; the library's gather opens the
+        # same file (RFWHIP_RCCL_LIBRARY) instead of the system's librccl.so.1 — two RCCL builds side by side in one process, one
+        # of them with its symbols in the global scope, is a combination nobody tests.  (A host without torch — the plugin — uses
+        # the system's.)  An explicit RFWHIP_RCCL_LIBRARY in the environment wins.
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if "RFWHIP_RCCL_LIBRARY" not in os.environ and os.path.exists(bundled) and not one_device:
+            os.environ["RFWHIP_RCCL_LIBRARY"] = bundled
+        rccl_library = os.environ.get("RFWHIP_RCCL_LIBRARY", "librccl.so.1 (system)")
         try:
             idbuf = torch.zeros(128, dtype=torch.uint8, device="cpu" if one_device else dev)
             if rank == 0:
@@ -691,7 +700,7 @@ def main():
                                       len(scene.area_lights), len(scene.point_lights)),
                        "parallelism": ("single GPU, no collective" if world == 1 else
                                        "image strips of 8 rows interleaved over %d ranks, one gather per step into rank 0's HBM" % world),
-                       "gather": gather_mode if world > 1 else None,
+                       "gather": gather_mode if world > 1 else None, "rccl_library": rccl_library,
                        "gather_note": (None if world == 1 else
                                        "comm = rfwhip_comm_gather: ncclSend on every rank / ncclRecv x (world - 1) on the root issued by "
                                        "librfwhip.so, stream-ordered, overlapping the next step; torch = torch.distributed.gather"),
