@@ -79,6 +79,10 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_PACKET_FULL_SORT
 #define RT_PACKET_FULL_SORT 0
 #endif
+// the shade kernel's waves queue their misses as well as their hits (1), or shade every chunk's misses in place (0)
+#ifndef RT_MISS_QUEUE
+#define RT_MISS_QUEUE 1
+#endif
 #ifndef RT_SHADE_WAVES_PLAIN
 #define RT_SHADE_WAVES_PLAIN 5 // the shade kernel of scenes without textures: 111 registers unbounded; 4 / 5 / 6 waves ->
 								// 2492 / 2589 / 2584 Msamples/s (96 registers + a few spilled dwords at 5)
@@ -832,7 +836,7 @@ RT_FN void skin_shade_item(TriShade *shade, const f4 *verts, const f4 *vnormals,
 	else
 		a = 3u * i, b = a + 1u, c = a + 2u;
 	const f3 v0 = xyz(verts[a]), v1 = xyz(verts[b]), v2 = xyz(verts[c]);
-	const f3 N = normalize(cross(v1 - v0, v2 - v0));
+	const f3 N = normalize_ieee(cross(v1 - v0, v2 - v0));
 	const f4 n0 = vnormals[a], n1 = vnormals[b], n2 = vnormals[c];
 	TriShade &t = shade[i];
 	t.n0 = mk4(n0.x, n0.y, n0.z, N.x);
@@ -1837,7 +1841,7 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	// No workgroup barrier anywhere (round 1's per-256 compaction parked the waves without hits at a barrier, holding
 	// their SIMD slots, while the others shaded), and the expensive path always runs with all lanes.  Which lane shades a
 	// path does not affect its result.
-	__shared__ uint32_t s_hits[BLOCK / 64][128];
+	__shared__ uint32_t s_hits[BLOCK / 64][RT_MISS_QUEUE ? 256 : 128];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *const q = s_hits[wave];
 	const f4 *const hits = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
@@ -1851,25 +1855,33 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	}
 	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
 	uint32_t nq = 0;								// queued hits (wave-uniform)
+	uint32_t nm = 0;								// queued misses (RT_MISS_QUEUE)
 	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
 #pragma nounroll
 	for (;;)
 	{
 		uint32_t idx = 0;
 		bool act = false;
-		if (nq >= 64u || (c >= nchunks && nq > 0u))
+		const bool drain = c >= nchunks;
+		const bool take_hits = nq >= 64u || (drain && nq > 0u);
+		if (take_hits || (RT_MISS_QUEUE && (nm >= 64u || (drain && nm > 0u))))
 		{
-			// one wave of queued hits; the rest of the queue moves down
-			const uint32_t n = nq < 64u ? nq : 64u, rest = nq - n;
-			nshaded += n;
+			// one wave of queued paths (hits before misses); the rest of that queue moves down
+			uint32_t *const qq = (RT_MISS_QUEUE && !take_hits) ? q + 128 : q;
+			const uint32_t have = take_hits ? nq : nm;
+			const uint32_t n = have < 64u ? have : 64u, rest = have - n;
+			nshaded += take_hits ? n : 0u;
 			act = lane < n;
-			idx = act ? q[lane] : 0u;
-			const uint32_t moved = lane < rest ? q[64u + lane] : 0u;
+			idx = act ? qq[lane] : 0u;
+			const uint32_t moved = lane < rest ? qq[64u + lane] : 0u;
 			if (lane < rest)
-				q[lane] = moved;
-			nq = rest;
+				qq[lane] = moved;
+			if (take_hits)
+				nq = rest;
+			else
+				nm = rest;
 		}
-		else if (c < nchunks)
+		else if (!drain)
 		{
 			idx = c * 64u + lane;
 			c += nwaves;
@@ -1883,7 +1895,16 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 				q[nq + wave_prefix(m)] = idx;
 			nq += (uint32_t)__popcll(m);
 			act = prim == -1; // a miss; HIT_VOID entries (unfilled queue slots) are nobody's path
-			if (__ballot(act) == 0ull)
+			const unsigned long long mm = __ballot(act);
+			if (RT_MISS_QUEUE)
+			{
+				// the misses of a bounce wave are mixed lane by lane with its hits as well: they wait for a full wave too
+				if (act)
+					q[128u + nm + wave_prefix(mm)] = idx;
+				nm += (uint32_t)__popcll(mm);
+				continue;
+			}
+			if (mm == 0ull)
 				continue;
 		}
 		else

@@ -21,6 +21,26 @@ namespace rt
 {
 
 // ---------------------------------------------------------------------------------------------------------------
+// division and square root of the SHADING arithmetic (BSDF, light sampling, normals: everything behind the hit record)
+// ---------------------------------------------------------------------------------------------------------------
+// The shipped device build takes the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 there: a correctly rounded fp32
+// division is 10 instructions around the same v_rcp_f32 (two v_div_scale, four fmas, v_div_fmas, v_div_fixup — ~46 issue
+// cycles against 18), a correctly rounded square root a dozen around v_sqrt_f32, and the plain shade kernel held 106 + 50 of
+// them.  The host build and the validation build (RT_STRICT_MATH) keep IEEE division and square root, like the oracle; ray
+// generation, traversal and the triangle test are not written with these (rounded(), safe_rcp).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_STRICT_MATH)
+RT_FN float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_FN float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+RT_FN float m_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+RT_FN float m_rsqrtf(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+RT_FN float m_rcp(float x) { return 1.0f / x; }
+RT_FN float m_div(float a, float b) { return a / b; }
+RT_FN float m_sqrtf(float x) { return sqrtf(x); }
+RT_FN float m_rsqrtf(float x) { return 1.0f / sqrtf(x); }
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
 // small vector algebra
 // ---------------------------------------------------------------------------------------------------------------
 RT_FN f3 mk3(float x, float y, float z)
@@ -43,8 +63,18 @@ RT_FN f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_FN f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 RT_FN float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_FN f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-RT_FN float length(f3 a) { return sqrtf(dot(a, a)); }
-RT_FN f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+RT_FN float length(f3 a) { return m_sqrtf(dot(a, a)); }
+RT_FN f3 normalize(f3 a) { return a * m_rsqrtf(dot(a, a)); }
+// a / s per component: one reciprocal in the shipped device build, three divisions where the arithmetic is IEEE
+RT_FN f3 m_div3(f3 a, float s)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_STRICT_MATH)
+	return a * m_rcp(s);
+#else
+	return mk3(a.x / s, a.y / s, a.z / s);
+#endif
+}
+RT_FN f3 normalize_ieee(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); } // (the parity integrator, geometry updates)
 RT_FN f3 lerp3(f3 a, f3 b, float t) { return a + (b - a) * t; }
 RT_FN float lerp1(float a, float b, float t) { return a + t * (b - a); }
 RT_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -958,7 +988,7 @@ RT_FN f4 parity_shade(const SceneView &sc, f3 O, f3 D, const Hit &h, TravStack &
 	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, tv4 = ts.tv;
 	const MaterialRec &mat = sc.materials[fbits(tv4.w)];
 	const f3 iNl = (xyz(n0) * bary.x + xyz(n1) * bary.y) + xyz(n2) * bary.z;
-	const f3 iN = normalize(mul_normal(in, iNl));
+	const f3 iN = normalize_ieee(mul_normal(in, iNl));
 	f3 color = material_color(mat);
 	const uint32_t mflags = mat.flags;
 	if (mat_flag(mflags, MF_DIFFUSE_MAP))
@@ -1071,36 +1101,36 @@ RT_FN float gtr1(float NDotH, float a)
 		return RT_INVPI;
 	const float a2 = a * a;
 	const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-	return (a2 - 1.0f) / (RT_PI * m_logf(a2) * t);
+	return m_div(a2 - 1.0f, RT_PI * m_logf(a2) * t);
 }
 RT_FN float gtr2(float NDotH, float a)
 {
 	const float a2 = a * a;
 	const float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-	return a2 / (RT_PI * t * t);
+	return m_div(a2, RT_PI * t * t);
 }
 RT_FN float smith_ggx(float NDotv, float alphaG)
 {
 	const float a = alphaG * alphaG;
 	const float b = NDotv * NDotv;
-	return 1.0f / (NDotv + sqrtf(a + b - a * b));
+	return m_rcp(NDotv + m_sqrtf(a + b - a * b));
 }
 RT_FN float fresnel_fr(float VDotN, float eio)
 {
 	const float SinThetaT2 = sqr(eio) * (1.0f - VDotN * VDotN);
 	if (SinThetaT2 > 1.0f)
 		return 1.0f;
-	const float LDotN = sqrtf(1.0f - SinThetaT2);
-	const float eta = 1.0f / eio;
-	const float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
-	const float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+	const float LDotN = m_sqrtf(1.0f - SinThetaT2);
+	const float eta = m_rcp(eio);
+	const float r1 = m_div(VDotN - eta * LDotN, VDotN + eta * LDotN);
+	const float r2 = m_div(LDotN - eta * VDotN, LDotN + eta * VDotN);
 	return 0.5f * (sqr(r1) + sqr(r2));
 }
 RT_FN f3 safe_normalize(f3 a)
 {
 	const float ls = dot(a, a);
 	if (ls > 0.0f)
-		return a * (1.0f / sqrtf(ls));
+		return a * m_rsqrtf(ls);
 	return mk3(0, 0, 0);
 }
 RT_FN bool refract_dir(f3 wi, f3 n, float eta, f3 &wt)
@@ -1110,7 +1140,7 @@ RT_FN bool refract_dir(f3 wi, f3 n, float eta, f3 &wt)
 	const float sin2ThetaT = eta * eta * sin2ThetaI;
 	if (sin2ThetaT >= 1.0f)
 		return false;
-	const float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+	const float cosThetaT = m_sqrtf(1.0f - sin2ThetaT);
 	wt = (wi * -1.0f) * eta + n * (eta * cosThetaI - cosThetaT);
 	return true;
 }
@@ -1126,7 +1156,7 @@ RT_FN float bsdf_pdf(const Shading &sd, f3 N, f3 wo, f3 wi)
 		const f3 halfway = safe_normalize(wi + wo);
 		const float cosThetaHalf = fabsf(dot(halfway, N));
 		const float pdfHalf = gtr2(cosThetaHalf, sd_roughness(sd)) * cosThetaHalf;
-		const float pdfSpec = 0.25f * pdfHalf / fmaxf(1.e-6f, dot(wi, halfway));
+		const float pdfSpec = m_div(0.25f * pdfHalf, fmaxf(1.e-6f, dot(wi, halfway)));
 		const float pdfDiff = fabsf(dot(wi, N)) * RT_INVPI * (1.0f - sd_subsurface(sd));
 		bsdfPdf = pdfSpec * F;
 		brdfPdf = lerp1(pdfDiff, pdfSpec, 0.5f);
@@ -1143,7 +1173,7 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 	const float LDotH = dot(wi, H);
 	const f3 Cdlin = sd.color;
 	const float Cdlum = .3f * Cdlin.x + .6f * Cdlin.y + .1f * Cdlin.z;
-	const f3 Ctint = Cdlum > 0.0f ? Cdlin * (1.0f / Cdlum) : mk3(1, 1, 1);
+	const f3 Ctint = Cdlum > 0.0f ? Cdlin * m_rcp(Cdlum) : mk3(1, 1, 1);
 	const float METALLIC = sd_metallic(sd), TRANSMISSION = sd_transmission(sd), SUBSURFACE = sd_subsurface(sd);
 	const float ROUGHNESS = sd_roughness(sd), ETA = sd_eta(sd);
 	const f3 Cspec0 = lerp3(lerp3(mk3(1, 1, 1), Ctint, sd_spectint(sd)) * (sd_specular(sd) * .08f), Cdlin, METALLIC);
@@ -1153,7 +1183,7 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 		if (NDotL <= 0)
 		{
 			const float F = fresnel_fr(NDotV, ETA);
-			const float s = (1.0f - F) / fabsf(NDotL) * (1.0f - METALLIC) * TRANSMISSION;
+			const float s = m_div(1.0f - F, fabsf(NDotL)) * (1.0f - METALLIC) * TRANSMISSION;
 			bsdf = mk3(s, s, s);
 		}
 		else
@@ -1172,7 +1202,7 @@ RT_FN f3 bsdf_eval(const Shading &sd, f3 N, f3 wo, f3 wi, float t, bool backfaci
 		{
 			if (SUBSURFACE > 0.0f)
 			{
-				const f3 s = mk3(sqrtf(sd.color.x), sqrtf(sd.color.y), sqrtf(sd.color.z));
+				const f3 s = mk3(m_sqrtf(sd.color.x), m_sqrtf(sd.color.y), m_sqrtf(sd.color.z));
 				const float FL = schlick_fresnel(fabsf(NDotL)), FV = schlick_fresnel(NDotV);
 				const float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
 				brdf = (((s * RT_INVPI) * SUBSURFACE) * Fd) * (1.0f - METALLIC);
@@ -1221,22 +1251,26 @@ RT_FN void sincos_turns(float frac, float &s, float &c)
 RT_FN f3 reflect_dir(f3 I, f3 N) { return I - N * (dot(N, I) * 2.0f); }
 RT_FN f3 diffuse_reflection_uniform(float r0, float r1)
 {
-	const float term2 = sqrtf(1.0f - r1 * r1);
+	const float term2 = m_sqrtf(1.0f - r1 * r1);
 	float sn, cs;
 	sincos_turns(r0, sn, cs);
 	return mk3(cs * term2, sn * term2, r1);
 }
 RT_FN f3 diffuse_reflection_cos_weighted(float r0, float r1)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_STRICT_MATH)
+	const float term2 = m_sqrtf(1.0f - r1); // (1 - r1 is exact above one half; below it the float and the double form differ in the last place)
+#else
 	const float term2 = (float)sqrt(1.0 - (double)r1); // tools.h:113 computes this term in double
+#endif
 	float sn, cs;
 	sincos_turns(r0, sn, cs);
-	return normalize(mk3(cs * term2, sn * term2, sqrtf(r1)));
+	return normalize(mk3(cs * term2, sn * term2, m_sqrtf(r1)));
 }
 RT_FN f3 ggx_halfway(f3 T, f3 B, f3 N, f3 wo, float rough, float r1, float r2)
 {
-	const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(rough) - 1.0f) * r2));
-	const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
+	const float cosThetaHalf = m_sqrtf(m_div(1.0f - r2, 1.0f + (sqr(rough) - 1.0f) * r2));
+	const float sinThetaHalf = m_sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
 	float sinPhiHalf, cosPhiHalf;
 	sincos_turns(r1, sinPhiHalf, cosPhiHalf);
 	f3 halfway = (T * (sinThetaHalf * cosPhiHalf) + B * (sinThetaHalf * sinPhiHalf)) + N * cosThetaHalf;
@@ -1254,8 +1288,8 @@ RT_FN void bsdf_sample(const Shading &sd, f3 T, f3 B, f3 N, f3 wo, f3 &wi, float
 		const float F = fresnel_fr(dot(N, wo), sd_eta(sd));
 		if (r4 < F)
 		{
-			const float r1 = r3 / transmission;
-			const float r2 = r4 / F;
+			const float r1 = m_div(r3, transmission);
+			const float r2 = m_div(r4, F);
 			wi = reflect_dir(wo * -1.0f, ggx_halfway(T, B, N, wo, ROUGHNESS, r1, r2));
 		}
 		else
@@ -1266,7 +1300,7 @@ RT_FN void bsdf_sample(const Shading &sd, f3 T, f3 B, f3 N, f3 wo, f3 &wi, float
 		}
 		return;
 	}
-	const float r1 = (r3 - transmission) / (1 - transmission);
+	const float r1 = m_div(r3 - transmission, 1 - transmission);
 	if (r4 < 0.5f)
 	{
 		const float r2 = r4 * 2;
@@ -1274,13 +1308,13 @@ RT_FN void bsdf_sample(const Shading &sd, f3 T, f3 B, f3 N, f3 wo, f3 &wi, float
 		f3 d;
 		if (r2 < subsurface)
 		{
-			const float r5 = r2 / subsurface;
+			const float r5 = m_div(r2, subsurface);
 			d = diffuse_reflection_uniform(r1, r5);
 			d.z *= -1.0f;
 		}
 		else
 		{
-			const float r5 = (r2 - subsurface) / (1.0f - subsurface);
+			const float r5 = m_div(r2 - subsurface, 1.0f - subsurface);
 			d = diffuse_reflection_cos_weighted(r1, r5);
 		}
 		wi = (T * d.x + B * d.y) + N * d.z;
@@ -1296,7 +1330,7 @@ RT_FN void bsdf_sample(const Shading &sd, f3 T, f3 B, f3 N, f3 wo, f3 &wi, float
 // bsdf/tools.h
 RT_FN uint32_t pack_normal(f3 N)
 {
-	const float f = 65535.0f / fmaxf(sqrtf(8.0f * N.z + 8.0f), 0.0001f);
+	const float f = m_div(65535.0f, fmaxf(m_sqrtf(8.0f * N.z + 8.0f), 0.0001f));
 	return f2u_sat(N.x * f + 32767.0f) + (f2u_sat(N.y * f + 32767.0f) << 16);
 }
 RT_FN f3 unpack_normal(uint32_t p)
@@ -1306,7 +1340,7 @@ RT_FN f3 unpack_normal(uint32_t p)
 	const float nz0 = 1.0f, nw = -1.0f;
 	float l = nx * -nx + ny * -ny + nz0 * -nw;
 	const float nz = l;
-	l = sqrtf(l);
+	l = m_sqrtf(l);
 	nx *= l, ny *= l;
 	return mk3(nx * 2.0f, ny * 2.0f, nz * 2.0f - 1.0f);
 }
@@ -1315,13 +1349,13 @@ RT_FN f3 clamp_intensity(f3 v, float clampValue)
 {
 	const float m = fmaxf(v.x, fmaxf(v.y, v.z));
 	if (m > clampValue)
-		return v * (clampValue / m);
+		return v * m_div(clampValue, m);
 	return v;
 }
 RT_FN void create_tangent_space(f3 N, f3 &T, f3 &B)
 {
 	const float s = signf(N.z);
-	const float a = -1.0f / (s + N.z);
+	const float a = -m_rcp(s + N.z);
 	const float b = N.x * N.y * a;
 	T = mk3(1.0f + s * N.x * N.x * a, s * b, -s * N.x);
 	B = mk3(b, s + N.y * N.y * a, -N.y);
@@ -1337,7 +1371,7 @@ RT_FN float pot_area(const SceneView &sc, uint32_t idx, f3 O, f3 N, f3 I, f3 bar
 	if (bary.x >= 0)
 		L = (ld3(l.vertex0) * bary.x + ld3(l.vertex1) * bary.y) + ld3(l.vertex2) * bary.z;
 	L = L - O;
-	const float att = 1.0f / dot(L, L);
+	const float att = m_rcp(dot(L, L));
 	L = normalize(L);
 	const float LNdotL = fmaxf(0.0f, -dot(ld3(l.normal), L));
 	const float NdotL = fmaxf(0.0f, dot(N, L));
@@ -1348,16 +1382,16 @@ RT_FN float pot_point(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 	const PointLight &l = sc.point[idx];
 	const f3 L = ld3(l.position) - I;
 	const float NdotL = fmaxf(0.0f, dot(N, L));
-	const float att = 1.0f / dot(L, L);
+	const float att = m_rcp(dot(L, L));
 	return l.energy * NdotL * att;
 }
 RT_FN float pot_spot(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 {
 	const SpotLight &l = sc.spot[idx];
 	f3 L = ld3(l.position) - I;
-	const float att = 1.0f / dot(L, L);
+	const float att = m_rcp(dot(L, L));
 	L = normalize(L);
-	const float d = (fmaxf(0.0f, -dot(L, ld3(l.direction))) - l.cosOuter) / (l.cosInner - l.cosOuter);
+	const float d = m_div(fmaxf(0.0f, -dot(L, ld3(l.direction))) - l.cosOuter, l.cosInner - l.cosOuter);
 	const float NdotL = fmaxf(0.0f, dot(N, L));
 	const float LNdotL = fmaxf(0.0f, fminf(1.0f, d));
 	return l.energy * LNdotL * NdotL * att;
@@ -1400,7 +1434,7 @@ RT_FN float light_pick_prob(const SceneView &sc, int idx, f3 O, f3 N, f3 I)
 		sum += pot_dir(sc, i, N);
 	if (sum <= 0)
 		return 0;
-	return mine / sum;
+	return m_div(mine, sum);
 }
 // lights.h:119-157: sixteen rounds of "pick one of the four sub-triangles" (two bits of r0 each, most significant first),
 // then the centroid.  The reference walks the three corners through a 16-iteration loop of four-way branches — ~600
@@ -1491,7 +1525,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 		if (k == lights - 1)
 			li = 0, chosen = first;
 	}
-	pickProb = chosen / sum;
+	pickProb = m_div(chosen, sum);
 	if (li < sc.n_area)
 	{
 		const AreaLight &l = sc.area[li];
@@ -1502,9 +1536,9 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 		const float sqDist = dot(L, L);
 		L = normalize(L);
 		const float LNdotL = dot(L, LN);
-		const float reciSolidAngle = sqDist / (l.area * LNdotL);
+		const float reciSolidAngle = m_div(sqDist, l.area * LNdotL);
 		const float energy = length(ld3(l.radiance)); // DeviceAreaLight::getEnergy, device_structs.h:115
-		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? (reciSolidAngle * (1.0f / energy)) : 0;
+		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? (reciSolidAngle * m_rcp(energy)) : 0;
 		return P;
 	}
 	li -= sc.n_area;
@@ -1515,7 +1549,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 		lightColor = ld3(l.radiance);
 		const f3 L = I - pos;
 		const float sqDist = dot(L, L);
-		lightPdf = dot(L, N) < 0 ? (sqDist / l.energy) : 0;
+		lightPdf = dot(L, N) < 0 ? m_div(sqDist, l.energy) : 0;
 		return pos;
 	}
 	li -= sc.n_point;
@@ -1526,9 +1560,9 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 		f3 L = I - P;
 		const float sqDist = dot(L, L);
 		L = normalize(L);
-		const float d = fmaxf(0.0f, dot(L, ld3(l.direction)) - l.cosOuter) / (l.cosInner - l.cosOuter);
+		const float d = m_div(fmaxf(0.0f, dot(L, ld3(l.direction)) - l.cosOuter), l.cosInner - l.cosOuter);
 		const float LNdotL = fminf(1.0f, d);
-		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? (sqDist / (LNdotL * l.energy)) : 0;
+		lightPdf = (LNdotL > 0 && dot(L, N) < 0) ? m_div(sqDist, LNdotL * l.energy) : 0;
 		lightColor = ld3(l.radiance);
 		return P;
 	}
@@ -1537,7 +1571,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 	const f3 L = ld3(l.direction);
 	lightColor = ld3(l.radiance);
 	const float NdotL = dot(L, N);
-	lightPdf = NdotL < 0 ? (1.0f / l.energy) : 0;
+	lightPdf = NdotL < 0 ? m_rcp(l.energy) : 0;
 	return I - L * 1000.0f;
 }
 
@@ -1614,7 +1648,7 @@ RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, c
 	const float tu = sf.bw0 * sf.tu4.x + sf.bw1 * sf.tu4.y + sf.bw2 * sf.tu4.z;
 	const float tv = sf.bw0 * sf.tv4.x + sf.bw1 * sf.tv4.y + sf.bw2 * sf.tv4.z;
 	const float coneWidth = cam.spread_angle * t;
-	const float lambda = sf.ex.y + m_log2f(coneWidth * (1.0f / fabsf(dot(D * -1.0f, sf.N))));
+	const float lambda = sf.ex.y + m_log2f(coneWidth * m_rcp(fabsf(dot(D * -1.0f, sf.N))));
 	// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
 #define RT_LAYER(K) \
 	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \
@@ -1686,7 +1720,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	f3 T = in.T;
 	if (h.prim < 0)
 	{
-		f3 contribution = (T * (1.0f / in.bsdfPdf)) * pt_sky(sc, D);
+		f3 contribution = (T * m_rcp(in.bsdfPdf)) * pt_sky(sc, D);
 		if (any_nan(contribution))
 			return;
 		out.radiance = clamp_intensity(contribution, cam.clamp_value);
@@ -1735,18 +1769,18 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 			if (in.depth == 0)
 				contribution = sd.color;
 			else if (in.flags & 1u)
-				contribution = (T * sd.color) * (1.0f / in.bsdfPdf);
+				contribution = (T * sd.color) * m_rcp(in.bsdfPdf);
 			else
 			{
 				const f3 lastN = unpack_normal(in.packedN);
-				const float lightPdf = (h.t * h.t) / (-dot(D, N) * ex.x); // lights.h:78-81
+				const float lightPdf = m_div(h.t * h.t, -dot(D, N) * ex.x); // lights.h:78-81
 				const int ltri = (int)fbits(tu4.w);
 				// the reference reads the material id as light index (device_structs.h:37,40); lightTriIdx is meant
 				const float pickProb =
 					(ltri >= 0 && (uint32_t)ltri < sc.n_area) ? light_pick_prob(sc, ltri, O, lastN, I) : 0.0f;
 				if ((in.bsdfPdf + lightPdf * pickProb) <= 0)
 					return;
-				contribution = (T * sd.color) * (1.0f / (in.bsdfPdf + lightPdf * pickProb));
+				contribution = (T * sd.color) * m_rcp(in.bsdfPdf + lightPdf * pickProb);
 			}
 		}
 		if (any_nan(contribution))
@@ -1763,7 +1797,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	const float flip = (dot(D, N) > 0) ? -1.0f : 1.0f;
 	N = N * flip;
 	iN = iN * flip;
-	T = T * (1.0f / in.bsdfPdf);
+	T = T * m_rcp(in.bsdfPdf);
 	const f3 wo = D * -1.0f;
 	// next-event estimation: Kernels.cu:702-755.  The connections of a shade call are traced by the NEXT iteration of the
 	// reference's host loop (CUDART/src/Context.cpp:109-120), so those of the last call (depth == max_depth) never are:
@@ -1782,7 +1816,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 			q0 = random_float(seed), q1 = random_float(seed);
 		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache) - I;
 		const float dist = length(L);
-		L = L * (1.0f / dist);
+		L = L * m_rcp(dist);
 		const float NdotL = dot(L, iN);
 		if (NdotL > 0 && lightPdf > 0)
 		{
@@ -1790,7 +1824,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 			const float shadowPdf = bsdf_pdf(sd, iN, wo, L);
 			if (shadowPdf > 0)
 			{
-				f3 contribution = ((T * bs) * lightColor) * (NdotL / (shadowPdf + lightPdf * pickProb));
+				f3 contribution = ((T * bs) * lightColor) * m_div(NdotL, shadowPdf + lightPdf * pickProb);
 				contribution = clamp_intensity(contribution, cam.clamp_value);
 				if (!any_nan(contribution))
 				{
@@ -1813,7 +1847,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	{
 		// throughput * 1.0f / SurvivalProbability(throughput) * bsdf * abs(dot(iN, R))   (Kernels.cu:783)
 		const float surv = survival_probability(T);
-		T = ((mk3(T.x / surv, T.y / surv, T.z / surv)) * bs) * fabsf(dot(iN, R));
+		T = (m_div3(T, surv) * bs) * fabsf(dot(iN, R));
 	}
 	if (newPdf < 1e-6f || (newPdf != newPdf) || T.x < 0.0f || T.y < 0.0f || T.z < 0.0f)
 		return;

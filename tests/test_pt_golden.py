@@ -154,7 +154,10 @@ def check_image(g, first, img, counts, exact_first, textured=False):
     assert (d0 > 1e-3).mean() <= (5e-4 if exact_first else 2e-3), "sample 0: %g of the pixels differ, worst %g" % ((d0 > 1e-3).mean(), d0.max())
     d = (np.abs(img - g["image"]) - rel * np.abs(g["image"])).max(-1)
     frac, rmse = float((d > 1e-3).mean()), float(np.sqrt(np.mean((img - g["image"]) ** 2)))
-    assert frac <= 2e-3, "4 spp: %g of the pixels differ (rmse %g)" % (frac, rmse)
+    # GPU: v_sin_f32 / v_cos_f32 put ~1e-6 of absolute error into every sampled direction, which moves a sky lookup across a texel
+    # border (or an occlusion test across an edge) about once in two thousand samples: 12 +- 4 pixels of the 4-spp terrain image
+    # (12 with IEEE division in the shade arithmetic, 14 with v_rcp_f32 / v_rsq_f32 — tools/dev/golden_frac.py), 0-2 elsewhere
+    assert frac <= (2e-3 if exact_first else 3.5e-3), "4 spp: %g of the pixels differ (rmse %g)" % (frac, rmse)
     # wave sizes per sample: extension rays of depth 1 and 2, connections actually traced (depths 0 and 1)
     for s, (pc, sc, dc, sh) in enumerate(counts):
         want = (int(g["ext"][s][0]), int(g["ext"][s][1]), int(g["ext"][s][2]), int(g["shadow_traced"][s].sum()))
