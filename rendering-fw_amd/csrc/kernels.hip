@@ -2105,8 +2105,12 @@ void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t
 #ifndef RT_GRID_BLOCKS_PER_CU
 #define RT_GRID_BLOCKS_PER_CU 8u
 #endif
+// Round 4: the shade kernel's grid is what a CU HOLDS of it (5 workgroups of the plain variant at 96 registers, 4 of the textured
+// one at 128).  Its waves walk their chunks with a static stride, so the 3 workgroups per CU that a grid of 8 left waiting ran as
+// a second round on a chip 60 % full: shade alone on the chip 10.4 -> 9.5 ms per 64-spp sub-batch (8 / 5 / 4 / 10 per CU ->
+// 10.37 / 9.51 / 9.87 / 9.60; the pipelined step does not notice: 4428-4442 / 4432 / 4400 / 4443 Msamples/s).
 #ifndef RT_SHADE_BLOCKS_PER_CU
-#define RT_SHADE_BLOCKS_PER_CU 8u
+#define RT_SHADE_BLOCKS_PER_CU(TEX) ((TEX) ? (uint32_t)RT_SHADE_WAVES : (uint32_t)RT_SHADE_WAVES_PLAIN)
 #endif
 #ifndef RT_GRID_CHUNKS_PER_BLOCK
 #define RT_GRID_CHUNKS_PER_BLOCK 32u // a workgroup should find about this many 256-item chunks to be worth launching
@@ -2114,7 +2118,7 @@ void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t
 static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID_BLOCKS_PER_CU)
 {
 	const uint32_t chunks = (items + BLOCK - 1) / BLOCK;
-	const uint32_t lo = (uint32_t)g_cus * 8u, hi = (uint32_t)g_cus * per_cu;
+	const uint32_t lo = (uint32_t)g_cus * (per_cu < 8u ? per_cu : 8u), hi = (uint32_t)g_cus * per_cu;
 	uint32_t blocks = chunks / RT_GRID_CHUNKS_PER_BLOCK;
 	blocks = blocks < lo ? lo : (blocks > hi ? hi : blocks);
 	if (blocks > chunks)
@@ -2219,14 +2223,17 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 }
 
 // slots the void entries of one shade launch over max_items paths can take beyond the rays themselves (per queue)
-uint32_t queue_pad(uint32_t max_items) { return persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU) * (BLOCK / 64u) * QUEUE_BLOCK; }
+uint32_t queue_pad(uint32_t max_items)
+{
+	return std::max(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(false)), persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(true))) * (BLOCK / 64u) * QUEUE_BLOCK;
+}
 
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 {
 	if (p.textured)
-		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
+		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(true))), dim3(BLOCK), 0, (hipStream_t)s, p);
 	else
-		hipLaunchKernelGGL(k_shade_pt<false>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU)), dim3(BLOCK), 0, (hipStream_t)s, p);
+		hipLaunchKernelGGL(k_shade_pt<false>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(false))), dim3(BLOCK), 0, (hipStream_t)s, p);
 }
 
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
