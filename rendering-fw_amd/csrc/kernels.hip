@@ -346,8 +346,17 @@ template <bool TEX> RT_FN void shade_tex_prepass_item(const Params &p, uint32_t 
 	ctx.tex[6 * TEX_STRIDE] = ubits(tf);
 }
 
-template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
+#if defined(RT_DIAG_SHADE_CLOCK)
+__device__ unsigned long long g_shade_clk[32];
+#define RT_ITEM_CLK , ClkProbe *clk
+#define RT_ITEM_TICK(K) clk_tick(*clk, K)
+#else
+#define RT_ITEM_CLK
+#define RT_ITEM_TICK(K)
+#endif
+template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx RT_ITEM_CLK)
 {
+	RT_ITEM_TICK(0);
 	const uint32_t b = p.depth & 1u, nb = b ^ 1u;
 	ShadeOut out;
 	out.radiance = mk3(0, 0, 0);
@@ -407,10 +416,10 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 				tx.color = mk3(ctx.tex[0], ctx.tex[TEX_STRIDE], ctx.tex[2 * TEX_STRIDE]);
 				tx.iN = mk3(ctx.tex[3 * TEX_STRIDE], ctx.tex[4 * TEX_STRIDE], ctx.tex[5 * TEX_STRIDE]);
 				tx.flags = fbits(ctx.tex[6 * TEX_STRIDE]);
-				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, &tx);
+				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, &tx RT_CLK_ARG);
 			}
 			else
-				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot);
+				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, nullptr RT_CLK_ARG);
 			write_rad = true;
 		}
 	}
@@ -436,6 +445,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 			p.wv.rad[slot] = r;
 		}
 	}
+	RT_ITEM_TICK(7);
 	WaveCounters *c = p.wv.counters;
 	const uint32_t si = ctx.alloc(ctx.q_shadow, out.emit_shadow, &c->shadow_n[p.depth]);
 	if (out.emit_shadow)
@@ -451,6 +461,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		p.wv.dir[nb][ei] = out.ed;
 		p.wv.thr[nb][ei] = out.et;
 	}
+	RT_ITEM_TICK(8);
 }
 
 // The end of shadow ray i of path slot `slot`.  Depth 0 with a connection buffer: the FIRST term of the slot's sum is stored —
@@ -1853,10 +1864,19 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		const uint32_t per_wave = count / (nwaves * 4u);
 		ctx.q_block = per_wave > QUEUE_BLOCK ? QUEUE_BLOCK : (per_wave < 64u ? 0u : per_wave);
 	}
+#if defined(RT_DIAG_SHADE_CLOCK)
+	__shared__ unsigned long long s_clk[BLOCK / 64][32];
+	if (lane < 32u)
+		s_clk[wave][lane] = 0ull;
+	ClkProbe clk;
+	clk.last = __builtin_readcyclecounter(), clk.acc = s_clk[wave];
+#endif
 	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
 	uint32_t nq = 0;								// queued hits (wave-uniform)
 	uint32_t nm = 0;								// queued misses (RT_MISS_QUEUE)
 	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
+	// (fetching a chunk's primitive ids one chunk ahead, so that a scan is not a memory round trip with nothing beside it, costs
+	// a register the shading needs: shade alone 8.55 -> 9.0 ms per sub-batch, 4640 -> 4540 Msamples/s.  Not done.)
 #pragma nounroll
 	for (;;)
 	{
@@ -1915,8 +1935,16 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			shade_tex_prepass_item<TEX>(p, idx, act, ctx);
 			__builtin_amdgcn_wave_barrier();
 		}
+#if defined(RT_DIAG_SHADE_CLOCK)
+		shade_pt_item<TEX>(p, idx, act, ctx, &clk);
+#else
 		shade_pt_item<TEX>(p, idx, act, ctx);
+#endif
 	}
+#if defined(RT_DIAG_SHADE_CLOCK)
+	if (lane < 32u)
+		atomicAdd(g_shade_clk + lane, s_clk[wave][lane]);
+#endif
 	// what is left of this wave's last queue blocks becomes void entries; the ray counts go to the statistics
 	WaveCounters *const wc = p.wv.counters;
 	const uint32_t nb = (p.depth & 1u) ^ 1u;
@@ -2230,6 +2258,21 @@ uint32_t queue_pad(uint32_t max_items)
 
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 {
+#if defined(RT_DIAG_SHADE_CLOCK)
+	static int launches = 0;
+	if (++launches % 96 == 0)
+	{
+		unsigned long long h[32];
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_clk), sizeof(h));
+		double tot = 0;
+		for (int k = 0; k < 16; k++)
+			tot += (double)h[k];
+		fprintf(stderr, "[shade clock] after %d launches:", launches);
+		for (int k = 0; k < 13; k++)
+			fprintf(stderr, " %d: %.1f%% (%.0f cyc x %llu)", k, 100.0 * (double)h[k] / tot, h[16 + k] ? (double)h[k] / (double)h[16 + k] : 0.0, h[16 + k]);
+		fprintf(stderr, "\n");
+	}
+#endif
 	if (p.textured)
 		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(true))), dim3(BLOCK), 0, (hipStream_t)s, p);
 	else
@@ -2629,7 +2672,13 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 	Ctx ctx;
 	const uint32_t n = p.wv.counters->ext_n[p.depth];
 	for (uint32_t i = 0; i < n; i++)
+#if defined(RT_DIAG_SHADE_CLOCK)
+		ClkProbe clk0;
+		clk0.last = 0, clk0.acc = nullptr;
+		p.textured ? shade_pt_item<true>(p, i, true, ctx, &clk0) : shade_pt_item<false>(p, i, true, ctx, &clk0);
+#else
 		p.textured ? shade_pt_item<true>(p, i, true, ctx) : shade_pt_item<false>(p, i, true, ctx);
+#endif
 	p.wv.counters->ext[p.depth + 1] += ctx.q_ext.rays, p.wv.counters->shadow[p.depth] += ctx.q_shadow.rays;
 }
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)

@@ -20,6 +20,34 @@
 namespace rt
 {
 
+// RT_DIAG_SHADE_CLOCK (development builds, tools/dev/variant.sh): where a wave of the shade kernel spends its cycles.  RT_TICK(k)
+// adds the shader-clock cycles since the previous tick to phase k of a global table (one atomic per wave and tick; a load's
+// latency lands in the phase that first uses its result).
+#if defined(RT_DIAG_SHADE_CLOCK)
+struct ClkProbe
+{
+	unsigned long long last;
+	unsigned long long *acc;
+};
+RT_FN void clk_tick(ClkProbe &c, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned long long t = __builtin_readcyclecounter();
+	const unsigned long long m = __ballot(1);
+	if (m && (int)__lane_id() == __ffsll((long long)m) - 1)
+		c.acc[k] += t - c.last, c.acc[16 + k] += 1ull; // (the wave's own table in LDS; flushed once when the kernel ends)
+	c.last = __builtin_readcyclecounter();
+#endif
+}
+#define RT_TICK(K) do { if (clk) clk_tick(*clk, K); } while (0)
+#define RT_CLK_PARAM , ClkProbe *clk = nullptr
+#define RT_CLK_ARG , clk
+#else
+#define RT_TICK(K)
+#define RT_CLK_PARAM
+#define RT_CLK_ARG
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // division and square root of the SHADING arithmetic (BSDF, light sampling, normals: everything behind the hit record)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1364,9 +1392,29 @@ RT_FN void create_tangent_space(f3 N, f3 &T, f3 &B)
 // ---------------------------------------------------------------------------------------------------------------
 // light sampling: CUDART/src/lights.h
 // ---------------------------------------------------------------------------------------------------------------
+// A record of a table whose index is the same in every lane of the wave (the loops over all lights): on the device it is read
+// through the constant address space, from which the compiler selects scalar loads — one s_load per 16 / 32 / 64 bytes into
+// SGPRs, waited for with lgkmcnt — instead of a global_load per lane with the same address and a wait for EVERY load the wave has
+// in flight.  (The light loop of a shaded hit was ten dependent round trips of that kind: 46 % of the shade kernel's wave time,
+// tools/dev: RT_DIAG_SHADE_CLOCK.)  A lane-varying index still works (the compiler falls back to vector loads).
+template <typename T> RT_FN T uniform_record(const T *table, uint32_t idx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+	const __attribute__((address_space(4))) uint32_t *src = (const __attribute__((address_space(4))) uint32_t *)(table + idx);
+	T r;
+	uint32_t *dst = (uint32_t *)&r;
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; i++)
+		dst[i] = src[i];
+	return r;
+#else
+	return table[idx];
+#endif
+}
 RT_FN float pot_area(const SceneView &sc, uint32_t idx, f3 O, f3 N, f3 I, f3 bary)
 {
-	const AreaLight &l = sc.area[idx];
+	const AreaLight l = uniform_record(sc.area, idx);
 	f3 L = I;
 	if (bary.x >= 0)
 		L = (ld3(l.vertex0) * bary.x + ld3(l.vertex1) * bary.y) + ld3(l.vertex2) * bary.z;
@@ -1379,7 +1427,7 @@ RT_FN float pot_area(const SceneView &sc, uint32_t idx, f3 O, f3 N, f3 I, f3 bar
 }
 RT_FN float pot_point(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 {
-	const PointLight &l = sc.point[idx];
+	const PointLight l = uniform_record(sc.point, idx);
 	const f3 L = ld3(l.position) - I;
 	const float NdotL = fmaxf(0.0f, dot(N, L));
 	const float att = m_rcp(dot(L, L));
@@ -1387,7 +1435,7 @@ RT_FN float pot_point(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 }
 RT_FN float pot_spot(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 {
-	const SpotLight &l = sc.spot[idx];
+	const SpotLight l = uniform_record(sc.spot, idx);
 	f3 L = ld3(l.position) - I;
 	const float att = m_rcp(dot(L, L));
 	L = normalize(L);
@@ -1398,7 +1446,7 @@ RT_FN float pot_spot(const SceneView &sc, uint32_t idx, f3 I, f3 N)
 }
 RT_FN float pot_dir(const SceneView &sc, uint32_t idx, f3 N)
 {
-	const DirectionalLight &l = sc.dir[idx];
+	const DirectionalLight l = uniform_record(sc.dir, idx);
 	return l.energy * fmaxf(0.0f, -dot(ld3(l.direction), N));
 }
 RT_FN uint32_t total_lights(const SceneView &sc) { return sc.n_area + sc.n_point + sc.n_spot + sc.n_dir; }
@@ -1491,23 +1539,34 @@ constexpr int POT_STRIDE = 256;
 constexpr int POT_STRIDE = 1;
 #endif
 RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3 N, float &pickProb, float &lightPdf,
-							   f3 &lightColor, float *pot_cache)
+							   f3 &lightColor, float *pot_cache RT_CLK_PARAM)
 {
 	const uint32_t lights = total_lights(sc);
 	const f3 bary = random_barycentrics(r0);
+	RT_TICK(9);
+	// (one loop per kind of light, in the order of pot_any(): a loop without the four-way branch, whose records are read by
+	// scalar loads and which the compiler can unroll)
 	float sum = 0;
-	for (uint32_t k = 0; k < lights; k++)
-	{
-		const float pk = pot_any(sc, k, I, N, bary);
-		if (pot_cache && k < POT_CACHE)
-			pot_cache[k * POT_STRIDE] = pk;
-		sum += pk;
+	uint32_t kk = 0;
+#define RT_POT_LOOP(COUNT, EXPR)                      \
+	for (uint32_t i = 0; i < (COUNT); i++, kk++)      \
+	{                                                 \
+		const float pk = EXPR;                        \
+		if (pot_cache && kk < POT_CACHE)              \
+			pot_cache[kk * POT_STRIDE] = pk;          \
+		sum += pk;                                    \
 	}
+	RT_POT_LOOP(sc.n_area, pot_area(sc, i, I, N, mk3(0, 0, 0), bary))
+	RT_POT_LOOP(sc.n_point, pot_point(sc, i, I, N))
+	RT_POT_LOOP(sc.n_spot, pot_spot(sc, i, I, N))
+	RT_POT_LOOP(sc.n_dir, pot_dir(sc, i, N))
+#undef RT_POT_LOOP
 	if (sum <= 0)
 	{
 		lightPdf = 0;
 		return mk3(1, 1, 1);
 	}
+	RT_TICK(10);
 	r1 *= sum;
 	float total = 0, chosen = 0, first = 0;
 	uint32_t li = 0;
@@ -1526,6 +1585,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 			li = 0, chosen = first;
 	}
 	pickProb = m_div(chosen, sum);
+	RT_TICK(11);
 	if (li < sc.n_area)
 	{
 		const AreaLight &l = sc.area[li];
@@ -1712,23 +1772,26 @@ RT_FN void pt_texture_prepass(const SceneView &sc, const CamView &cam, f3 D, con
 // tex: the pre-pass's record of this hit (TEX only; null: the layers are fetched here).
 template <bool TEX>
 RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
-					ShadeOut &out, float *pot_cache, const TexShade *tex = nullptr)
+					ShadeOut &out, float *pot_cache, const TexShade *tex = nullptr RT_CLK_PARAM)
 {
 	out.radiance = mk3(0, 0, 0);
 	out.emit_shadow = false, out.emit_ext = false;
 	const f3 O = in.O, D = in.D;
 	f3 T = in.T;
+	RT_TICK(1);
 	if (h.prim < 0)
 	{
 		f3 contribution = (T * m_rcp(in.bsdfPdf)) * pt_sky(sc, D);
 		if (any_nan(contribution))
 			return;
 		out.radiance = clamp_intensity(contribution, cam.clamp_value);
+		RT_TICK(2);
 		return;
 	}
 	const f3 I = O + D * h.t;
 	Surface sf;
 	pt_surface(sc, h, sf);
+	RT_TICK(3);
 	const MaterialRec &mat = *sf.mat;
 	const f4 tu4 = sf.tu4, ex = sf.ex;
 	Shading sd;
@@ -1788,6 +1851,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 		out.radiance = clamp_intensity(contribution, cam.clamp_value);
 		return;
 	}
+	RT_TICK(4);
 	uint32_t flags = in.flags;
 	if (sd_roughness(sd) < 0.01f)
 		flags |= 1u;
@@ -1814,7 +1878,8 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 		}
 		else
 			q0 = random_float(seed), q1 = random_float(seed);
-		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache) - I;
+		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache RT_CLK_ARG) - I;
+		RT_TICK(12);
 		const float dist = length(L);
 		L = L * m_rcp(dist);
 		const float NdotL = dot(L, iN);
@@ -1837,6 +1902,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 			}
 		}
 	}
+	RT_TICK(5);
 	if (in.depth >= max_depth)
 		return;
 	f3 R = mk3(0, 0, 1);
@@ -1856,6 +1922,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (flags & 1u)));
 	out.ed = mk4(R.x, R.y, R.z, ubits(pack_normal(iN)));
 	out.et = mk4(T.x, T.y, T.z, newPdf);
+	RT_TICK(6);
 }
 
 } // namespace rt
