@@ -68,6 +68,27 @@ RT_FN float m_sqrtf(float x) { return sqrtf(x); }
 RT_FN float m_rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #endif
 
+// A record of a table whose index is the same in every lane of the wave (the loops over all lights): on the device it is read
+// through the constant address space, from which the compiler selects scalar loads — one s_load per 16 / 32 / 64 bytes into
+// SGPRs, waited for with lgkmcnt — instead of a global_load per lane with the same address and a wait for EVERY load the wave has
+// in flight.  (The light loop of a shaded hit was ten dependent round trips of that kind: 46 % of the shade kernel's wave time,
+// tools/dev: RT_DIAG_SHADE_CLOCK.)  A lane-varying index still works (the compiler falls back to vector loads).
+template <typename T> RT_FN T uniform_record(const T *table, uint32_t idx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+	const __attribute__((address_space(4))) uint32_t *src = (const __attribute__((address_space(4))) uint32_t *)(table + idx);
+	T r;
+	uint32_t *dst = (uint32_t *)&r;
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; i++)
+		dst[i] = src[i];
+	return r;
+#else
+	return table[idx];
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // small vector algebra
 // ---------------------------------------------------------------------------------------------------------------
@@ -1058,7 +1079,7 @@ RT_FN f4 parity_shade(const SceneView &sc, f3 O, f3 D, const Hit &h, TravStack &
 	Hit sh;
 	for (uint32_t i = 0; i < sc.n_area; i++)
 	{
-		const AreaLight &l = sc.area[i];
+		const AreaLight l = uniform_record(sc.area, i);
 		f3 L = ld3(l.position) - p;
 		const float sq = dot(L, L), dist = sqrtf(sq);
 		L = mk3(L.x / dist, L.y / dist, L.z / dist);
@@ -1075,7 +1096,7 @@ RT_FN f4 parity_shade(const SceneView &sc, f3 O, f3 D, const Hit &h, TravStack &
 	}
 	for (uint32_t i = 0; i < sc.n_point; i++)
 	{
-		const PointLight &l = sc.point[i];
+		const PointLight l = uniform_record(sc.point, i);
 		f3 L = ld3(l.position) - p;
 		const float sq = dot(L, L), dist = sqrtf(sq);
 		L = mk3(L.x / dist, L.y / dist, L.z / dist);
@@ -1392,26 +1413,6 @@ RT_FN void create_tangent_space(f3 N, f3 &T, f3 &B)
 // ---------------------------------------------------------------------------------------------------------------
 // light sampling: CUDART/src/lights.h
 // ---------------------------------------------------------------------------------------------------------------
-// A record of a table whose index is the same in every lane of the wave (the loops over all lights): on the device it is read
-// through the constant address space, from which the compiler selects scalar loads — one s_load per 16 / 32 / 64 bytes into
-// SGPRs, waited for with lgkmcnt — instead of a global_load per lane with the same address and a wait for EVERY load the wave has
-// in flight.  (The light loop of a shaded hit was ten dependent round trips of that kind: 46 % of the shade kernel's wave time,
-// tools/dev: RT_DIAG_SHADE_CLOCK.)  A lane-varying index still works (the compiler falls back to vector loads).
-template <typename T> RT_FN T uniform_record(const T *table, uint32_t idx)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
-	const __attribute__((address_space(4))) uint32_t *src = (const __attribute__((address_space(4))) uint32_t *)(table + idx);
-	T r;
-	uint32_t *dst = (uint32_t *)&r;
-#pragma unroll
-	for (uint32_t i = 0; i < sizeof(T) / 4; i++)
-		dst[i] = src[i];
-	return r;
-#else
-	return table[idx];
-#endif
-}
 RT_FN float pot_area(const SceneView &sc, uint32_t idx, f3 O, f3 N, f3 I, f3 bary)
 {
 	const AreaLight l = uniform_record(sc.area, idx);
@@ -1533,6 +1534,7 @@ RT_FN f3 random_barycentrics(float r0)
 // lights.h:159-265 with importance sampling over the potential contribution of every light.  The potentials are
 // recomputed in the selection pass instead of being kept in a MAX_IS_LIGHTS array, so any light count is valid.
 constexpr uint32_t POT_CACHE = 16; // potentials of the first 16 lights are kept (in LDS on the GPU) between the passes
+constexpr uint32_t POT_SLOTS = POT_CACHE + 1; // + one slot that takes the writes of every further light (a store without a branch)
 #if defined(RT_DEVICE_BUILD)
 constexpr int POT_STRIDE = 256;
 #else
@@ -1552,8 +1554,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 	for (uint32_t i = 0; i < (COUNT); i++, kk++)      \
 	{                                                 \
 		const float pk = EXPR;                        \
-		if (pot_cache && kk < POT_CACHE)              \
-			pot_cache[kk * POT_STRIDE] = pk;          \
+		pot_cache[(kk < POT_CACHE ? kk : POT_CACHE) * POT_STRIDE] = pk; \
 		sum += pk;                                    \
 	}
 	RT_POT_LOOP(sc.n_area, pot_area(sc, i, I, N, mk3(0, 0, 0), bary))
@@ -1572,7 +1573,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 	uint32_t li = 0;
 	for (uint32_t k = 0; k < lights; k++)
 	{
-		const float p = (pot_cache && k < POT_CACHE) ? pot_cache[k * POT_STRIDE] : pot_any(sc, k, I, N, bary);
+		const float p = k < POT_CACHE ? pot_cache[k * POT_STRIDE] : pot_any(sc, k, I, N, bary);
 		if (k == 0)
 			first = p;
 		total += p;
