@@ -75,6 +75,32 @@ def test_spot_and_directional_lights_in_the_path_tracer(pkg, make_emu, make_orac
     assert frac <= 2e-2, (frac, rmse)
 
 
+def many_lights_scene(pkg, w, h):
+    """The Cornell room with 2 area-light triangles, 20 point lights, 3 spot lights and a directional light: 26 lights — more than the
+    16 potentials the shade step keeps between its two passes over the lights (rt::POT_CACHE: the others are recomputed in the
+    selection pass, their stores go to the spare slot)."""
+    scene = pkg.scenes.cornell(w, h, geometric_emitter=True)
+    for k in range(20):
+        x, z = -4.0 + 2.0 * (k % 5), -4.0 + 2.5 * (k // 5)
+        scene.add_point_light((x, 8.5 - 0.2 * (k % 3), z), (2.0 + 0.3 * k, 3.0, 8.0 - 0.3 * k))
+    scene.add_spot_light((0.0, 9.0, 0.0), 20.0, (40.0, 40.0, 35.0), 35.0, (0.1, -1.0, 0.2))
+    scene.add_spot_light((-3.0, 8.0, 2.0), 15.0, (30.0, 10.0, 10.0), 30.0, (0.4, -1.0, -0.2))
+    scene.add_spot_light((3.0, 8.0, -2.0), 25.0, (10.0, 30.0, 10.0), 40.0, (-0.4, -1.0, 0.2))
+    scene.add_directional_light((0.3, -1.0, 0.6), (0.8, 0.7, 0.6))
+    return scene
+
+
+def test_more_lights_than_the_potential_cache_holds(pkg, make_emu, make_oracle):
+    scene = many_lights_scene(pkg, 64, 48)
+    ctxs = [make_emu(), make_oracle()]
+    a, b = _run(pkg, ctxs, scene, 64, 48, {"integrator": "pt", "spp": 8})
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 2e-2, (frac, rmse)
+    sa, sb = ctxs[0].get_stats(), ctxs[1].get_stats()
+    assert abs(sa.shadowCount - sb.shadowCount) <= max(3, 2e-3 * sb.shadowCount), (sa.shadowCount, sb.shadowCount)
+    assert sb.shadowCount > 0
+
+
 def test_textured_materials_both_integrators(pkg, make_emu, make_oracle):
     """UINT (RGBA8 + 5 mips) and FLOAT4 diffuse maps: nearest/level-0 with the (w-1) scaling and the switch
     fall-through in the parity integrator (Context.cpp:439-473), trilinear in the path tracer

@@ -391,6 +391,20 @@ def test_spot_and_directional_lights_on_the_gpu(pkg, make_hip, make_oracle):
     assert a[..., :3].mean() > 1.02 * hip2.framebuffer()[..., :3].mean() or a[..., :3].mean() < 0.98 * hip2.framebuffer()[..., :3].mean()
 
 
+def test_more_lights_than_the_potential_cache_holds_on_the_gpu(pkg, make_hip, make_oracle):
+    """26 lights of all four kinds: the loops over the lights read their records by scalar loads (rt::uniform_record), the first 16
+    potentials wait in LDS for the selection pass, the others are recomputed there."""
+    from test_emu_parity import many_lights_scene
+    scene = many_lights_scene(pkg, 256, 192)
+    hip, ref = _pair(pkg, make_hip, make_oracle, scene, 256, 192, {"integrator": "pt", "spp": 16})
+    a, b = hip.framebuffer(), ref.framebuffer()
+    frac, rmse, _ = image_stats(a, b, 2e-2)
+    assert frac <= 1e-2 and rmse <= 3e-2, (frac, rmse)
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) <= 3e-3 * b[..., :3].mean()
+    sa, sb = hip.get_stats(), ref.get_stats()
+    assert abs(sa.shadowCount - sb.shadowCount) <= 2e-3 * sb.shadowCount, (sa.shadowCount, sb.shadowCount)
+
+
 @pytest.mark.parametrize("scene_name", ["cornell", "cards"])
 def test_per_depth_wave_counts_equal_the_oracle(pkg, make_hip, make_oracle, scene_name):
     """Wave sizes per depth (Kernels.cu:640,747,788: the compaction counters): extension rays of depth 1, of depths >= 2, and
