@@ -416,11 +416,12 @@ def main():
         bounce = {k: per_step[k] - prim[k] for k in prim}
         # ---- algorithmic bytes per step, stage by stage ---------------------------------------------------------
         # primary: 16 B direction + 20 B hit record written per ray (pinhole camera: no origin record), traversal per RAY;
-        # bounce: 32 B ray in + 20 B hit out; shadow: 48 B ray in (the 32 B read-modify-write of an unoccluded ray's radiance is
-        # not counted: no count of them is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
+        # bounce: 32 B ray in + 20 B hit out; shadow: 32 B ray in (the contribution record and the 32 B read-modify-write of an
+        # unoccluded ray's radiance at depths >= 1, the 16 B store of an occluded one at depth 0 are not counted: no count of them
+        # is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
         algo_primary = prim["rays_extend"] * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
         algo_bounce = bounce["rays_extend"] * (32 + 20) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
-        algo_shadow = per_step["rays_shadow"] * 48 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
+        algo_shadow = per_step["rays_shadow"] * 32 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
         # shade: depth-0 entries read direction + hit record (36 B) and write 16 B radiance (+ 16 B for the connection term of a
         # path that emits no shadow ray); deeper entries read origin, direction, throughput, hit record (68 B); a shaded hit gathers
         # its 96 B shading record and 48 B of material; 48 B per emitted shadow ray, 48 B per emitted extension ray

@@ -436,9 +436,14 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 			// 16 bytes less written here and 16 less read there for every such path (two in five on the terrain).
 			const bool ends = p.wv.rad_nee && !out.emit_shadow && !out.emit_ext;
 			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, ends ? -1.0f : 1.0f);
-			// the connection wave of depth 0 STORES its slot's first term (connect_store), so only the paths that emit no shadow
-			// ray here but go on initialise theirs: 16 bytes less written per connecting path, in the one kernel that is short of bytes
-			if (p.wv.rad_nee && !out.emit_shadow && out.emit_ext)
+			// The slot's connection term starts as what the shadow ray of this vertex would add if the light is visible — 0 + e: the
+			// bits an accumulation onto a zeroed slot produces — and the connection wave of depth 0 only ZEROES it for an occluded
+			// light (connect_finish): that wave then retires a ray without reading anything (the contribution record and the wait for
+			// it were 8 % of a shadow wave's time), and no contribution record is written here.  Paths that emit no shadow ray but
+			// go on start theirs at zero.
+			if (p.wv.rad_nee && out.emit_shadow)
+				p.wv.rad_nee[slot] = mk4(0.0f + out.se.x, 0.0f + out.se.y, 0.0f + out.se.z, 0.0f);
+			else if (p.wv.rad_nee && out.emit_ext)
 				p.wv.rad_nee[slot] = mk4(0, 0, 0, 0);
 		}
 		else if (out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
@@ -457,7 +462,8 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	{
 		p.wv.sh_org[si] = out.so;
 		p.wv.sh_dir[si] = out.sd;
-		p.wv.sh_rad[si] = out.se;
+		if (p.depth != 0 || !p.wv.rad_nee) // (depth 0 with a connection buffer: the term already waits in its slot, above)
+			p.wv.sh_rad[si] = out.se;
 	}
 	const uint32_t ei = ctx.alloc(ctx.q_ext, out.emit_ext, &c->ext_n[p.depth + 1]);
 	if (out.emit_ext)
@@ -469,17 +475,14 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	RT_ITEM_TICK(8);
 }
 
-// The end of shadow ray i of path slot `slot`.  Depth 0 with a connection buffer: the FIRST term of the slot's sum is stored —
-// 0 + e for a visible light, 0 for an occluded one: the bits the accumulation onto a zeroed slot produced — so the shade kernel
-// need not zero the slot and nothing is read back.  Later depths accumulate.
+// The end of shadow ray i of path slot `slot`.  Depth 0 with a connection buffer: the slot already holds the term of a visible
+// light (shade_pt_item); an occluded one zeroes it — nothing is read.  Later depths accumulate.
 RT_FN void connect_finish(const Params &p, uint32_t i, uint32_t slot, bool visible)
 {
 	if (p.depth == 0 && p.wv.rad_nee)
 	{
-		f4 e4 = mk4(0, 0, 0, 0);
-		if (visible)
-			e4 = p.wv.sh_rad[i];
-		p.wv.rad_nee[slot] = mk4(0.0f + e4.x, 0.0f + e4.y, 0.0f + e4.z, 0.0f);
+		if (!visible)
+			p.wv.rad_nee[slot] = mk4(0, 0, 0, 0);
 	}
 	else if (visible)
 	{
@@ -1252,9 +1255,25 @@ enum
 	STREAM_PRIMARY_PT = 2
 };
 
+// RT_DIAG_TRACE_CLOCK (development builds): a traversal wave's cycles by phase of its loop — refill, node phase, leaf phase,
+// retirement — kept in scalar registers (s_memtime), added to a global table when the wave leaves.
+#if defined(RT_DIAG_TRACE_CLOCK)
+__device__ unsigned long long g_trace_clk[3][8];
+#define RT_TRACE_TICK(K)                                           \
+	{                                                              \
+		const unsigned long long t_ = __builtin_readcyclecounter(); \
+		clk_acc[K] += t_ - clk_last, clk_n[K]++;                    \
+		clk_last = __builtin_readcyclecounter();                    \
+	}
+#else
+#define RT_TRACE_TICK(K)
+#endif
 template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(const Params &p, const uint32_t count, Ctx &ctx)
 {
 	constexpr bool ANY = MODE == STREAM_ANY;
+#if defined(RT_DIAG_TRACE_CLOCK)
+	unsigned long long clk_acc[4] = {0, 0, 0, 0}, clk_n[4] = {0, 0, 0, 0}, clk_last = __builtin_readcyclecounter();
+#endif
 	WaveCounters *const wc = p.wv.counters;
 	uint32_t *const head = &wc->work[p.queue][0];
 	const uint32_t b = p.depth & 1u;
@@ -1364,7 +1383,9 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 				break;
 			continue; // (primary slots outside the image leave their lanes idle: take the next ones)
 		}
+		RT_TRACE_TICK(0)
 		T.template descend<VOTE>(p.sc, ctx.stk, st);
+		RT_TRACE_TICK(1)
 		const auto world = [&](f3 &O, f3 &D) {
 			if constexpr (WORLD)
 				O = T.O, D = T.D;
@@ -1385,6 +1406,10 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 #if !RT_WAVE_TRIS
 			T.visit(p.sc, ctx.stk, st, world);
 #endif
+		}
+		RT_TRACE_TICK(2)
+		if (has_ray)
+		{
 			if (T.done())
 			{
 				if (ANY)
@@ -1399,7 +1424,14 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 				has_ray = false;
 			}
 		}
+		RT_TRACE_TICK(3)
 	}
+#if defined(RT_DIAG_TRACE_CLOCK)
+	if (lane == 0u)
+		for (int k = 0; k < 4; k++)
+			atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : (MODE == STREAM_EXT ? 0 : 2)][k], clk_acc[k]),
+				atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : (MODE == STREAM_EXT ? 0 : 2)][4 + k], clk_n[k]);
+#endif
 	if (COUNT)
 	{
 		ctx.add64(ANY ? &wc->inner_shadow : &wc->inner_extend, st.inner);
@@ -2303,6 +2335,26 @@ void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)
 
 void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s)
 {
+#if defined(RT_DIAG_TRACE_CLOCK)
+	static int launches = 0;
+	if (++launches % 64 == 0)
+	{
+		unsigned long long h[3][8];
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace_clk), sizeof(h));
+		const char *names[3] = {"ext", "any", "primary"};
+		for (int m = 0; m < 3; m++)
+		{
+			double tot = 0;
+			for (int k = 0; k < 4; k++)
+				tot += (double)h[m][k];
+			if (tot == 0)
+				continue;
+			fprintf(stderr, "[trace clock %s] refill %.1f%% (%.0f cyc x %llu)  nodes %.1f%% (%.0f)  leaves %.1f%% (%.0f)  retire %.1f%% (%.0f)\n", names[m],
+					100 * h[m][0] / tot, (double)h[m][0] / (double)h[m][4], h[m][4], 100 * h[m][1] / tot, (double)h[m][1] / (double)h[m][5],
+					100 * h[m][2] / tot, (double)h[m][2] / (double)h[m][6], 100 * h[m][3] / tot, (double)h[m][3] / (double)h[m][7]);
+		}
+	}
+#endif
 	const dim3 g(persistent_grid(max_items));
 	const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
 	if (count)

@@ -17,7 +17,7 @@ scene.upload(ctx)
 ctx.set_setting("integrator", "pt")
 ctx.set_setting("spp", spp)
 ctx.set_setting("max_depth", 2)
-ctx.set_setting("fuse", 0)
+ctx.set_setting("fuse", int(os.environ.get("PC_FUSE", "0")))
 ctx.set_setting("streams", 1)
 for f in range(frames):
     ctx.render_frame(scene.camera, pkg.RESET if f == 0 else 0)
