@@ -1884,8 +1884,8 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ctx.tex = s_tex + (TEX ? threadIdx.x : 0);
 	const uint32_t count = p.wv.counters->ext_n[p.depth];
 	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by lane
-	// on the bounce waves.  Every WAVE keeps its own queue of hit paths in LDS: it walks 64-path chunks, shades a chunk's
-	// misses in place and appends its hits to the queue; whenever 64 hits are queued it shades them as one full wave.
+	// on the bounce waves.  Every WAVE keeps its own queues of hit paths and of misses in LDS: it walks 64-path chunks and appends
+	// every entry to its queue; whenever 64 of a kind are queued it shades them as one full wave (hits first).
 	// No workgroup barrier anywhere (round 1's per-256 compaction parked the waves without hits at a barrier, holding
 	// their SIMD slots, while the others shaded), and the expensive path always runs with all lanes.  Which lane shades a
 	// path does not affect its result.

@@ -21,8 +21,8 @@ namespace rt
 {
 
 // RT_DIAG_SHADE_CLOCK (development builds, tools/dev/variant.sh): where a wave of the shade kernel spends its cycles.  RT_TICK(k)
-// adds the shader-clock cycles since the previous tick to phase k of a global table (one atomic per wave and tick; a load's
-// latency lands in the phase that first uses its result).
+// adds the s_memtime ticks since the previous tick to phase k of the wave's table in LDS, which the wave adds to a global one when
+// it leaves (a load's latency lands in the phase that first uses its result).
 #if defined(RT_DIAG_SHADE_CLOCK)
 struct ClkProbe
 {
