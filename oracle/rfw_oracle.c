@@ -1295,7 +1295,8 @@ static v3 pt_sky(const rfwo_context *c, v3 D)
 	if (!c->sky || !c->skyW || !c->skyH)
 		return V3(0, 0, 0);
 	const float inv_pi = 0.318309886183790671538f;
-	const uint32_t u = f2u_sat((float)c->skyW * 0.5f * (1.0f + atan2f(D.x, -D.z) * inv_pi));
+	const float turns = rounded(atan2f(D.x, -D.z) * inv_pi); /* (the product rounded on its own: csrc/rt_core.h, pt_sky) */
+	const uint32_t u = f2u_sat((float)c->skyW * 0.5f * (1.0f + turns));
 	const uint32_t v = f2u_sat((float)c->skyH * acosf(fclamp(D.y, -1.0f, 1.0f)) * inv_pi);
 	const uint64_t idx = (uint64_t)u + (uint64_t)v * c->skyW;
 	if (idx < (uint64_t)c->skyW * c->skyH)

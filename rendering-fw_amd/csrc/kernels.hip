@@ -475,6 +475,33 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	RT_ITEM_TICK(8);
 }
 
+// The end of primary ray `idx` of the pt integrator's packet kernel (device: k_primary_packet, emulation: packet_emu::primary).
+// A hit goes to the shade stage: direction record + hit record.  A MISS is finished here (RT_PRIMARY_MISS): the wave is converged,
+// all 64 samples of a sky pixel miss together, and what the shade stage would do for it — the sky along the ray into the slot
+// (pt_shade, h.prim < 0 at depth 0: throughput 1, pdf 1; shade_pt_item: alpha -1 = the path ends, no connection record) — needs
+// nothing the kernel does not hold.  The shade kernel then neither queues the path nor reads its direction (27 % of the bench
+// scene's primaries), and no direction record is written for it; its hit record says HIT_MISS_SHADED (read back as a miss).
+#ifndef RT_PRIMARY_MISS
+#define RT_PRIMARY_MISS 1
+#endif
+RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h)
+{
+	int prim = h.prim;
+	if (RT_PRIMARY_MISS && prim < 0)
+	{
+		f3 radiance = mk3(0, 0, 0);
+		const f3 contribution = (mk3(1, 1, 1) * m_rcp(1.0f)) * pt_sky(q.sc, D);
+		if (!any_nan(contribution))
+			radiance = clamp_intensity(contribution, q.cam.clamp_value);
+		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
+		prim = HIT_MISS_SHADED;
+	}
+	else
+		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
+	q.wv.hit0_inst[idx] = h.inst;
+}
+
 // The end of shadow ray i of path slot `slot`.  Depth 0 with a connection buffer: the slot already holds the term of a visible
 // light (shade_pt_item); an occluded one zeroes it — nothing is read.  Later depths accumulate.
 RT_FN void connect_finish(const Params &p, uint32_t i, uint32_t slot, bool visible)
@@ -1830,7 +1857,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 						pt_primary_ray(q.cam, q.fr.W, q.fr.H, pr.x, pr.y, q.fr.sample_base + pr.sample, O, D);
 						if (q.cam.aperture != 0.0f) // (pinhole: no origin record, extend_item)
 							q.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
-						q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
 					}
 				}
 			}
@@ -1839,9 +1865,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 			trace_packet<COUNT>(fresh_params().sc, active, O, D, 1e-5f, h, st);
 			if (active)
 			{
-				const Params &q = fresh_params();
-				q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
-				q.wv.hit0_inst[idx] = h.inst;
+				primary_finish_item(fresh_params(), idx, D, h); // (direction + hit record, or the sky term of a miss)
 				nrays++;
 			}
 		}
@@ -2667,7 +2691,6 @@ template <bool COUNT> void primary(const Params &p, uint32_t count)
 					pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O[l], D[l]);
 					if (p.cam.aperture != 0.0f)
 						p.wv.org[0][idx] = mk4(O[l].x, O[l].y, O[l].z, ubits((idx << 1) | 1u));
-					p.wv.dir[0][idx] = mk4(D[l].x, D[l].y, D[l].z, 0.0f);
 				}
 			}
 			h[l].t = 1e34f, h[l].u = 0.0f, h[l].v = 0.0f, h[l].prim = -1, h[l].inst = -1;
@@ -2676,9 +2699,7 @@ template <bool COUNT> void primary(const Params &p, uint32_t count)
 		for (int l = 0; l < WAVE; l++)
 			if (active[l])
 			{
-				const uint32_t idx = base + (uint32_t)l;
-				p.wv.hit0[idx] = mk4(h[l].t, h[l].u, h[l].v, ubits((uint32_t)h[l].prim));
-				p.wv.hit0_inst[idx] = h[l].inst;
+				primary_finish_item(p, base + (uint32_t)l, D[l], h[l]);
 				nrays++;
 			}
 	}
@@ -2729,6 +2750,10 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 	Ctx ctx;
 	const uint32_t n = p.wv.counters->ext_n[p.depth];
 	for (uint32_t i = 0; i < n; i++)
+	{
+		// (a primary miss the packet form finished itself, primary_finish_item: the device kernel's scan passes it over)
+		if (p.depth == 0 && (int)fbits(p.wv.hit0[i].w) == HIT_MISS_SHADED)
+			continue;
 #if defined(RT_DIAG_SHADE_CLOCK)
 		ClkProbe clk0;
 		clk0.last = 0, clk0.acc = nullptr;
@@ -2736,6 +2761,7 @@ void launch_shade_pt(const Params &p, uint32_t, stream_t)
 #else
 		p.textured ? shade_pt_item<true>(p, i, true, ctx) : shade_pt_item<false>(p, i, true, ctx);
 #endif
+	}
 	p.wv.counters->ext[p.depth + 1] += ctx.q_ext.rays, p.wv.counters->shadow[p.depth] += ctx.q_shadow.rays;
 }
 void launch_connect(const Params &p, bool count, uint32_t, stream_t)

@@ -2512,6 +2512,8 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 			const size_t o = (size_t)y * c->W + x;
 			int pr;
 			memcpy(&pr, &h[slot].w, 4);
+			if (pr == rt::HIT_MISS_SHADED) // (a miss the primary kernel shaded itself: kernels.hip, primary_finish_item)
+				pr = -1;
 			if (t)
 				t[o] = h[slot].x;
 			if (u)

@@ -1016,7 +1016,10 @@ RT_FN f3 pt_sky(const SceneView &sc, f3 D)
 {
 	if (!sc.sky_w || !sc.sky_h)
 		return mk3(0, 0, 0);
-	const uint32_t u = f2u_sat((float)sc.sky_w * 0.5f * (1.0f + m_atan2f(D.x, -D.z) * RT_INV_PI));
+	// (fixed shape, see rounded(): the product is rounded before the sum — a miss is shaded by the shade kernel or, for the packet
+	// form of the primary wave, by that kernel itself, and one of two million pixels got another texel from each)
+	const float turns = rounded(m_atan2f(D.x, -D.z) * RT_INV_PI);
+	const uint32_t u = f2u_sat((float)sc.sky_w * 0.5f * (1.0f + turns));
 	const uint32_t v = f2u_sat((float)sc.sky_h * m_acosf(clampf(D.y, -1.0f, 1.0f)) * RT_INV_PI);
 	const unsigned long long idx = (unsigned long long)u + (unsigned long long)v * sc.sky_w;
 	if (idx < (unsigned long long)sc.sky_w * sc.sky_h)

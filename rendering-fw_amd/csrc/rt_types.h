@@ -369,6 +369,7 @@ constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch
 constexpr uint32_t QUEUE_BLOCK = RT_QUEUE_BLOCK;
 constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w / sh_org.w of a void queue entry (slots are < 2^31)
 constexpr int HIT_VOID = -2;			   // hit.prim of a void entry (-1: miss)
+constexpr int HIT_MISS_SHADED = -3;	   // primary wave, packet form: a miss whose sky term is already in its slot (read back as -1)
 struct WaveCounters
 {
 	uint32_t ext[MAX_DEPTH_SLOTS];
