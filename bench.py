@@ -422,10 +422,16 @@ def main():
         algo_primary = prim["rays_extend"] * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
         algo_bounce = bounce["rays_extend"] * (32 + 20) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
         algo_shadow = per_step["rays_shadow"] * 32 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
-        # shade: depth-0 entries read direction + hit record (36 B) and write 16 B radiance (+ 16 B for the connection term of a
-        # path that emits no shadow ray); deeper entries read origin, direction, throughput, hit record (68 B); a shaded hit gathers
+        # shade: depth-0 hits read direction + hit record (36 B) and write 16 B radiance (+ 16 B for the connection term of a
+        # path that goes on without a shadow ray: at most the hits minus the shadow rays); deeper entries read origin, direction, throughput, hit record (68 B); a shaded hit gathers
         # its 96 B shading record and 48 B of material; 48 B per emitted shadow ray, 48 B per emitted extension ray
-        algo_shade = (prim["rays_extend"] * (36 + 16) + max(0.0, prim["rays_extend"] - per_step["rays_shadow"]) * 16 +
+        # (the packet form of the primary wave finishes its misses itself — sky term into the slot, no direction record: the shade
+        # kernel's scan reads their primitive id, 4 B, and nothing else; a per-lane primary kernel leaves them to the shade kernel)
+        prim_hits = float(cnt0["shaded"])
+        prim_miss = max(0.0, prim["rays_extend"] - prim_hits)
+        packet_primaries = (args.refill & 8) != 0 and args.integrator == "pt"
+        algo_shade = (prim_hits * (36 + 16) + prim_miss * (4 if packet_primaries else 36 + 16) +
+                      max(0.0, prim_hits - per_step["rays_shadow"]) * 16 +
                       bounce["rays_extend"] * 68 + per_step["shaded"] * (96 + 48) + per_step["rays_shadow"] * 48 + bounce["rays_extend"] * 48)
 
         # ---- every stage alone on the chip: one sub-batch's worth of samples on one stream, hipEvents around each launch.  The
