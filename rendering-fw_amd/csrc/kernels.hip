@@ -182,6 +182,34 @@ struct Ctx
 // ================================================================================================================
 // work items (one ray / path / pixel each) — shared by the device kernels and the host emulation
 // ================================================================================================================
+// The end of primary ray `idx` of the pt integrator where the wave is converged when its rays end: the packet kernel (device:
+// k_primary_packet, emulation: packet_emu::primary) and the one-ray-per-lane kernel of small launches (extend_item<GEN_PT>).
+// A hit goes to the shade stage: direction record + hit record.  A MISS is finished here (RT_PRIMARY_MISS): the wave is converged,
+// all 64 samples of a sky pixel miss together, and what the shade stage would do for it — the sky along the ray into the slot
+// (pt_shade, h.prim < 0 at depth 0: throughput 1, pdf 1; shade_pt_item: alpha -1 = the path ends, no connection record) — needs
+// nothing the kernel does not hold.  The shade kernel then neither queues the path nor reads its direction (27 % of the bench
+// scene's primaries), and no direction record is written for it; its hit record says HIT_MISS_SHADED (read back as a miss).
+#ifndef RT_PRIMARY_MISS
+#define RT_PRIMARY_MISS 1
+#endif
+RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h)
+{
+	int prim = h.prim;
+	if (RT_PRIMARY_MISS && prim < 0)
+	{
+		f3 radiance = mk3(0, 0, 0);
+		const f3 contribution = (mk3(1, 1, 1) * m_rcp(1.0f)) * pt_sky(q.sc, D);
+		if (!any_nan(contribution))
+			radiance = clamp_intensity(contribution, q.cam.clamp_value);
+		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
+		prim = HIT_MISS_SHADED;
+	}
+	else
+		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
+	q.wv.hit0_inst[idx] = h.inst;
+}
+
 template <int GEN, bool COUNT>
 RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 {
@@ -251,7 +279,8 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 			// i — the shade kernel needs no origin record: 16 bytes less written here and read there per primary ray)
 			if (GEN != GEN_PT || p.cam.aperture != 0.0f)
 				p.wv.org[0][i] = mk4(O.x, O.y, O.z, ubits((i << 1) | 1u));
-			p.wv.dir[0][i] = mk4(D.x, D.y, D.z, 0.0f);
+			if (GEN != GEN_PT) // (pt: written with the hit record, or not at all for a miss — primary_finish_item)
+				p.wv.dir[0][i] = mk4(D.x, D.y, D.z, 0.0f);
 		}
 	}
 	Hit h;
@@ -261,10 +290,15 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	if (active)
 	{
 		trace<false, COUNT>(p.sc, O, D, t_min, t_max, h, ctx.stk, st);
-		f4 *hb = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
-		int *ib = p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
-		hb[i] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
-		ib[i] = h.inst;
+		if (GEN == GEN_PT)
+			primary_finish_item(p, i, D, h);
+		else
+		{
+			f4 *hb = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
+			int *ib = p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
+			hb[i] = mk4(h.t, h.u, h.v, ubits((uint32_t)h.prim));
+			ib[i] = h.inst;
+		}
 	}
 	if (COUNT)
 	{
@@ -473,33 +507,6 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		p.wv.thr[nb][ei] = out.et;
 	}
 	RT_ITEM_TICK(8);
-}
-
-// The end of primary ray `idx` of the pt integrator's packet kernel (device: k_primary_packet, emulation: packet_emu::primary).
-// A hit goes to the shade stage: direction record + hit record.  A MISS is finished here (RT_PRIMARY_MISS): the wave is converged,
-// all 64 samples of a sky pixel miss together, and what the shade stage would do for it — the sky along the ray into the slot
-// (pt_shade, h.prim < 0 at depth 0: throughput 1, pdf 1; shade_pt_item: alpha -1 = the path ends, no connection record) — needs
-// nothing the kernel does not hold.  The shade kernel then neither queues the path nor reads its direction (27 % of the bench
-// scene's primaries), and no direction record is written for it; its hit record says HIT_MISS_SHADED (read back as a miss).
-#ifndef RT_PRIMARY_MISS
-#define RT_PRIMARY_MISS 1
-#endif
-RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h)
-{
-	int prim = h.prim;
-	if (RT_PRIMARY_MISS && prim < 0)
-	{
-		f3 radiance = mk3(0, 0, 0);
-		const f3 contribution = (mk3(1, 1, 1) * m_rcp(1.0f)) * pt_sky(q.sc, D);
-		if (!any_nan(contribution))
-			radiance = clamp_intensity(contribution, q.cam.clamp_value);
-		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
-		prim = HIT_MISS_SHADED;
-	}
-	else
-		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
-	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
-	q.wv.hit0_inst[idx] = h.inst;
 }
 
 // The end of shadow ray i of path slot `slot`.  Depth 0 with a connection buffer: the slot already holds the term of a visible
