@@ -415,7 +415,7 @@ def main():
         prim = {k: float(cnt0[k]) for k in ("rays_extend", "inner_extend", "tris_extend", "lds_extend")}
         bounce = {k: per_step[k] - prim[k] for k in prim}
         # ---- algorithmic bytes per step, stage by stage ---------------------------------------------------------
-        # primary: 16 B direction + 20 B hit record written per ray (pinhole camera: no origin record), traversal per RAY;
+        # primary: 16 B direction (a miss: 16 B radiance instead) + 20 B hit record written per ray (pinhole camera: no origin record), traversal per RAY;
         # bounce: 32 B ray in + 20 B hit out; shadow: 32 B ray in (the contribution record and the 32 B read-modify-write of an
         # unoccluded ray's radiance at depths >= 1, the 16 B store of an occluded one at depth 0 are not counted: no count of them
         # is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
