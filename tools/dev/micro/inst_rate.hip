@@ -36,6 +36,8 @@ constexpr int ITER = 2048;
 	F(22, "v_med3_f32", "v_med3_f32 %0, %4, %5, %0\n\tv_med3_f32 %1, %4, %5, %1\n\tv_med3_f32 %2, %4, %5, %2\n\tv_med3_f32 %3, %4, %5, %3")            \
 	F(23, "v_fmac_f32", "v_fmac_f32 %0, %4, %5\n\tv_fmac_f32 %1, %4, %5\n\tv_fmac_f32 %2, %4, %5\n\tv_fmac_f32 %3, %4, %5")                            \
 	F(24, "v_fma_f32 (sgpr operand)", "v_fma_f32 %0, %4, s20, %0\n\tv_fma_f32 %1, %4, s20, %1\n\tv_fma_f32 %2, %4, s20, %2\n\tv_fma_f32 %3, %4, s20, %3") \
+	F(29, "v_rcp_f32", "v_rcp_f32 %0, %4\n\tv_rcp_f32 %1, %4\n\tv_rcp_f32 %2, %4\n\tv_rcp_f32 %3, %4") \
+	F(30, "v_sqrt_f32", "v_sqrt_f32 %0, %4\n\tv_sqrt_f32 %1, %4\n\tv_sqrt_f32 %2, %4\n\tv_sqrt_f32 %3, %4") \
 	F(25, "v_mad_mix-free: v_fma_mix_f32 (all f32)", "v_fma_mix_f32 %0, %4, %5, %0\n\tv_fma_mix_f32 %1, %4, %5, %1\n\tv_fma_mix_f32 %2, %4, %5, %2\n\tv_fma_mix_f32 %3, %4, %5, %3")
 
 template <int OP> __global__ __launch_bounds__(256, 8) void k(float *out, uint32_t seed)
@@ -51,6 +53,32 @@ template <int OP> __global__ __launch_bounds__(256, 8) void k(float *out, uint32
 	}
 		OPS(F)
 #undef F
+	}
+	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+// packed fp32 (two lanes' worth of operands per 64-bit register pair)
+template <int OP> __global__ __launch_bounds__(256, 8) void kp(double *out, double seed)
+{
+	double q = seed + threadIdx.x, b = 1.0009765625;
+	double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	for (int i = 0; i < ITER; i++)
+	{
+		if (OP == 0)
+		{
+			R8(asm volatile("v_pk_fma_f32 %0, %4, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\tv_pk_fma_f32 %2, %4, %5, %2\n\tv_pk_fma_f32 %3, %4, %5, %3"
+							: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(q), "v"(b));)
+		}
+		else if (OP == 1)
+		{
+			R8(asm volatile("v_pk_mul_f32 %0, %4, %0\n\tv_pk_mul_f32 %1, %4, %1\n\tv_pk_mul_f32 %2, %4, %2\n\tv_pk_mul_f32 %3, %4, %3"
+							: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(q), "v"(b));)
+		}
+		else
+		{
+			R8(asm volatile("v_pk_add_f32 %0, %4, %0\n\tv_pk_add_f32 %1, %4, %1\n\tv_pk_add_f32 %2, %4, %2\n\tv_pk_add_f32 %3, %4, %3"
+							: "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(q), "v"(b));)
+		}
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
 }
@@ -83,5 +111,30 @@ int main()
 	}
 	OPS(F)
 #undef F
+	{
+		double *outd;
+		if (hipMalloc(&outd, (size_t)blocks * 256 * 8) != hipSuccess)
+			return 1;
+		const char *names[3] = {"v_pk_fma_f32 (two fmas)", "v_pk_mul_f32 (two muls)", "v_pk_add_f32 (two adds)"};
+		for (int op = 0; op < 3; op++)
+			for (int rep = 0; rep < 2; rep++)
+			{
+				(void)hipEventRecord(e0, 0);
+				if (op == 0)
+					hipLaunchKernelGGL(kp<0>, dim3(blocks), dim3(256), 0, 0, outd, 1.5);
+				else if (op == 1)
+					hipLaunchKernelGGL(kp<1>, dim3(blocks), dim3(256), 0, 0, outd, 1.5);
+				else
+					hipLaunchKernelGGL(kp<2>, dim3(blocks), dim3(256), 0, 0, outd, 1.5);
+				(void)hipEventRecord(e1, 0);
+				(void)hipEventSynchronize(e1);
+				float ms = 0;
+				(void)hipEventElapsedTime(&ms, e0, e1);
+				const double insts = (double)blocks * 4 * ITER * 32;
+				if (rep)
+					printf("%-40s %.3f ms  %.2f clocks per instruction per SIMD\n", names[op], ms,
+						   (double)p.multiProcessorCount * 4 * p.clockRate * 1e3 / (insts / (ms * 1e-3)));
+			}
+	}
 	return 0;
 }
