@@ -503,7 +503,7 @@ def main():
                     "valu_issue_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK, 4) if rate else None,
                     "valu_issue_frac_of_4_cycle_rate": round(rate / (VALU_ISSUE_PEAK / 2), 4) if rate else None,
                     "valu_lane_weighted_frac_of_2_cycle_rate": round(rate / VALU_ISSUE_PEAK * lanes / 64.0, 4) if (rate and lanes) else None,
-                    # share of SIMD cycles a VALU instruction occupied, by instruction class: (2 x (FMA + MUL + ADD_F32) + 16 x transcendentals
+                    # share of SIMD cycles a VALU instruction occupied, by instruction class: (2 x (FMA + MUL + ADD_F32) + 8 x transcendentals
                     # + 4 x the rest) / SIMD cycles (profiles/summarize.py; validated on a pure v_fma_f32 kernel: traffic_source.valu_busy_validation)
                     "valu_busy_frac": k.get("valu_busy_frac"), "valu_2_cycle_share": k.get("valu_2_cycle_share"),
                     "valu_transcendental_share": k.get("valu_transcendental_share"),

@@ -95,7 +95,7 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
     out = {"workload": workload, "spp": int(spp), "streams": int(streams), "tag": tag, "csrc_hash": csrc_hash, "kernels": {}}
     # VALU-time model: cycles a wave64 instruction occupies its SIMD by class — v_fma / v_mul / v_add_f32: 2 (what
     # profiles/micro/valu_calib.hip and tools/dev/micro/sdwa_micro.hip measure: 2.3-2.6 nominal clocks per instruction), transcendentals
-    # 16 (quarter rate), everything else — compares, selects, conversions, min / max, integer — 4.  SIMD cycles = GRBM_GUI_ACTIVE
+    # 8 (v_rcp_f32 / v_sqrt_f32: 8.25 clocks, tools/dev/micro/inst_rate.hip; 16 until r04e), everything else — compares, selects, conversions, min / max, integer — 4.  SIMD cycles = GRBM_GUI_ACTIVE
     # (summed over the 8 XCDs) x 32 CUs x 4 SIMDs.  (Round 3's SQ_ACTIVE_INST_VALU x 4 exceeded 1: that counter equals SQ_INSTS_VALU here.)
     def model(t):
         if not (t.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_INSTS_VALU" in t and "SQ_INSTS_VALU_FMA_F32" in t):
@@ -103,7 +103,7 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
         fast = t.get("SQ_INSTS_VALU_FMA_F32", 0.0) + t.get("SQ_INSTS_VALU_MUL_F32", 0.0) + t.get("SQ_INSTS_VALU_ADD_F32", 0.0)
         trans = t.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
         slow = max(0.0, t["SQ_INSTS_VALU"] - fast - trans)
-        return (2.0 * fast + 16.0 * trans + 4.0 * slow) / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), fast / t["SQ_INSTS_VALU"], trans / t["SQ_INSTS_VALU"]
+        return (2.0 * fast + 8.0 * trans + 4.0 * slow) / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), fast / t["SQ_INSTS_VALU"], trans / t["SQ_INSTS_VALU"]
     # validation: the model on a kernel that is nothing but independent v_fma_f32 at 8 waves per SIMD (must read ~1)
     import os
     calib = None
@@ -147,7 +147,7 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
         out["kernels"][k] = e
     out["provenance"] = ("%s: MI355X, separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                          "--no-roofline` (tools/evidence.sh); per dispatch averages; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
-                         "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = (2 x (FMA + MUL + ADD_F32) + 16 x TRANS_F32 + 4 x the other VALU instructions) / "
+                         "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = (2 x (FMA + MUL + ADD_F32) + 8 x TRANS_F32 + 4 x the other VALU instructions) / "
                          "(GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs): the share of SIMD cycles a VALU instruction occupied, by instruction class "
                          "(valu_busy_validation: the same model on a pure v_fma_f32 kernel); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
     print(json.dumps(out, indent=1))

@@ -26,7 +26,7 @@ t=$(pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum | tail -1)
 p=$(pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum | tail -1)
 q=$(pass sq_issue SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY | tail -1)
 l=$(pass sq_lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE | tail -1)
-# VALU instruction classes (for the VALU-time model: FMA / MUL / ADD_F32 occupy a SIMD for 2 cycles, transcendentals 16, the rest 4)
+# VALU instruction classes (for the VALU-time model: FMA / MUL / ADD_F32 occupy a SIMD for 2 cycles, transcendentals 8, the rest 4)
 m=$(pass mix SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU | tail -1)
 # validation of the VALU-time model: a kernel that is nothing but independent v_fma_f32 at 8 waves per SIMD, under the same counters
 (cd $R/profiles/micro && [ -x valu_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value valu_calib.hip -o valu_calib)
