@@ -1165,6 +1165,9 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #ifndef RT_LEAF_VOTE_ANY
 #define RT_LEAF_VOTE_ANY 40
 #endif
+#ifndef RT_REFILL_PIN
+#define RT_REFILL_PIN 1
+#endif
 
 
 
@@ -1389,7 +1392,16 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 					}
 					else
 					{
+#if RT_REFILL_PIN
+						// both records of the ray in ONE round trip: left alone, the compiler fetches the slot word first, tests it
+						// for RAY_VOID and only then asks for the rest — two dependent waits per refill for the whole wave
+						typedef float v4f_ __attribute__((ext_vector_type(4)));
+						v4f_ oa = *(const v4f_ *)(ray_o + idx), da = *(const v4f_ *)(ray_d + idx);
+						asm volatile("" : "+v"(oa), "+v"(da));
+						const f4 o4 = mk4(oa.x, oa.y, oa.z, oa.w), d4 = mk4(da.x, da.y, da.z, da.w);
+#else
 						const f4 o4 = ray_o[idx], d4 = ray_d[idx];
+#endif
 						// void entries (the unfilled rest of a shade wave's last queue block) are skipped
 						if (fbits(o4.w) == RAY_VOID)
 						{

@@ -473,6 +473,65 @@ RT_FN float fast_rcp(float x)
 #endif
 }
 
+// RT_FAST_ID: 1/d of the slab test by v_rcp_f32 (1 ulp) instead of a correctly rounded division (ten instructions, three times
+// per ray and change of space).  1/d only feeds the box tests — which boxes a ray enters, never what it hits there: the
+// triangle test takes o and d — and the boxes carry a margin of 2e-5 plus the outward rounding of their quantisation.
+#ifndef RT_FAST_ID
+#define RT_FAST_ID 1
+#endif
+RT_FN float slab_rcp(float d)
+{
+	const float c = fabsf(d) > 1e-30f ? d : copysignf(1e-30f, d);
+#if RT_FAST_ID
+	return fast_rcp(c);
+#else
+	return 1.0f / c;
+#endif
+}
+
+// RT_NORM_T: the slab test in NORMALISED distances s = t * k with k = (1 - 2^-16) / hit.t (k = 2^-100 while the ray has no hit
+// and no bound): the interval a box must meet, [0, hit.t], becomes [0, 1] — exactly what the `clamp` output modifier of
+// v_max3_f32 / v_min3_f32 clamps to for free.  With near' = clamp(max3(..)), far' = clamp(min3(..)) the reference's three
+// conditions (aabb.cpp:39-77: tmax > tmin && tmin < t, plus tmax >= 0 here) are ONE compare, near' < far': per child
+// max3, min3, one compare, one select instead of max3, min3, three compares, one select (all of them 4-clock instructions).
+// k multiplies 1/d and o/d of the ray (ids, oids), so the node step itself is unchanged; when a closest-hit ray finds a nearer
+// hit the six values are rescaled by hit.t_old / hit.t_new (a handful of instructions, once or twice per ray).  The factor
+// 1 - 2^-16 keeps the far clamp conservative against the rounding of k and of the rescaling: a box is culled by distance only
+// when its entry lies beyond hit.t * (1 + 1.5e-5).  (A box that ENDS exactly at the ray's origin, tmax == 0, was entered before
+// and is not now; nothing in it can be hit: t > t_min = 1e-5.)
+#ifndef RT_NORM_T
+#define RT_NORM_T 1
+#endif
+
+RT_FN float norm_k(float t)
+{
+	// t >= 1e30: "no bound" (the integrators' 1e34): a power of two, so the scaling is exact; k <= 1e3 keeps o/d * k finite
+	// for the shortest shadow rays (their far clamp is then merely looser)
+	const float tt = fmaxf(t, 1e-3f);
+	return t >= 1e30f ? 7.8886090522101181e-31f : 0.99998474f * fast_rcp(tt);
+}
+// max3 / min3 clamped to [0, 1]: one instruction each on the device (output modifier)
+RT_FN float max3_clamp01(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r;
+	asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+#else
+	return fminf(fmaxf(fmaxf(fmaxf(a, b), c), 0.0f), 1.0f);
+#endif
+}
+RT_FN float min3_clamp01(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r;
+	asm("v_min3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+#else
+	return fminf(fmaxf(fminf(fminf(a, b), c), 0.0f), 1.0f);
+#endif
+}
+
 // Slab test (aabb.cpp:39-77) in fma form: t = b * (1/d) - o * (1/d).  a = bmin.xyz, bmax.x ; b = bmax.y, bmax.z, ...
 // The reference accepts tmax > tmin && tmin < t; boxes entirely behind the origin (tmax < 0) cannot contain an
 // accepted hit (t > t_min >= 0) and are culled as well.
@@ -602,9 +661,22 @@ struct Traverser : TraverserWorld<WORLD>
 	RT_FN void enter_space(f3 o_, f3 d_)
 	{
 		o = o_, d = d_;
-		id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+		id = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+#if RT_NORM_T
+		id = id * norm_k(hit.t); // (id, oid hold the NORMALISED 1/d and o/d: see RT_NORM_T)
+#endif
 		oid = o * id;
 		neg_x = id.x < 0.0f, neg_y = id.y < 0.0f, neg_z = id.z < 0.0f;
+	}
+	// RT_NORM_T: the closest hit moved from t_old to hit.t — rescale the normalised 1/d and o/d
+	RT_FN void renormalise(float t_old)
+	{
+#if RT_NORM_T
+		// (the last factor, 1 - 2^-21, outweighs the rounding of the line: however often a ray's hit moves, k only drifts DOWN —
+		// towards a looser far clamp — never past (1 - 2^-16) / hit.t)
+		const float r = norm_k(hit.t) * fast_rcp(norm_k(t_old)) * 0.99999952f;
+		id = id * r, oid = oid * r;
+#endif
 	}
 
 	RT_FN void begin(const SceneView &sc, f3 O_, f3 D_, float t_min_, float t_max)
@@ -631,6 +703,7 @@ struct Traverser : TraverserWorld<WORLD>
 	RT_FN bool parked() const { return (cur & ENTRY_LEAF) && !(RT_SPECULATE && held == ENTRY_DONE && tri_leaf(cur)); }
 
 	static constexpr int LDS_DEPTH = ANY ? LDS_STACK_ANY : LDS_STACK;
+	static constexpr float NODE_INF = 3.0e38f;
 	RT_FN void push(const TravStack stk, uint32_t e)
 	{
 		if (sp < LDS_DEPTH)
@@ -689,7 +762,6 @@ struct Traverser : TraverserWorld<WORLD>
 	// One 4-wide node: fetch its four rows (LDS copy of the top of the tree, or the table), slab-test the four children
 	// (aabb.cpp:39-77 in fma form) and — closest-hit rays — order them by entry distance.  Out: t[k] = entry distance or INF
 	// (a miss, an empty slot = an inverted box), e[k] = the children's stack entries; closest-hit: nearest first.
-	static constexpr float NODE_INF = 3.0e38f;
 	RT_FN void node_step(const SceneView &sc, const TravStack stk, TStat &st, uint32_t entry, float &t0, float &t1, float &t2, float &t3,
 						 uint32_t &e0, uint32_t &e1, uint32_t &e2, uint32_t &e3)
 	{
@@ -723,12 +795,21 @@ struct Traverser : TraverserWorld<WORLD>
 		const uint32_t nyq = neg_y ? hiy : loy, fyq = neg_y ? loy : hiy;
 		const uint32_t nzq = neg_z ? hiz : loz, fzq = neg_z ? loz : hiz;
 		const float INF = NODE_INF;
+#if RT_NORM_T
+#define RT_SLAB4(UB, OUT)                                                                                   \
+	{                                                                                                       \
+		const float tmin = max3_clamp01(fmaf(UB(nxq), Ax, Bx), fmaf(UB(nyq), Ay, By), fmaf(UB(nzq), Az, Bz)); \
+		const float tmax = min3_clamp01(fmaf(UB(fxq), Ax, Bx), fmaf(UB(fyq), Ay, By), fmaf(UB(fzq), Az, Bz)); \
+		OUT = tmax > tmin ? tmin : INF;                                                                     \
+	}
+#else
 #define RT_SLAB4(UB, OUT)                                                                                   \
 	{                                                                                                       \
 		const float tmin = fmaxf(fmaxf(fmaf(UB(nxq), Ax, Bx), fmaf(UB(nyq), Ay, By)), fmaf(UB(nzq), Az, Bz)); \
 		const float tmax = fminf(fminf(fmaf(UB(fxq), Ax, Bx), fmaf(UB(fyq), Ay, By)), fmaf(UB(fzq), Az, Bz)); \
 		OUT = (tmax > tmin && tmin < hit.t && tmax >= 0.0f) ? tmin : INF;                                   \
 	}
+#endif
 		RT_SLAB4(ub0, t0)
 		RT_SLAB4(ub1, t1)
 		RT_SLAB4(ub2, t2)
@@ -861,6 +942,9 @@ struct Traverser : TraverserWorld<WORLD>
 		}
 		const uint32_t first = leaf & ENTRY_FIRST_MASK;
 		const uint32_t count = ((leaf >> 27) & 7u) + 1u;
+#if RT_NORM_T
+		const float t_before = hit.t;
+#endif
 		for (uint32_t i = 0; i < count; i++)
 		{
 			const f4 *tv = sc.tri_verts + 3u * (first + i);
@@ -885,6 +969,10 @@ struct Traverser : TraverserWorld<WORLD>
 				}
 			}
 		}
+#if RT_NORM_T
+		if (!ANY && hit.t != t_before)
+			renormalise(t_before);
+#endif
 		if (!from_held)
 			cur = pop(stk);
 	}
