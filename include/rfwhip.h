@@ -238,17 +238,16 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 3: three chains + the main stream
  *                  are the HIP runtime's four hardware queues; a host that keeps four frames in flight with
  *                  rfwhip_group_present_async sets 4)
- *   refill       = bit mask, default 15: persistent lanes on — bit 0 the extension (bounce) waves, bit 1 the shadow waves,
- *                  bit 2 the pt integrator's primary wave (a lane that finishes its ray pulls the next one from the
- *                  wave's run of the launch's queue; the primary wave generates it); bit 3: the pt primary wave in PACKET
- *                  form — a wave walks the tree once for the rays of its 64 slots (scalar node fetches, one stack per wave;
- *                  used when the samples of a pixel sit side by side, sample_group >= 2, or the launch is large, and only
- *                  for scenes whose trees fit its 61-entry stack; hit records are those of the per-lane kernels)
+ *   refill       = bit mask, default 15: bit 0 the extension (bounce) waves, bit 1 the shadow waves keep persistent lanes (a
+ *                  lane that finishes its ray pulls the next one from the wave's run of the launch's queue; off: the
+ *                  one-ray-per-lane kernels, kept as a cross-check); bit 3: the pt primary wave in PACKET form — a wave walks
+ *                  the tree once for the rays of its 64 slots (scalar node fetches, one stack per wave; used when the samples
+ *                  of a pixel sit side by side, sample_group >= 2, or the launch is large, and only for scenes whose trees fit
+ *                  its 61-entry stack; hit records are those of the per-lane kernels; off: one ray per lane).  Bit 2 selected
+ *                  a persistent-lane primary kernel until round 5 and is ignored
  *   fuse         = "1" (default): the extension rays of depth d + 1 and the shadow rays of depth d share ONE launch (both
  *                  queues are complete when the shade stage of depth d has finished; one kernel tail per depth instead of
  *                  two: 1-spp frames 1.34 -> 1.21 ms); "0": a launch each.  Never changes the image
- *   arm          = "0" (default): a launch chain starts with the one-workgroup kernel that re-arms the call's device counters;
- *                  "1": the pt primary kernel does that itself (measured slower for small frames: DESIGN.md §4)
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

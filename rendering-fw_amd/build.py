@@ -22,7 +22,7 @@ def _stale(out, deps):
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".hpp"))]
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".hpp", ".inc"))]
     d += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
     pdir = os.path.join(CSRC, "plugin")
     if os.path.isdir(pdir):
@@ -37,14 +37,8 @@ def build(force=False, verbose=False):
     outs = []
     core = os.path.join(HERE, "librfwhip.so")
     if force or _stale(core, deps):
-        objs = []
-        for src in CORE_SOURCES:
-            obj = os.path.join(CSRC, src + ".o")
-            cmd = [HIPCC] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj]
-            if src.endswith(".hip"):
-                cmd += ["-x", "hip"] if False else []
-            _run(cmd, verbose)
-            objs.append(obj)
+        objs = [os.path.join(CSRC, src + ".o") for src in CORE_SOURCES]
+        _run_parallel([[HIPCC] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj] for src, obj in zip(CORE_SOURCES, objs)], verbose)
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", core, "-lpthread", "-ldl"], verbose)
     outs.append(core)
     plugin_src = os.path.join(CSRC, "plugin", "HipRT.cpp")
@@ -75,13 +69,19 @@ def build_strict(force=False, verbose=False):
     if not force and not _stale(out, _deps()):
         return out
     os.makedirs(out_dir, exist_ok=True)
-    objs = []
-    for src in CORE_SOURCES:
-        obj = os.path.join(out_dir, src + ".o")
-        _run([HIPCC] + COMMON + ["-DRT_STRICT_MATH", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj], verbose)
-        objs.append(obj)
+    objs = [os.path.join(out_dir, src + ".o") for src in CORE_SOURCES]
+    _run_parallel([[HIPCC] + COMMON + ["-DRT_STRICT_MATH", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
+                   for src, obj in zip(CORE_SOURCES, objs)], verbose)
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-lpthread", "-ldl"], verbose)
     return out
+
+
+def _run_parallel(cmds, verbose):
+    """The translation units of one library side by side (hipcc spends half a minute on each of the two .hip files)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, (os.cpu_count() or 2) // 2))) as pool:
+        for f in [pool.submit(_run, c, verbose) for c in cmds]:
+            f.result()
 
 
 def _run(cmd, verbose):

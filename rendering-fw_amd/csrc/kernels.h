@@ -21,8 +21,6 @@ struct Params
 	uint32_t group;		// chunks per XCD group (one row of tiles for the primary wave)
 	uint32_t refill;	// incoherent waves: lanes that finish a ray pull the next one (persistent lanes)
 	uint32_t textured;	// some material carries a texture / normal map: the shade kernel variant with the texture layers
-	uint32_t arm;		// pt primary wave: bit 0 = re-arm the call's counters on entry (no k_init_counters launch at the head of the
-						// chain), bit 1 = leave its own queue head and clock ready for the next call on exit (kernels.hip: primary_arm_*)
 };
 
 enum GenMode

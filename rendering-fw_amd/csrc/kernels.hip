@@ -1,6 +1,6 @@
 // kernels.hip — the wavefront stages of the HIP rendercore for gfx950 (MI355X, CDNA4).
 //
-//   extend        closest-hit traversal of one wave of rays: k_primary_stream / k_trace_stream<false> keep 64 traversals in
+//   extend        closest-hit traversal of one wave of rays: k_primary_packet walks the tree once per wave; k_trace_stream<false> keeps 64 traversals in
 //                 flight per wave and refill finished lanes themselves (stream_rays); k_extend is the one-ray-per-lane form
 //                 (parity primaries, small pt launches, rfwhip_trace_rays)
 //   shade_parity  EmbreeRT-equivalent direct-lighting integrator (shadow rays traced inline, fixed light order)
@@ -39,7 +39,6 @@ namespace rtk
 {
 
 constexpr int BLOCK = 256;
-constexpr int TEX_RECORD = 7; // rt::TexShade as floats: colour, shading normal, flags
 constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (static_assert in rfwhip_api.cpp)
 // minimum waves per SIMD the register allocator must leave room for in the traversal kernels.  Swept on MI355X with
 // the final kernels: 4 / 5 / 6 / 7 / 8 -> 1863 / 1910 / 1923 / 1864 / 1863 Msamples/s (the 85-register budget of 6 makes
@@ -65,20 +64,6 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4 // the textured shade kernel: 128 registers
 #endif
-// Texture layers of a batch of hits as a pre-pass whose result goes through LDS (shade_tex_prepass_item), so that the registers of
-// the trilinear fetches are free before the BSDF needs its own — round 3's verdict asked for it.  Measured on the MI355X (atrium,
-// 256 spp per step) and OFF: with the pre-pass the kernel does fit 96 registers = 5 waves per SIMD, but it still spills 17 dwords
-// around the BSDF and repeats the surface set-up (shading record, material, normals, tangent frame) in both passes: 2274
-// Msamples/s at 5 waves and 2371 at 4 (shade 27.6 / 23.1 ms per 64-spp sub-batch) against 2498 with the layers fetched inside
-// pt_shade at 4 waves (20.2 ms).  Bit-identical images either way (same functions, same order).
-#ifndef RT_TEX_PREPASS
-#define RT_TEX_PREPASS 0
-#endif
-// packet form of the primary wave (trace_packet): 0 = the nearest entered child first, the others in no particular order (3 of
-// the 5 comparators of the sorting network); 1 = all entered children by distance
-#ifndef RT_PACKET_FULL_SORT
-#define RT_PACKET_FULL_SORT 0
-#endif
 // the shade kernel's waves queue their misses as well as their hits (1), or shade every chunk's misses in place (0).
 // (Two queued misses per lane through a routine of their own — the loads of both in flight together, a miss being four dependent
 // round trips and a few dozen instructions — was built, is bit-identical, and loses: shade alone 8.57 -> 9.05 ms per sub-batch,
@@ -100,8 +85,6 @@ struct Ctx
 {
 	TravStack stk;
 	float *pot = nullptr; // this lane's column of the light-potential cache (shade kernel)
-	volatile uint16_t *tri_map = nullptr; // this WAVE's 64 entries of the triangle phase's pair map (wave_triangle_phase)
-	volatile float *tex = nullptr;		  // this lane's column of the texture pre-pass records (textured shade kernel): tex[k * BLOCK]
 
 	// Block-wise slot allocation of the shade kernel's two output queues (rt_types.h: QUEUE_BLOCK).  Wave-uniform state.
 	struct OutQueue
@@ -151,8 +134,6 @@ struct Ctx
 	uint32_t lds[LDS_STACK_MAX], spill[SPILL_STACK];
 	float potbuf[POT_SLOTS];
 	float *pot;
-	float texbuf[TEX_RECORD];
-	volatile float *tex = texbuf; // (emulation: the pre-pass record of the item in hand, stride 1)
 	uint32_t overflow_sink = 0;
 	Ctx() { stk.lds = lds, stk.spill = spill, pot = potbuf, stk.top = nullptr, stk.top_first = 0, stk.top_count = 0, stk.overflow = &overflow_sink, stk.stride = 1; }
 	explicit Ctx(const Params &p) : Ctx()
@@ -350,39 +331,6 @@ RT_FN void shade_parity_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 	}
 }
 
-// The texture layers of path entry i (a valid entry: a hit of the wave's queue, or a miss, which has none) as a PRE-PASS: only
-// the direction and the hit record are read, the result — colour, shading normal, alpha flag (rt_core.h: TexShade) — goes into
-// the lane's record (LDS on the device).  What the trilinear fetches hold in registers is gone before the BSDF and the light
-// sampling need theirs: the textured shade kernel fits 96 registers = 5 waves per SIMD instead of 128 = 4.
-#if defined(RT_DEVICE_BUILD)
-constexpr int TEX_STRIDE = BLOCK;
-#else
-constexpr int TEX_STRIDE = 1;
-#endif
-template <bool TEX> RT_FN void shade_tex_prepass_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
-{
-	if (!TEX)
-		return;
-	f3 tc = mk3(0, 0, 0), tn = mk3(0, 0, 1);
-	uint32_t tf = 0u;
-	if (active)
-	{
-		const uint32_t b = p.depth & 1u;
-		const f4 d4 = p.wv.dir[b][i];
-		const f4 h4 = (p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i];
-		Hit h;
-		h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = 0;
-		if (h.prim >= 0)
-		{
-			h.inst = (p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst)[i];
-			pt_texture_prepass(p.sc, p.cam, xyz(d4), h, tc, tn, tf);
-		}
-	}
-	ctx.tex[0] = tc.x, ctx.tex[TEX_STRIDE] = tc.y, ctx.tex[2 * TEX_STRIDE] = tc.z;
-	ctx.tex[3 * TEX_STRIDE] = tn.x, ctx.tex[4 * TEX_STRIDE] = tn.y, ctx.tex[5 * TEX_STRIDE] = tn.z;
-	ctx.tex[6 * TEX_STRIDE] = ubits(tf);
-}
-
 #if defined(RT_DIAG_SHADE_CLOCK)
 __device__ unsigned long long g_shade_clk[32];
 #define RT_ITEM_CLK , ClkProbe *clk
@@ -442,21 +390,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 				WaveCounters *c = p.wv.counters;
 				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
 			}
-			if (TEX && RT_TEX_PREPASS)
-			{
-				// the texture layers ran as a pre-pass of this batch (shade_tex_prepass_item; the device kernel calls it for the whole
-				// wave before this function, the emulation right here): their result comes back from the lane's record
-#if !defined(RT_DEVICE_BUILD)
-				shade_tex_prepass_item<TEX>(p, i, true, ctx);
-#endif
-				TexShade tx;
-				tx.color = mk3(ctx.tex[0], ctx.tex[TEX_STRIDE], ctx.tex[2 * TEX_STRIDE]);
-				tx.iN = mk3(ctx.tex[3 * TEX_STRIDE], ctx.tex[4 * TEX_STRIDE], ctx.tex[5 * TEX_STRIDE]);
-				tx.flags = fbits(ctx.tex[6 * TEX_STRIDE]);
-				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, &tx RT_CLK_ARG);
-			}
-			else
-				pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot, nullptr RT_CLK_ARG);
+			pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot RT_CLK_ARG);
 			write_rad = true;
 		}
 	}
@@ -674,52 +608,7 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t 
 	for (uint32_t q = t; q < (uint32_t)WORK_QUEUES * 8u; q += nt)
 		work[q] = 0u;
 	if (t == 0u)
-		c->probe_valid = 0u, c->stack_overflow = 0u, c->primary_exit = 0u;
-}
-
-// The pt primary wave can re-arm the counters of its call ITSELF (Params::arm, setting `arm`; measured and OFF by default, see
-// rfwhip_api.cpp), so that a launch chain does not begin with a one-workgroup kernel that — small as it is — waits for a slot
-// among the persistent grids of the chains in flight (1.07 ms on average in round 3's concurrent trace, at the head of every chain):
-//   primary_arm_begin  workgroup 0, on entry: everything the LATER stages of this call read or add to — ext / shadow counts, the
-//                      queue heads of the later launches, probe and overflow flags, the clocks of the deeper extend launches —
-//                      nothing the primary wave itself touches, so no other workgroup needs to wait for it;
-//   primary_arm_end    the LAST workgroup to leave (one atomic per workgroup): what the primary wave itself used — its queue
-//                      head(s), its clock — ready for the next call on this set of counters.
-// The host launches k_init_counters only for a set that is not in this state (first use, after a parity frame or rfwhip_trace_rays).
-RT_FN void primary_arm_begin_item(WaveCounters *c, uint32_t primary_count, uint32_t own_queue, uint32_t t, uint32_t nt)
-{
-	for (uint32_t d = t; d < (uint32_t)MAX_DEPTH_SLOTS; d += nt)
-	{
-		c->ext[d] = c->ext_n[d] = d == 0u ? primary_count : 0u, c->shadow[d] = c->shadow_n[d] = 0u;
-		if (d != 0u)
-		{
-			if (c->t_last[d] > c->t_first[d]) // fold the previous call's extend-stage clock
-			{
-#if defined(__HIP_DEVICE_COMPILE__)
-				atomicAdd(&c->ext_ticks, c->t_last[d] - c->t_first[d]);
-				atomicAdd(&c->ext_timed, 1u);
-#else
-				c->ext_ticks += c->t_last[d] - c->t_first[d], c->ext_timed++;
-#endif
-			}
-			c->t_first[d] = ~0ull, c->t_last[d] = 0ull;
-		}
-	}
-	uint32_t *const work = &c->work[0][0];
-	for (uint32_t q = t; q < (uint32_t)WORK_QUEUES * 8u; q += nt)
-		if (q / 8u != own_queue)
-			work[q] = 0u;
-	if (t == 0u)
 		c->probe_valid = 0u, c->stack_overflow = 0u;
-}
-RT_FN void primary_arm_end_item(WaveCounters *c, uint32_t own_queue)
-{
-	if (c->t_last[0] > c->t_first[0])
-		c->ext_ticks += c->t_last[0] - c->t_first[0], c->ext_timed++;
-	c->t_first[0] = ~0ull, c->t_last[0] = 0ull;
-	for (uint32_t x = 0; x < 8u; x++)
-		c->work[own_queue][x] = 0u;
-	c->primary_exit = 0u;
 }
 
 // One pixel: its samples in sample order whatever the slot layout (rt_core.h: sample groups) — the image is independent of
@@ -1011,20 +900,11 @@ struct ChunkQueue
 #define RT_TRACE_BLOCK 256
 #endif
 constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
-#if RT_WAVE_TRIS
-#define RT_TRIMAP_DECL(NTHREADS) __shared__ uint16_t s_trimap[(NTHREADS)];
-#define RT_TRIMAP_SET ctx.tri_map = s_trimap + (threadIdx.x & ~63u);
-#else
-#define RT_TRIMAP_DECL(NTHREADS)
-#define RT_TRIMAP_SET
-#endif
 #define RT_STACK_DECL_N(DEPTH, NTHREADS)                                                     \
 	__shared__ uint32_t s_stack[(DEPTH) * (NTHREADS)];                                      \
 	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];                                          \
-	RT_TRIMAP_DECL(NTHREADS)                                                                \
 	uint32_t spill_[SPILL_STACK];                                                           \
 	Ctx ctx;                                                                                \
-	RT_TRIMAP_SET                                                                           \
 	ctx.stk.lds = s_stack + threadIdx.x;                                                    \
 	ctx.stk.stride = (NTHREADS);                                                            \
 	ctx.stk.spill = spill_;                                                                 \
@@ -1062,41 +942,9 @@ __device__ __forceinline__ void clock_out(WaveCounters *wc, uint32_t depth)
 		atomicMax(&wc->t_last[depth], (unsigned long long)wall_clock64());
 }
 
-// Params::arm (pt primary kernels): see primary_arm_begin_item
-__device__ __forceinline__ void primary_arm_begin(const Params &p, uint32_t primary_count)
-{
-	if ((p.arm & 1u) && blockIdx.x == 0)
-		primary_arm_begin_item(p.wv.counters, primary_count, p.queue, threadIdx.x, blockDim.x);
-}
-__device__ __forceinline__ void primary_arm_end(const Params &p)
-{
-	if (!(p.arm & 2u))
-		return;
-	__syncthreads(); // (every wave of this workgroup is done with the queue)
-	if (threadIdx.x == 0)
-	{
-		WaveCounters *const wc = p.wv.counters;
-		__threadfence();
-		if (atomicAdd(&wc->primary_exit, 1u) == gridDim.x - 1u)
-		{
-			// the last workgroup out: every other one has made its clock_out and its last queue access before its increment
-			__threadfence();
-			const unsigned long long t1 = atomicMax(&wc->t_last[0], 0ull), t0 = atomicMin(&wc->t_first[0], ~0ull);
-			if (t1 > t0)
-				atomicAdd(&wc->ext_ticks, t1 - t0), atomicAdd(&wc->ext_timed, 1u);
-			atomicExch(&wc->t_first[0], ~0ull), atomicExch(&wc->t_last[0], 0ull);
-			for (uint32_t x = 0; x < 8u; x++)
-				atomicExch(&wc->work[p.queue][x], 0u);
-			atomicExch(&wc->primary_exit, 0u);
-		}
-	}
-}
-
 template <int GEN, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params p, const uint32_t fixed_count)
 {
-	if (GEN == GEN_PT)
-		primary_arm_begin(p, fixed_count);
 	clock_in(p.wv.counters, p.depth);
 	RT_STACK_DECL_CLOSEST
 	const uint32_t count = (GEN == GEN_BUFFER || GEN == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : fixed_count;
@@ -1109,8 +957,6 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 			extend_item<GEN, COUNT>(p, i, i < count, ctx);
 	}
 	clock_out(p.wv.counters, p.depth);
-	if (GEN == GEN_PT)
-		primary_arm_end(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1140,27 +986,14 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #ifndef RT_LEAF_VOTE_EXT
 #define RT_LEAF_VOTE_EXT 40 // (of 64: the share of the wave's lanes WITH a ray that must hold a leaf, rt_core.h RT_VOTE_RELATIVE)
 #endif
-#ifndef RT_LEAF_VOTE_PRIMARY
-#define RT_LEAF_VOTE_PRIMARY 32
-#endif
-#ifndef RT_REFILL_IDLE_PRIMARY
-#define RT_REFILL_IDLE_PRIMARY 40 // (24 / 32 / 40: 2548 / 2548 / 2554 Msamples/s; the one-ray-per-lane primary kernel: 2494)
-#endif
-// the primary wave takes the persistent-lane form only when the launch is large (1080p: >= 8 spp per sub-batch): measured on
-// the MI355X, 32 spp per launch 6.68 -> 6.05 ms, 1 spp per launch 0.42 -> 0.61 ms (a wave then sees only ~4 tiles, and the
-// tile-row-to-XCD dealing of the one-ray-per-lane kernel is worth more than the refills)
-#ifndef RT_PRIMARY_STREAM_MIN
-#define RT_PRIMARY_STREAM_MIN (16u << 20)
-#endif
-#ifndef RT_PRIMARY_STREAM_WAVES
-#define RT_PRIMARY_STREAM_WAVES 7
+// a single-sample primary launch (sample groups of 1: a wave is an 8x8 tile of different pixels) takes the packet form only when
+// it is large; small ones keep the one-ray-per-lane kernel with its tile-row-to-XCD dealing (launch_extend)
+#ifndef RT_PRIMARY_PACKET_MIN
+#define RT_PRIMARY_PACKET_MIN (16u << 20)
 #endif
 // rays a wave takes from the launch's queue per atomic (0: one atomic per refill, exactly the idle lanes)
 #ifndef RT_STREAM_CHUNK
 #define RT_STREAM_CHUNK 512
-#endif
-#ifndef RT_STREAM_CHUNK_QUEUED // the same for the kernels that read their rays from a queue (extension, shadow)
-#define RT_STREAM_CHUNK_QUEUED RT_STREAM_CHUNK
 #endif
 #ifndef RT_LEAF_VOTE_ANY
 #define RT_LEAF_VOTE_ANY 40
@@ -1172,124 +1005,13 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 
 
 
-// ----------------------------------------------------------------------------------------------------------------
-// Wave-wide triangle phase of the persistent-lane kernels (RT_WAVE_TRIS).  In the while-while traversal a wave leaves the node
-// phase with some of its lanes holding a triangle leaf (1..4 triangles each) and Traverser::visit() lets every such lane test
-// its own: the loop runs as long as the longest leaf, with the lanes of shorter leaves, of instance switches and of unfinished
-// descents idle — 12 (bounce) to 19 (shadow) of 64 lanes on the incoherent waves, in what is a third of their instructions.
-// Here the wave pools the work: the (lane, triangle) pairs of all leaves in hand are numbered by a prefix sum over the leaf
-// sizes (four ballots of the size's bits + mbcnt), pair j goes to lane j — the OWNER's ray (origin, direction, current hit
-// distance) and leaf come across the wave with ds_bpermute_b32, the triangle's three vertices from memory as before — and the
-// results go back the same way: the owner takes the nearest accepted hit of its segment of lanes, the earliest on a tie. That
-// is exactly what its own loop would have produced (it accepts a triangle when t_min < t < the nearest so far; the minimum
-// over those accepted against the distance at the start of the leaf is the same triangle), so hit records are bit-identical.
-// A phase is ONE round: the owners whose pairs fit into 64 lanes; the others keep their leaf for the next phase.  Only a
-// 128-byte lane map per wave lives in LDS (pair -> owner lane and triangle number).
-// ----------------------------------------------------------------------------------------------------------------
-// Measured on the MI355X (terrain_1002k, 256 spp per step) and OFF: bit-identical images and wave counts (tools/dev/packet_probe.py
-// compares against the one-ray-per-lane kernels), but the bounce wave takes 6.80 instead of 6.37 ms and the shadow wave 8.79 instead
-// of 8.04 ms per 64-spp sub-batch, 4070 against 4236 Msamples/s (vote thresholds 16 / 24 / 32 / 40: 3997 / 4067 / 4090 / 4070; a
-// second round for the overflow of a phase instead of carrying it over: 4101 against 4213).  What the pooling saves — leaves hold
-// 1..4 triangles, so a lane's own loop runs three to four iterations at 12-19 lanes — it spends again on getting the work to the
-// lanes and back: four ballots and eight mbcnt for the prefix sum, the scatter of the pair map and its read-back through LDS,
-// eight ds_bpermute_b32 for the foreign ray and five per accepted hit for the way back, each a dependent LDS round trip in
-// front of the vertex fetch that the lane's own loop issues straight away.
-#ifndef RT_WAVE_TRIS
-#define RT_WAVE_TRIS 0
-#endif
-__device__ __forceinline__ float wave_fetch(uint32_t src_lane_x4, float v)
-{
-	return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)src_lane_x4, __builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ uint32_t wave_fetch(uint32_t src_lane_x4, uint32_t v)
-{
-	return (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane_x4, (int)v);
-}
-template <bool ANY, bool COUNT, bool WORLD>
-__device__ __forceinline__ void wave_triangle_phase(Traverser<ANY, COUNT, WORLD> &T, const SceneView &sc, const bool has_ray, volatile uint16_t *map,
-													const TravStack stk, TStat &st)
-{
-	static_assert(!RT_SPECULATE, "the wave-wide triangle phase has no held leaves");
-	const uint32_t lane = __lane_id();
-	const bool pending = has_ray && Traverser<ANY, COUNT, WORLD>::tri_leaf(T.cur);
-	if (__ballot(pending) == 0ull)
-		return;
-	// ONE round per phase: the owners whose pairs fit into 64 lanes are served, the others keep their leaf in hand and are
-	// first in line — by then with the leaves the next node steps bring — in the next phase: every round runs nearly full
-	// (a second round for the overflow of this one would run with a handful of lanes)
-	{
-		const uint32_t first = T.cur & ENTRY_FIRST_MASK;
-		const uint32_t cnt = pending ? ((T.cur >> 27) & 7u) + 1u : 0u; // 1..8
-		// exclusive prefix sum of the leaf sizes over the lanes
-		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u),
-								 b3 = __ballot((cnt & 8u) != 0u);
-		const uint32_t prefix = wave_prefix(b0) + 2u * wave_prefix(b1) + 4u * wave_prefix(b2) + 8u * wave_prefix(b3);
-		const bool in_round = pending && prefix + cnt <= 64u; // (prefixes grow with the lane: the owners of a round are a lane prefix)
-		// pair -> (owner lane, triangle number of the leaf); 0xFFFF: no pair for this lane
-		map[lane] = (uint16_t)0xFFFFu;
-		__builtin_amdgcn_wave_barrier();
-		if (in_round)
-			for (uint32_t k = 0; k < cnt; k++)
-				map[prefix + k] = (uint16_t)(lane | (k << 8));
-		__builtin_amdgcn_wave_barrier();
-		const uint32_t e = map[lane];
-		const bool valid = e != 0xFFFFu;
-		const uint32_t owner4 = (e & 63u) << 2, k = (e >> 8) & 7u;
-		// the owner's ray and leaf (every lane executes the fetches: a disabled lane cannot be read from)
-		const f3 fo = mk3(wave_fetch(owner4, T.o.x), wave_fetch(owner4, T.o.y), wave_fetch(owner4, T.o.z));
-		const f3 fd = mk3(wave_fetch(owner4, T.d.x), wave_fetch(owner4, T.d.y), wave_fetch(owner4, T.d.z));
-		float ft = wave_fetch(owner4, T.hit.t);
-		const uint32_t fprim = ANY ? 0u : wave_fetch(owner4, (uint32_t)T.hit.prim);
-		const uint32_t ffirst = wave_fetch(owner4, first);
-		float ru = 0.0f, rv = 0.0f;
-		uint32_t rprim = 0u, rinst = 0u;
-		bool rhit = false;
-		if (valid)
-		{
-			const f4 *tv = sc.tri_verts + 3u * (ffirst + k);
-			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-			rprim = fbits(v0.w), rinst = fbits(v1.w);
-			rhit = tri_test<!ANY>(fo, fd, T.t_min, ft, xyz(v0), xyz(v1), xyz(v2), ru, rv, rprim, fprim);
-		}
-		if (COUNT)
-			st.tris += in_round ? cnt : 0u;
-		// back to the owners: the accepted hits of an owner's segment of lanes [prefix, prefix + cnt)
-		const unsigned long long hm = __ballot(rhit);
-		uint32_t seg = in_round ? (uint32_t)(hm >> prefix) & ((1u << cnt) - 1u) : 0u;
-		if (ANY)
-		{
-			if (seg)
-				T.hit.prim = 0, T.cur = ENTRY_DONE; // occluded: which triangle does not matter
-		}
-		else
-		{
-			// (iterations = the largest number of accepted hits in one segment: mostly one)
-			while (__ballot(seg != 0u) != 0ull)
-			{
-				const uint32_t kk = seg ? (uint32_t)__ffs((int)seg) - 1u : 0u;
-				const uint32_t src4 = ((prefix + kk) & 63u) << 2;
-				const float t2 = wave_fetch(src4, ft), u2 = wave_fetch(src4, ru), v2 = wave_fetch(src4, rv);
-				const uint32_t p2 = wave_fetch(src4, rprim), i2 = wave_fetch(src4, rinst);
-				if (seg && (t2 < T.hit.t || (t2 == T.hit.t && p2 < (uint32_t)T.hit.prim))) // (tri_test's total order on (t, prim))
-				{
-					T.hit.t = t2, T.hit.u = u2, T.hit.v = v2, T.hit.prim = (int)p2;
-					T.hit.inst = T.cur_inst >= 0 ? T.cur_inst : (int)i2;
-				}
-				seg &= seg - 1u;
-			}
-		}
-		if (in_round && !(ANY && T.cur == ENTRY_DONE))
-			T.cur = T.pop(stk);
-	}
-}
-
-// MODE: where a lane's next ray comes from — the extension-ray buffers of this depth, the shadow-ray buffers, or the
-// pt integrator's primary-ray generator (item = path slot; the ray is also stored for the shade kernel)
+// MODE: where a lane's next ray comes from — the extension-ray buffers of this depth or the shadow-ray buffers.  (The pt
+// integrator's primary wave had a persistent-lane form of its own, k_primary_stream, until the packet form of round 4 replaced
+// it; round 5 took it out of the sources: DESIGN_LOG.md, "variants removed".)
 enum
 {
 	STREAM_EXT = 0,
-	STREAM_ANY = 1,
-	STREAM_PRIMARY_PT = 2
+	STREAM_ANY = 1
 };
 
 // RT_DIAG_TRACE_CLOCK (development builds): a traversal wave's cycles by phase of its loop — refill, node phase, leaf phase,
@@ -1317,9 +1039,9 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
 	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
 	// (the queue-fed waves re-read a ray's record on the rare instance switch instead of keeping the world-space ray)
-	constexpr bool WORLD = MODE == STREAM_PRIMARY_PT;
+	constexpr bool WORLD = false;
 	Traverser<ANY, COUNT, WORLD> T;
-	T.cur = ENTRY_DONE, T.held = ENTRY_DONE;
+	T.cur = ENTRY_DONE;
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
 	uint32_t nrays = 0;
@@ -1330,18 +1052,17 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	uint32_t q_next = 0, q_end = 0; // wave-uniform: the rest of the run this wave owns
 	// run length: RT_STREAM_CHUNK for big launches, down to 64 when the launch has fewer than ~4 runs per wave
 	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
-	constexpr uint32_t RUN_MAX = MODE == STREAM_PRIMARY_PT ? (uint32_t)RT_STREAM_CHUNK : (uint32_t)RT_STREAM_CHUNK_QUEUED;
+	constexpr uint32_t RUN_MAX = (uint32_t)RT_STREAM_CHUNK;
 	run = run > RUN_MAX ? RUN_MAX : (run < 64u ? 64u : run);
 #endif
-	uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : (MODE == STREAM_EXT ? RT_REFILL_IDLE_EXT : RT_REFILL_IDLE_PRIMARY);
+	uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE_EXT;
 	// Waves of near-identical rays — the slot layout's sample groups put >= 8 samples of a pixel side by side (rt_core.h), so a
-	// wave of primary rays, or of the shadow rays their first vertices emit, walks the same nodes in step — are refilled only
-	// as a whole: a partial refill mixes rays at different stages into the wave and the two phases of the traversal fall out
-	// of step again (MI355X, 32 samples per group: primary wave 4.88 -> 4.32 ms, depth-0 shadow wave 6.40 -> 5.63 ms per
-	// 32-spp launch; the vote threshold stays: 48 / 64 lose 2-7 %)
-	if ((MODE == STREAM_PRIMARY_PT || (MODE == STREAM_ANY && p.depth == 0)) && p.fr.sgroup_log2 >= 3u)
+	// wave of the shadow rays the first vertices emit walks the same nodes in step — are refilled only as a whole: a partial
+	// refill mixes rays at different stages into the wave and the two phases of the traversal fall out of step again (MI355X,
+	// 32 samples per group: depth-0 shadow wave 6.40 -> 5.63 ms per 32-spp launch; the vote threshold stays: 48 / 64 lose 2-7 %)
+	if (MODE == STREAM_ANY && p.depth == 0 && p.fr.sgroup_log2 >= 3u)
 		REFILL = 64u;
-	constexpr int VOTE = MODE == STREAM_ANY ? RT_LEAF_VOTE_ANY : (MODE == STREAM_EXT ? RT_LEAF_VOTE_EXT : RT_LEAF_VOTE_PRIMARY);
+	constexpr int VOTE = MODE == STREAM_ANY ? RT_LEAF_VOTE_ANY : RT_LEAF_VOTE_EXT;
 	for (;;)
 	{
 		const unsigned long long idle_mask = __ballot(!has_ray);
@@ -1376,21 +1097,6 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 				const uint32_t idx = base + wave_prefix(idle_mask);
 				if (idx < limit)
 				{
-					if (MODE == STREAM_PRIMARY_PT)
-					{
-						const PixelRef pr = slot_to_pixel(p.fr, idx);
-						if (pr.valid)
-						{
-							f3 O, D;
-							pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
-							if (p.cam.aperture != 0.0f) // (pinhole: no origin record, extend_item)
-								p.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
-							p.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
-							T.begin(p.sc, O, D, 1e-5f, 1e34f);
-							has_ray = true, ray = idx, nrays++;
-						}
-					}
-					else
 					{
 #if RT_REFILL_PIN
 						// both records of the ray in ONE round trip: left alone, the compiler fetches the slot word first, tests it
@@ -1433,26 +1139,11 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 		T.template descend<VOTE>(p.sc, ctx.stk, st);
 		RT_TRACE_TICK(1)
 		const auto world = [&](f3 &O, f3 &D) {
-			if constexpr (WORLD)
-				O = T.O, D = T.D;
-			else
-			{
-				const f4 o4 = ray_o[ray], d4 = ray_d[ray];
-				O = xyz(o4), D = xyz(d4);
-			}
+			const f4 o4 = ray_o[ray], d4 = ray_d[ray];
+			O = xyz(o4), D = xyz(d4);
 		};
-#if RT_WAVE_TRIS
-		// instance switches stay with their lanes; the triangle leaves in hand are tested by the wave as a whole
-		if (has_ray && !Traverser<ANY, COUNT, WORLD>::tri_leaf(T.cur))
-			T.visit(p.sc, ctx.stk, st, world);
-		wave_triangle_phase(T, p.sc, has_ray, ctx.tri_map, ctx.stk, st);
-#endif
 		if (has_ray)
-		{
-#if !RT_WAVE_TRIS
 			T.visit(p.sc, ctx.stk, st, world);
-#endif
-		}
 		RT_TRACE_TICK(2)
 		if (has_ray)
 		{
@@ -1462,10 +1153,8 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 					connect_finish(p, ray, slot, T.hit.prim < 0);
 				else
 				{
-					f4 *const hb = MODE == STREAM_PRIMARY_PT ? p.wv.hit0 : p.wv.hit;
-					int *const ib = MODE == STREAM_PRIMARY_PT ? p.wv.hit0_inst : p.wv.hit_inst;
-					hb[ray] = mk4(T.hit.t, T.hit.u, T.hit.v, ubits((uint32_t)T.hit.prim));
-					ib[ray] = T.hit.inst;
+					p.wv.hit[ray] = mk4(T.hit.t, T.hit.u, T.hit.v, ubits((uint32_t)T.hit.prim));
+					p.wv.hit_inst[ray] = T.hit.inst;
 				}
 				has_ray = false;
 			}
@@ -1475,8 +1164,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 #if defined(RT_DIAG_TRACE_CLOCK)
 	if (lane == 0u)
 		for (int k = 0; k < 4; k++)
-			atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : (MODE == STREAM_EXT ? 0 : 2)][k], clk_acc[k]),
-				atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : (MODE == STREAM_EXT ? 0 : 2)][4 + k], clk_n[k]);
+			atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : 0][k], clk_acc[k]), atomicAdd(&g_trace_clk[MODE == STREAM_ANY ? 1 : 0][4 + k], clk_n[k]);
 #endif
 	if (COUNT)
 	{
@@ -1530,18 +1218,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) __attribute__((am
 	clock_out(pe.wv.counters, pe.depth);
 	if (count_a)
 		stream_rays<STREAM_ANY, COUNT>(pa, count_a, ctx);
-}
-
-// the pt integrator's primary wave in the same persistent-lane form: a lane generates its next primary ray itself
-template <bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK, RT_PRIMARY_STREAM_WAVES) k_primary_stream(const Params p, const uint32_t count)
-{
-	primary_arm_begin(p, count);
-	clock_in(p.wv.counters, 0);
-	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
-	stream_rays<STREAM_PRIMARY_PT, COUNT>(p, count, ctx);
-	clock_out(p.wv.counters, 0);
-	primary_arm_end(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1766,12 +1442,9 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			RT_PSWAP(k0, e0, k1, e1)
 			RT_PSWAP(k2, e2, k3, e3)
 			RT_PSWAP(k0, e0, k2, e2)
-#if RT_PACKET_FULL_SORT
-			RT_PSWAP(k1, e1, k3, e3)
-			RT_PSWAP(k1, e1, k2, e2)
-#endif
 #undef RT_PSWAP
-			// far children first (full sort), so the nearest of them is popped first; the pop below reads what was just written
+			// (three of the five comparators: the nearest entered child first, the others in no particular order — all five measure
+			// the same, 5.18 against 4.93 ms per primary wave.)  The pop below reads what was just written
 			// (1 when the key is not all ones, as integer arithmetic)
 			stk.push3(e3, packet_flag(k3), e2, packet_flag(k2), e1, packet_flag(k1));
 			if (k0 == 0xFFFFFFFFu)
@@ -1842,7 +1515,6 @@ __device__ __forceinline__ const Params &fresh_params()
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet(const Params p, const uint32_t count)
 {
-	primary_arm_begin(p, count);
 	clock_in(p.wv.counters, 0);
 	uint32_t *const head = &p.wv.counters->work[p.queue][0];
 	const uint32_t lane = __lane_id();
@@ -1898,7 +1570,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 		ctx.add64(&wc->rays_extend, nrays);
 	}
 	clock_out(p.wv.counters, 0);
-	primary_arm_end(p);
 }
 
 template <bool COUNT>
@@ -1923,8 +1594,6 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ctx.stk.lds = nullptr, ctx.stk.spill = nullptr, ctx.stk.top = nullptr, ctx.stk.top_first = 0, ctx.stk.top_count = 0;
 	ctx.stk.overflow = nullptr, ctx.stk.stride = 0;
 	ctx.pot = s_pot + threadIdx.x;
-	__shared__ float s_tex[TEX ? TEX_RECORD * BLOCK : 1];
-	ctx.tex = s_tex + (TEX ? threadIdx.x : 0);
 	const uint32_t count = p.wv.counters->ext_n[p.depth];
 	// Hits and misses cost two orders of magnitude apart (sky lookup vs. BSDF + light sampling) and are mixed lane by lane
 	// on the bounce waves.  Every WAVE keeps its own queues of hit paths and of misses in LDS: it walks 64-path chunks and appends
@@ -2010,11 +1679,6 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		else
 			break;
 		__builtin_amdgcn_wave_barrier();
-		if (TEX && RT_TEX_PREPASS)
-		{
-			shade_tex_prepass_item<TEX>(p, idx, act, ctx);
-			__builtin_amdgcn_wave_barrier();
-		}
 #if defined(RT_DIAG_SHADE_CLOCK)
 		shade_pt_item<TEX>(p, idx, act, ctx, &clk);
 #else
@@ -2283,7 +1947,7 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 		else
 			RT_EXT(GEN_RANGED, false);
 	}
-	else if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= RT_PRIMARY_STREAM_MIN))
+	else if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= RT_PRIMARY_PACKET_MIN))
 	{
 		// packet form of the primary wave: no LDS, one wave = one 64-slot group at a time.  MI355X, 1080p terrain, 64 spp per
 		// launch, primary wave per-lane / packet by sample-group size: 1: 9.33 / 9.07 ms, 4: 9.08 / 6.60, 8: 8.87 / 6.39, 16: 8.79 /
@@ -2295,14 +1959,6 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 			hipLaunchKernelGGL((k_primary_packet<true>), gt, bt, 0, st, p, max_items);
 		else
 			hipLaunchKernelGGL((k_primary_packet<false>), gt, bt, 0, st, p, max_items);
-	}
-	else if (gen == GEN_PT && (p.refill & 4u) && max_items >= RT_PRIMARY_STREAM_MIN)
-	{
-		const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
-		if (count)
-			hipLaunchKernelGGL((k_primary_stream<true>), gt, bt, 0, st, p, max_items);
-		else
-			hipLaunchKernelGGL((k_primary_stream<false>), gt, bt, 0, st, p, max_items);
 	}
 	else if (gen == GEN_PT)
 	{
@@ -2485,407 +2141,8 @@ void launch_refit(Node *nodes, uint32_t node_base, const int *parents, uint32_t 
 }
 
 // ================================================================================================================
-#else // RFWHIP_HOST_EMULATION: the same work items driven by plain loops (tests/emu only — never shipped)
-// ================================================================================================================
-
-void set_device_cus(int) {}
-uint32_t max_lds_nodes() { return MAX_LDS_NODES; }
-void launch_init_counters(WaveCounters *c, uint32_t primary_count, stream_t) { init_counters_item(c, primary_count, 0u, 1u); }
-void launch_set_ext_count(WaveCounters *c, uint32_t depth, uint32_t count, stream_t) { c->ext[depth] = c->ext_n[depth] = count; }
-
-void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
-					   uint32_t packets_per_sample, uint32_t spp, stream_t)
-{
-	const uint32_t total = packets_per_sample * spp;
-	for (uint32_t r = 0; r < (total + RNG_RUN - 1) / RNG_RUN; r++)
-		rng_states_item(states, base_state, jump_table, total, r);
-}
-
-// ---- the packet form of the pt primary wave (device: trace_packet / k_primary_packet), one wave = 64 array entries ---------------
-// The same steps in the same order with the same arithmetic — ballots are loops, v_readlane / v_writelane are array accesses —
-// so that the CPU tier checks the algorithm (stack discipline, partial child order, mixed direction signs, instances) against
-// the per-lane traversal and the oracle.
-namespace packet_emu
-{
-constexpr int WAVE = 64;
-struct Space
-{
-	f3 o[WAVE], d[WAVE], id[WAVE], noid[WAVE];
-	uint32_t off_n[3], off_f[3];
-	bool mixed;
-	void enter(const f3 *o_, const f3 *d_, unsigned long long act)
-	{
-		unsigned long long mx = 0, my = 0, mz = 0;
-		for (int l = 0; l < WAVE; l++)
-		{
-			o[l] = o_[l], d[l] = d_[l];
-			id[l] = mk3(safe_rcp(d[l].x), safe_rcp(d[l].y), safe_rcp(d[l].z));
-			noid[l] = mk3(-(o[l].x * id[l].x), -(o[l].y * id[l].y), -(o[l].z * id[l].z));
-			mx |= (unsigned long long)(id[l].x < 0.0f) << l, my |= (unsigned long long)(id[l].y < 0.0f) << l, mz |= (unsigned long long)(id[l].z < 0.0f) << l;
-		}
-		mx &= act, my &= act, mz &= act;
-		mixed = (mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act);
-		off_n[0] = mx ? 48u : 0u, off_f[0] = mx ? 0u : 48u;
-		off_n[1] = my ? 64u : 16u, off_f[1] = my ? 16u : 64u;
-		off_n[2] = mz ? 80u : 32u, off_f[2] = mz ? 32u : 80u;
-	}
-};
-struct Stack
-{
-	uint32_t s0[WAVE];
-	uint32_t sp = 1u;
-	Stack()
-	{
-		for (int l = 0; l < WAVE; l++)
-			s0[l] = 0u;
-		s0[0] = ENTRY_DONE;
-	}
-	void push(uint32_t e) { s0[sp++ & 63u] = e; }
-	uint32_t pop() { return s0[--sp & 63u]; }
-	void push3(uint32_t ea, uint32_t na, uint32_t eb, uint32_t nb, uint32_t ec, uint32_t nc)
-	{
-		s0[sp & 63u] = ea, s0[(sp + na) & 63u] = eb, s0[(sp + na + nb) & 63u] = ec;
-		sp += na + nb + nc;
-	}
-};
-template <bool COUNT> void trace(const SceneView &sc, const bool *active, const f3 *O, const f3 *D, float t_min, Hit *hit, TStat &st)
-{
-	unsigned long long act = 0;
-	for (int l = 0; l < WAVE; l++)
-	{
-		act |= (unsigned long long)active[l] << l;
-		hit[l].t = active[l] ? hit[l].t : -3.0e38f;
-	}
-	if (act == 0ull)
-		return;
-	int ref_lane = 0;
-	while (!((act >> ref_lane) & 1ull))
-		ref_lane++;
-	uint32_t nact = 0;
-	for (int l = 0; l < WAVE; l++)
-		nact += active[l] ? 1u : 0u;
-	static thread_local Space sp;
-	sp.enter(O, D, act);
-	Stack stk;
-	int cur_inst = -1;
-	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
-	if (COUNT && cur != ENTRY_DONE)
-	{
-		if (!(cur & ENTRY_LEAF))
-			st.inner += nact;
-		else if (!(cur & ENTRY_TLAS))
-			st.tris += nact * (((cur >> 27) & 7u) + 1u);
-	}
-	const char *const nodes = (const char *)sc.nodes4f;
-	for (;;)
-	{
-		while (!(cur & ENTRY_LEAF))
-		{
-			const Node4f &nd = *(const Node4f *)(nodes + ((size_t)(cur & ENTRY_INDEX_MASK) << 7));
-			float tk_ref[4];
-			unsigned long long m[4];
-			for (int k = 0; k < 4; k++)
-			{
-				m[k] = 0ull;
-				for (int l = 0; l < WAVE; l++)
-				{
-					float tmin, tmax;
-					if (!sp.mixed)
-					{
-						const float *nx = (const float *)((const char *)&nd + sp.off_n[0]), *ny = (const float *)((const char *)&nd + sp.off_n[1]);
-						const float *nz = (const float *)((const char *)&nd + sp.off_n[2]), *fx = (const float *)((const char *)&nd + sp.off_f[0]);
-						const float *fy = (const float *)((const char *)&nd + sp.off_f[1]), *fz = (const float *)((const char *)&nd + sp.off_f[2]);
-						tmin = fmaxf(fmaxf(fmaf(nx[k], sp.id[l].x, sp.noid[l].x), fmaf(ny[k], sp.id[l].y, sp.noid[l].y)), fmaf(nz[k], sp.id[l].z, sp.noid[l].z));
-						tmax = fminf(fminf(fmaf(fx[k], sp.id[l].x, sp.noid[l].x), fmaf(fy[k], sp.id[l].y, sp.noid[l].y)), fmaf(fz[k], sp.id[l].z, sp.noid[l].z));
-					}
-					else
-					{
-						const float ax = fmaf(nd.lo[0][k], sp.id[l].x, sp.noid[l].x), bx = fmaf(nd.hi[0][k], sp.id[l].x, sp.noid[l].x);
-						const float ay = fmaf(nd.lo[1][k], sp.id[l].y, sp.noid[l].y), by = fmaf(nd.hi[1][k], sp.id[l].y, sp.noid[l].y);
-						const float az = fmaf(nd.lo[2][k], sp.id[l].z, sp.noid[l].z), bz = fmaf(nd.hi[2][k], sp.id[l].z, sp.noid[l].z);
-						tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-						tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-					}
-					const float tk = fmaxf(tmin, 0.0f);
-					if (l == ref_lane)
-						tk_ref[k] = tk;
-					if (tk < fminf(tmax, hit[l].t))
-						m[k] |= 1ull << l;
-				}
-				if (sp.mixed && nd.entry[k] == ENTRY_EMPTY)
-					m[k] = 0ull;
-			}
-			if (COUNT)
-				for (int k = 0; k < 4; k++) // per ray: the children IT enters (device: trace_packet)
-				{
-					const uint32_t e = nd.entry[k];
-					uint32_t n = 0;
-					for (int l = 0; l < WAVE; l++)
-						n += (uint32_t)((m[k] >> l) & 1ull);
-					if (!(e & ENTRY_LEAF))
-						st.inner += n;
-					else if (!(e & ENTRY_TLAS))
-						st.tris += n * (((e >> 27) & 7u) + 1u);
-				}
-			uint32_t kk[4], ee[4];
-			for (int k = 0; k < 4; k++)
-				kk[k] = m[k] ? fbits(tk_ref[k]) : 0xFFFFFFFFu, ee[k] = nd.entry[k];
-			auto pswap = [&](int a, int b) {
-				if (kk[b] < kk[a])
-				{
-					const uint32_t tk_ = kk[a], te_ = ee[a];
-					kk[a] = kk[b], ee[a] = ee[b], kk[b] = tk_, ee[b] = te_;
-				}
-			};
-			pswap(0, 1), pswap(2, 3), pswap(0, 2);
-#if RT_PACKET_FULL_SORT
-			pswap(1, 3), pswap(1, 2);
-#endif
-			stk.push3(ee[3], kk[3] != 0xFFFFFFFFu, ee[2], kk[2] != 0xFFFFFFFFu, ee[1], kk[1] != 0xFFFFFFFFu);
-			cur = kk[0] != 0xFFFFFFFFu ? ee[0] : stk.pop();
-		}
-		if (cur == ENTRY_DONE)
-			break;
-		if (cur == ENTRY_SENTINEL)
-		{
-			sp.enter(O, D, act);
-			cur_inst = -1;
-			cur = stk.pop();
-			continue;
-		}
-		if (cur & ENTRY_TLAS)
-		{
-			const uint32_t ii = sc.tlas_prims[cur & ENTRY_FIRST_MASK];
-			const Instance &in = sc.instances[ii];
-			stk.push(ENTRY_SENTINEL);
-			static thread_local f3 o2[WAVE], d2[WAVE];
-			for (int l = 0; l < WAVE; l++)
-			{
-				o2[l] = mk3(row_point_r(in.inv, O[l]), row_point_r(in.inv + 4, O[l]), row_point_r(in.inv + 8, O[l]));
-				d2[l] = mk3(row_dir_r(in.inv, D[l]), row_dir_r(in.inv + 4, D[l]), row_dir_r(in.inv + 8, D[l]));
-			}
-			sp.enter(o2, d2, act);
-			cur_inst = (int)ii;
-			cur = in.root_entry;
-			continue;
-		}
-		{
-			const uint32_t first = cur & ENTRY_FIRST_MASK, count = ((cur >> 27) & 7u) + 1u;
-			for (uint32_t i = 0; i < count; i++)
-			{
-				const f4 *tv = sc.tri_verts + 3u * (first + i);
-				const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-				for (int l = 0; l < WAVE; l++)
-					if (tri_test<true>(sp.o[l], sp.d[l], t_min, hit[l].t, xyz(v0), xyz(v1), xyz(v2), hit[l].u, hit[l].v, fbits(v0.w), (uint32_t)hit[l].prim))
-					{
-						hit[l].prim = (int)fbits(v0.w);
-						hit[l].inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);
-					}
-			}
-			cur = stk.pop();
-		}
-	}
-}
-template <bool COUNT> void primary(const Params &p, uint32_t count)
-{
-	TStat st;
-	st.inner = 0, st.tris = 0, st.lds = 0;
-	unsigned long long nrays = 0;
-	for (uint32_t base = 0; base < count; base += WAVE)
-	{
-		bool active[WAVE];
-		f3 O[WAVE], D[WAVE];
-		Hit h[WAVE];
-		for (int l = 0; l < WAVE; l++)
-		{
-			const uint32_t idx = base + (uint32_t)l;
-			active[l] = idx < count;
-			O[l] = mk3(0, 0, 0), D[l] = mk3(0, 0, 1);
-			if (active[l])
-			{
-				const PixelRef pr = slot_to_pixel(p.fr, idx);
-				active[l] = pr.valid;
-				if (active[l])
-				{
-					pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O[l], D[l]);
-					if (p.cam.aperture != 0.0f)
-						p.wv.org[0][idx] = mk4(O[l].x, O[l].y, O[l].z, ubits((idx << 1) | 1u));
-				}
-			}
-			h[l].t = 1e34f, h[l].u = 0.0f, h[l].v = 0.0f, h[l].prim = -1, h[l].inst = -1;
-		}
-		trace<COUNT>(p.sc, active, O, D, 1e-5f, h, st);
-		for (int l = 0; l < WAVE; l++)
-			if (active[l])
-			{
-				primary_finish_item(p, base + (uint32_t)l, D[l], h[l]);
-				nrays++;
-			}
-	}
-	if (COUNT)
-	{
-		WaveCounters *const wc = p.wv.counters;
-		wc->inner_extend += st.inner, wc->tris_extend += st.tris, wc->rays_extend += nrays;
-	}
-}
-} // namespace packet_emu
-
-void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t)
-{
-	if (gen == GEN_PT && (p.arm & 1u))
-		primary_arm_begin_item(p.wv.counters, max_items, p.queue, 0u, 1u);
-	if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= (16u << 20))) // (the device's rule)
-	{
-		count ? packet_emu::primary<true>(p, max_items) : packet_emu::primary<false>(p, max_items);
-		if (p.arm & 2u)
-			primary_arm_end_item(p.wv.counters, p.queue);
-		return;
-	}
-	Ctx ctx(p);
-	const uint32_t n = (gen == GEN_BUFFER || gen == GEN_RANGED) ? p.wv.counters->ext_n[p.depth] : max_items;
-	for (uint32_t i = 0; i < n; i++)
-	{
-		if (gen == GEN_BUFFER)
-			count ? extend_item<GEN_BUFFER, true>(p, i, true, ctx) : extend_item<GEN_BUFFER, false>(p, i, true, ctx);
-		else if (gen == GEN_RANGED)
-			count ? extend_item<GEN_RANGED, true>(p, i, true, ctx) : extend_item<GEN_RANGED, false>(p, i, true, ctx);
-		else if (gen == GEN_PT)
-			count ? extend_item<GEN_PT, true>(p, i, true, ctx) : extend_item<GEN_PT, false>(p, i, true, ctx);
-		else
-			count ? extend_item<GEN_PARITY, true>(p, i, true, ctx) : extend_item<GEN_PARITY, false>(p, i, true, ctx);
-	}
-	if (gen == GEN_PT && (p.arm & 2u))
-		primary_arm_end_item(p.wv.counters, p.queue);
-}
-void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t)
-{
-	Ctx ctx(p);
-	for (uint32_t i = 0; i < max_items; i++)
-		count ? shade_parity_item<true>(p, i, true, ctx) : shade_parity_item<false>(p, i, true, ctx);
-}
-uint32_t queue_pad(uint32_t) { return 0u; }
-void launch_shade_pt(const Params &p, uint32_t, stream_t)
-{
-	Ctx ctx;
-	const uint32_t n = p.wv.counters->ext_n[p.depth];
-	for (uint32_t i = 0; i < n; i++)
-	{
-		// (a primary miss the packet form finished itself, primary_finish_item: the device kernel's scan passes it over)
-		if (p.depth == 0 && (int)fbits(p.wv.hit0[i].w) == HIT_MISS_SHADED)
-			continue;
-#if defined(RT_DIAG_SHADE_CLOCK)
-		ClkProbe clk0;
-		clk0.last = 0, clk0.acc = nullptr;
-		p.textured ? shade_pt_item<true>(p, i, true, ctx, &clk0) : shade_pt_item<false>(p, i, true, ctx, &clk0);
-#else
-		p.textured ? shade_pt_item<true>(p, i, true, ctx) : shade_pt_item<false>(p, i, true, ctx);
-#endif
-	}
-	p.wv.counters->ext[p.depth + 1] += ctx.q_ext.rays, p.wv.counters->shadow[p.depth] += ctx.q_shadow.rays;
-}
-void launch_connect(const Params &p, bool count, uint32_t, stream_t)
-{
-	Ctx ctx(p);
-	const uint32_t n = connection_count(p.wv.counters, p.depth);
-	if (n == 0u && p.depth == 0 && p.wv.rad_nee)
-		for (uint32_t i = 0; i < p.wv.counters->shadow_n[0]; i++)
-			connect_skip_item(p, i);
-	for (uint32_t i = 0; i < n; i++)
-		count ? connect_item<true>(p, i, true, ctx) : connect_item<false>(p, i, true, ctx);
-}
-void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s)
-{
-	launch_extend(pe, GEN_BUFFER, count, max_items, s);
-	launch_connect(pa, count, max_items, s);
-}
-void launch_resolve(const Params &p, stream_t)
-{
-	for (uint32_t i = 0; i < p.fr.W * p.fr.local_rows; i++)
-		resolve_item(p, i);
-}
-void launch_present(const Params &p, f4 *out, float scale, int full, stream_t)
-{
-	for (uint32_t i = 0; i < p.fr.W * p.fr.local_rows; i++)
-		present_item(p, out, scale, full, i);
-}
-void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, uint32_t local_rows, uint32_t world, stream_t)
-{
-	for (uint32_t i = 0; i < W * H; i++)
-		deinterleave_item(gathered, out, W, H, local_rows, world, i);
-}
-void launch_kat(const Params &p, int function, const float *in, float *out, uint32_t n, stream_t)
-{
-	float pot[POT_SLOTS];
-	for (uint32_t i = 0; i < n; i++)
-		kat_item(p, function, in, out, i, pot);
-}
-void launch_skin_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const uint32_t *joints4,
-						  const f4 *weights4, const float *mats, uint32_t joint_count, uint32_t vertex_count, stream_t)
-{
-	for (uint32_t i = 0; i < vertex_count; i++)
-		skin_vertex_item(verts, vnormals, base_verts, base_normals, joints4, weights4, mats, joint_count, i);
-}
-void launch_morph_vertices(f4 *verts, f4 *vnormals, const f4 *base_verts, const f4 *base_normals, const f4 *tgt_pos,
-						   const f4 *tgt_nrm, const float *weights, uint32_t target_count, uint32_t vertex_count, stream_t)
-{
-	for (uint32_t i = 0; i < vertex_count; i++)
-		morph_vertex_item(verts, vnormals, base_verts, base_normals, tgt_pos, tgt_nrm, weights, target_count, vertex_count, i);
-}
-void launch_skin_shade(TriShade *shade, const f4 *verts, const f4 *vnormals, const uint32_t *indices, uint32_t tri_count, stream_t)
-{
-	for (uint32_t i = 0; i < tri_count; i++)
-		skin_shade_item(shade, verts, vnormals, indices, i);
-}
-void launch_stamp_instance(f4 *tri_verts, uint32_t tri_count, uint32_t instance, stream_t)
-{
-	for (uint32_t i = 0; i < tri_count; i++)
-		tri_verts[3ull * i + 1].w = ubits(instance);
-}
-void launch_refresh4(Node4c *nodes4, const uint32_t *src4, uint32_t count4, const Node *blas_nodes2, stream_t)
-{
-	for (uint32_t i = 0; i < count4; i++)
-		refresh4_item(nodes4, src4, blas_nodes2, i);
-}
-void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t)
-{
-	for (uint32_t i = 0; i < count4; i++)
-		expand4_item(nodes4, out, i);
-}
-void launch_refit(Node *all_nodes, uint32_t node_base, const int *parents, uint32_t node_count, f4 *tri_verts,
-				  uint32_t tri_base, const f4 *verts, const uint32_t *indices, uint32_t tri_count, uint32_t *flags, stream_t)
-{
-	for (uint32_t i = 0; i < tri_count; i++)
-		refit_tris_item(tri_verts + 3ull * tri_base, verts, indices, i);
-	memset(flags, 0, sizeof(uint32_t) * node_count);
-	Node *nodes = all_nodes + node_base;
-	for (uint32_t i = 0; i < node_count; i++)
-	{
-		const Node n = nodes[i];
-		if (n.count < 0 || i == 1u)
-			continue;
-		float mn[3], mx[3];
-		leaf_bounds(n, tri_verts, mn, mx);
-		for (int a = 0; a < 3; a++)
-			nodes[i].bmin[a] = mn[a], nodes[i].bmax[a] = mx[a];
-		int cur = (int)i;
-		for (;;)
-		{
-			const int parent = parents[cur];
-			if (parent < 0)
-				break;
-			if (flags[parent]++ == 0u)
-				break;
-			const int l = (int)(((uint32_t)nodes[parent].left_first & ENTRY_INDEX_MASK) - node_base);
-			for (int a = 0; a < 3; a++)
-			{
-				nodes[parent].bmin[a] = fminf(nodes[l].bmin[a], nodes[l + 1].bmin[a]);
-				nodes[parent].bmax[a] = fmaxf(nodes[l].bmax[a], nodes[l + 1].bmax[a]);
-			}
-			cur = parent;
-		}
-	}
-}
-
+#else // RFWHIP_HOST_EMULATION: the same work items driven by plain loops (tests/_emu only — never shipped)
+#include "kernels_emu.inc"
 #endif
 
 } // namespace rtk

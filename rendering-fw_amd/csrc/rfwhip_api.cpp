@@ -397,9 +397,10 @@ struct rfwhip_context
 	DevBuf d_blue_noise;
 	bool have_blue_noise = false;
 	int lds_nodes = -1; // -1: as many as the kernels hold (rtk::max_lds_nodes())
-	int refill = 15; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves, bit 2: the pt primary wave;
-					// bit 3: the pt primary wave in packet form (wave-uniform traversal, kernels.hip: trace_packet)
-	bool counters_armed[MAX_SUB] = {}; // the set of wave counters is as a pt launch chain leaves it: its next primary kernel re-arms it
+	int refill = 15; // persistent lanes on — bit 0: extension waves, bit 1: shadow waves (off: the one-ray-per-lane kernels, kept as
+					// a cross-check of the persistent-lane ones), bit 3: the pt primary wave in packet form (wave-uniform traversal,
+					// kernels.hip: trace_packet; off: one ray per lane); bit 2 selected round 2's persistent-lane primary kernel, which
+					// round 5 removed — accepted and ignored
 	bool packet_ok = false; // the scene's trees fit the packet kernel's stack and its 32-bit node offsets
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
@@ -408,10 +409,6 @@ struct rfwhip_context
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample;
 						   // 64 = a wave is ONE pixel: primary wave 3.67 instead of 4.01 ms per 32 spp, depth-0 shadow wave -7 %)
 	uint32_t sgroup_last = 0; // log2 of the group the most recent render call used
-	int arm = 0;	  // 1: the pt primary kernel re-arms its call's counters itself instead of a k_init_counters launch at the head of the
-					  // chain (kernels.hip: primary_arm_*).  Measured on the MI355X, same box, and OFF: 1-spp frames 1.25 against 1.20 ms,
-					  // 8 spp per step 5.00 against 4.89 ms, 256 spp per step equal — the workgroup barrier + atomic every workgroup
-					  // pays on leaving the primary kernel costs more than the 3-us kernel it replaces
 	int fuse = 1;	  // extension rays of depth d + 1 and shadow rays of depth d in one launch (kernels.hip: k_trace_fused)
 	int overlap = -1; // connection waves beside the next depth's stages on a second stream: 0 off, 1 on, -1 by launch size
 
@@ -1905,12 +1902,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		p.fr.spp = spp_i;
 		p.fr.sample_base = c->samples_done + s_begin;
 		const uint32_t n = c->fr.slots * spp_i;
-		// pt: the primary kernel re-arms the counters itself (kernels.hip: primary_arm_begin) once the set is in the state such a
-		// chain leaves it in; the explicit launch is for a set's first use, and after a parity frame or rfwhip_trace_rays
-		p.arm = (c->integrator == 1 && c->arm) ? (c->counters_armed[i] ? 3u : 2u) : 0u; // (bit 1: every pt primary leaves the set armed)
-		if (!(p.arm & 1u))
-			rtk::launch_init_counters(p.wv.counters, n, s);
-		c->counters_armed[i] = c->integrator == 1 && c->arm;
+		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
 		if (c->integrator == 0)
@@ -2243,7 +2235,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse", "arm"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2311,8 +2303,6 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->refill = atoi(value) & 15;
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
-	else if (k == "arm")
-		c->arm = atoi(value) != 0;
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);
@@ -2386,8 +2376,6 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->refill);
 	else if (k == "fuse")
 		snprintf(value, cap, "%d", c->fuse);
-	else if (k == "arm")
-		snprintf(value, cap, "%d", c->arm);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "sub_batch_paths")
@@ -2555,7 +2543,6 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 	RF_TRY(dm::h2d(c->d_dir2[1].p, d4.data(), n * sizeof(f4), s));
 	rtk::Params p;
 	fill_params(c, nullptr, p);
-	c->counters_armed[0] = false; // (this launch leaves its queue head used: the next frame's chain re-arms explicitly)
 	rtk::launch_init_counters(p.wv.counters, 0, s);
 	rtk::launch_set_ext_count(p.wv.counters, 1, (uint32_t)n, s);
 	p.depth = 1, p.queue = 0, p.group = 16;

@@ -439,8 +439,7 @@ constexpr uint32_t ENTRY_DONE = 0xFFFFFFFEu;
 // (profiles/micro/gather_micro.hip: 9.6 TB/s chip-wide whatever the table size) and that rate bounds the traversal
 // kernels; the same rows from LDS cost 4 cycles per 64 lanes, and every ray walks through these nodes.
 #ifndef RT_LDS_NODES
-#define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth); with RT_WAVE_TRIS
-						 // build with 120: the 512-byte pair map must fit into the same 20 KiB = 8 workgroups per CU
+#define RT_LDS_NODES 128 // about four levels (swept 0 / 21 / 85 / 128 / 170 / 341 against the LDS stack depth)
 #endif
 constexpr uint32_t MAX_LDS_NODES = RT_LDS_NODES;
 constexpr uint32_t TOP_ROWS = 4; // a compressed node is exactly four rows (the emulation's `top` aliases the node table)
@@ -626,13 +625,8 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 //
 // The traversal is a resumable per-lane state machine (begin / descend / visit) so that the persistent kernels can
 // hand a finished lane a new ray while its neighbours are still busy; trace() below runs it to completion.
-// RT_SPECULATE = 1: speculative traversal — a lane takes its first triangle leaf in hand and walks on (Traverser::descend).
-// Bit-identical hit records, and measured on the MI355X as a loss: the leaf vote already keeps the waiting short, and the
-// nodes a held leaf's hit would have culled are extra instructions in kernels that are VALU-bound (primary wave 7.32 -> 8.25 ms,
-// bounce wave 6.97 -> 7.28 ms per 64-spp sub-batch, bench 3812 -> 3672 Msamples/s).  Off.
-#ifndef RT_SPECULATE
-#define RT_SPECULATE 0
-#endif
+// (Speculative traversal — a lane takes its first triangle leaf in hand and walks on — was built in round 3, is bit-identical and
+// loses; round 5 took it out of the sources: DESIGN_LOG.md, "variants removed".)
 // WORLD = false: the lane does not keep the world-space ray beside the ray of the current space — the caller hands it to
 // visit() on the two occasions it is needed (entering and leaving an instance), e.g. by reading the ray record again (the
 // persistent-lane kernels: six registers less per lane, and instance switches are rare once static geometry is linked flat).
@@ -651,7 +645,6 @@ struct Traverser : TraverserWorld<WORLD>
 	int cur_inst;
 	int sp;
 	uint32_t cur; // entry in hand; ENTRY_DONE when the lane has no work
-	uint32_t held; // RT_SPECULATE: a triangle leaf taken in hand while the lane walks on (ENTRY_DONE: none)
 	float t_min;
 	Hit hit;
 
@@ -685,7 +678,7 @@ struct Traverser : TraverserWorld<WORLD>
 			this->O = O_, this->D = D_;
 		t_min = t_min_;
 		hit.t = t_max, hit.u = 0.0f, hit.v = 0.0f, hit.prim = -1, hit.inst = -1;
-		cur_inst = -1, sp = 0, held = ENTRY_DONE;
+		cur_inst = -1, sp = 0;
 		enter_space(O_, D_);
 		cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
 	}
@@ -696,11 +689,11 @@ struct Traverser : TraverserWorld<WORLD>
 		enter_space(mk3(row_point_r(in.inv, O), row_point_r(in.inv + 4, O), row_point_r(in.inv + 8, O)),
 					mk3(row_dir_r(in.inv, D), row_dir_r(in.inv + 4, D), row_dir_r(in.inv + 8, D)));
 	}
-	RT_FN bool done() const { return cur == ENTRY_DONE && (!RT_SPECULATE || held == ENTRY_DONE); }
+	RT_FN bool done() const { return cur == ENTRY_DONE; }
 	// a triangle leaf (not a top-level leaf, the sentinel or ENTRY_DONE, which all carry the ENTRY_TLAS bit)
 	static RT_FN bool tri_leaf(uint32_t e) { return (e & (ENTRY_LEAF | ENTRY_TLAS)) == ENTRY_LEAF; }
 	// has this lane nothing left to do in the node phase?
-	RT_FN bool parked() const { return (cur & ENTRY_LEAF) && !(RT_SPECULATE && held == ENTRY_DONE && tri_leaf(cur)); }
+	RT_FN bool parked() const { return (cur & ENTRY_LEAF) != 0u; }
 
 	static constexpr int LDS_DEPTH = ANY ? LDS_STACK_ANY : LDS_STACK;
 	static constexpr float NODE_INF = 3.0e38f;
@@ -771,19 +764,13 @@ struct Traverser : TraverserWorld<WORLD>
 		if (rel < stk.top_count)
 		{
 			rows = load_rows<false>((const char *)stk.top, rel * (TOP_ROWS * 16u));
-#if !defined(RT_DIAG_PHASES)
 			if (COUNT)
 				st.lds++;
-#endif
 		}
 		else // byte offset of the node in the table (tables stay below 4 GiB)
 			rows = load_rows<true>((const char *)sc.nodes4, idx << 6);
 		if (COUNT)
 			st.inner++;
-#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
-		if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
-			st.lds++; // wave-level iterations of the node loop (leader lane)
-#endif
 		// plane = org + q * 2^e  =>  distance = q * (2^e / d) + (org / d - o / d): three scales and three offsets per node,
 		// then one v_cvt_f32_ubyte + one fma per plane.  Which of a child's two planes per axis is the entry plane depends
 		// only on the sign of the direction: resolved per node by swapping the lo / hi dwords of the axis.
@@ -864,11 +851,6 @@ struct Traverser : TraverserWorld<WORLD>
 #ifndef RT_VOTE_RELATIVE
 #define RT_VOTE_RELATIVE 1
 #endif
-	// RT_SPECULATE (Aila & Laine's speculative traversal): a lane that reaches a triangle leaf takes it in hand (`held`) and walks
-	// on from its stack instead of idling until the wave's leaf phase; it parks only with a SECOND leaf (or an instance entry, the
-	// sentinel, an empty stack).  The leaves of a ray are still tested in the same order — visit() tests `held` before anything
-	// else — so every hit record is unchanged; what changes is that some nodes are visited which the held leaf's hit would have
-	// culled (counters), and that the node phase runs with more of its lanes.
 	template <int VOTE = 64> RT_FN void descend(const SceneView &sc, const TravStack stk, TStat &st)
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -876,8 +858,6 @@ struct Traverser : TraverserWorld<WORLD>
 #endif
 		for (;;)
 		{
-			if (RT_SPECULATE && held == ENTRY_DONE && tri_leaf(cur))
-				held = cur, cur = pop(stk);
 			if (cur & ENTRY_LEAF)
 				break;
 			float t0, t1, t2, t3;
@@ -911,11 +891,8 @@ struct Traverser : TraverserWorld<WORLD>
 	// world(O, D): the world-space ray of this lane (asked for when an instance is entered or left)
 	template <typename F> RT_FN void visit(const SceneView &sc, const TravStack stk, TStat &st, F world)
 	{
-		uint32_t leaf = cur;
-		const bool from_held = RT_SPECULATE && held != ENTRY_DONE;
-		if (from_held)
-			leaf = held, held = ENTRY_DONE; // the leaf in hand comes first; whatever `cur` is waits for the next phase
-		else if (cur == ENTRY_DONE || !(cur & ENTRY_LEAF)) // (an inner node in hand: the wave left descend<VOTE>() early)
+		const uint32_t leaf = cur;
+		if (cur == ENTRY_DONE || !(cur & ENTRY_LEAF)) // (an inner node in hand: the wave left descend<VOTE>() early)
 			return;
 		else if (cur == ENTRY_SENTINEL)
 		{
@@ -949,13 +926,8 @@ struct Traverser : TraverserWorld<WORLD>
 		{
 			const f4 *tv = sc.tri_verts + 3u * (first + i);
 			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
-#if defined(RT_DIAG_PHASES) && defined(__HIP_DEVICE_COMPILE__)
-			if (COUNT && __builtin_amdgcn_mbcnt_hi((uint32_t)(__builtin_amdgcn_read_exec() >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_read_exec(), 0u)) == 0u)
-				st.tris++; // wave-level iterations of the triangle loop (leader lane)
-#else
 			if (COUNT)
 				st.tris++;
-#endif
 			if (tri_test<!ANY>(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v, fbits(v0.w), (uint32_t)hit.prim))
 			{
 				hit.prim = (int)fbits(v0.w);
@@ -973,8 +945,7 @@ struct Traverser : TraverserWorld<WORLD>
 		if (!ANY && hit.t != t_before)
 			renormalise(t_before);
 #endif
-		if (!from_held)
-			cur = pop(stk);
+		cur = pop(stk);
 	}
 };
 
@@ -1748,19 +1719,6 @@ struct ShadeOut
 	f4 eo, ed, et; // extension ray: origin|slot<<1|flags, dir|packedN, throughput|pdf
 };
 
-// What the texture layers of a hit come to (getShadingData.h:141-206): the colour after the diffuse layers, the shading normal
-// after the normal-map layers, and whether the alpha test lets the path through.  Computed by pt_textures() — in the textured
-// shade kernel as a PRE-PASS of every queued hit whose result goes through LDS (kernels.hip: shade_pt_item), so that the
-// registers of the trilinear fetches (eight texels, their weights, the descriptors) are free again before the BSDF and the
-// light sampling need theirs; pt_shade() picks the record up.  The values themselves take no other path: same functions, same
-// order, same bits as the fetches inside pt_shade() (the form the host emulation and rfwhip_kat use).
-struct TexShade
-{
-	f3 color, iN;
-	uint32_t flags; // TEXSHADE_*
-};
-constexpr uint32_t TEXSHADE_VALID = 1u, TEXSHADE_ALPHA_SKIP = 2u;
-
 // the surface at a hit: shading record, material, barycentric weights, geometric / shading normal in world space, tangent frame
 struct Surface
 {
@@ -1843,28 +1801,11 @@ RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, c
 #undef RT_LAYER
 #undef RT_NORMAL_LAYER
 }
-// the pre-pass: the record of one hit (flags = 0: untextured, nothing to pick up)
-RT_FN void pt_texture_prepass(const SceneView &sc, const CamView &cam, f3 D, const Hit &h, f3 &color, f3 &iN, uint32_t &flags)
-{
-	flags = 0u, color = mk3(0, 0, 0), iN = mk3(0, 0, 1);
-	if (h.prim < 0)
-		return;
-	Surface sf;
-	pt_surface(sc, h, sf);
-	if (!pt_has_textures(sc, sf))
-		return;
-	bool alpha_skip = false;
-	color = material_color(*sf.mat), iN = sf.iN;
-	pt_textures(sc, cam, D, h.t, sf, color, iN, alpha_skip);
-	flags = TEXSHADE_VALID | (alpha_skip ? TEXSHADE_ALPHA_SKIP : 0u);
-}
-
 // TEX = false: the scene has no material with a texture or normal map (the host knows: rfwhip_set_materials) — the texture
 // layers, their descriptors and the level-of-detail arithmetic are compiled out, which frees a fifth of the registers.
-// tex: the pre-pass's record of this hit (TEX only; null: the layers are fetched here).
 template <bool TEX>
 RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
-					ShadeOut &out, float *pot_cache, const TexShade *tex = nullptr RT_CLK_PARAM)
+					ShadeOut &out, float *pot_cache RT_CLK_PARAM)
 {
 	out.radiance = mk3(0, 0, 0);
 	out.emit_shadow = false, out.emit_ext = false;
@@ -1894,12 +1835,7 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth,
 	f3 N = sf.N, iN = sf.iN;
 	const f3 Tg = sf.Tg, Bt = sf.Bt;
 	bool alpha_skip = false;
-	if (TEX && tex)
-	{
-		if (tex->flags & TEXSHADE_VALID)
-			sd.color = tex->color, iN = tex->iN, alpha_skip = (tex->flags & TEXSHADE_ALPHA_SKIP) != 0u;
-	}
-	else if (TEX && pt_has_textures(sc, sf))
+	if (TEX && pt_has_textures(sc, sf))
 		pt_textures(sc, cam, D, h.t, sf, sd.color, iN, alpha_skip);
 	// alpha pass-through (Kernels.cu:633-647): the path continues behind the surface, state untouched
 	if (alpha_skip)

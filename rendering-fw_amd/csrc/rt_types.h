@@ -384,8 +384,7 @@ struct WaveCounters
 	uint32_t probe_valid;
 	uint32_t stack_overflow; // traversal-stack entries dropped (must stay 0: rfwhip_update bounds the trees; rfwhip_wait fails otherwise)
 	uint32_t ext_timed;		 // extend-stage launches folded into ext_ticks so far
-	uint32_t primary_exit;	 // workgroups of the self-arming primary kernel that have left (kernels.hip: primary_arm_end)
-	uint32_t pad_[1];
+	uint32_t pad_[2];
 	// Device-side clock of the extend stage (what a kernel trace reports as the kernel's duration): first workgroup in /
 	// last workgroup out of the launch of depth d, in ticks of the constant 100 MHz counter (s_memrealtime); folded into
 	// ext_ticks when the counters are re-armed for the next call, or when the host reads them.

@@ -17,14 +17,14 @@ OUT = os.path.join(OUT_DIR, "librfwhip_emu.so")
 
 
 def build(force=False, defines=(), tag=""):
-    """defines / tag: a variant of the library built with other compile-time constants (e.g. ("-DRT_SPECULATE=1",), "_spec")."""
+    """defines / tag: a variant of the library built with other compile-time constants (e.g. ("-DRT_LDS_NODES=64",), "_lds64")."""
     out = OUT if not tag else os.path.join(OUT_DIR, "librfwhip_emu%s.so" % tag)
     return _build(force, list(defines), out)
 
 
 def _build(force, defines, OUT):
     srcs = [os.path.join(CSRC, f) for f in ("rfwhip_api.cpp", "rfwhip_group.cpp", "bvh_build.cpp", "kernels.hip", "lbvh.hip")]
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".inc"))]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT

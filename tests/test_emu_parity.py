@@ -356,9 +356,9 @@ def test_image_is_independent_of_how_calls_are_scheduled(pkg, make_emu, integrat
                               ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2),
                               ({"sample_group": 1}, 0), ({"sample_group": 2, "ring": 2}, 0), ({"sample_group": 64}, 1),
                               ({"sample_group": 4, "streams": 2, "sub_batch_paths": 1}, 0),
-                              # round 4: one launch per depth or two; the primary kernel re-arming the counters or a launch for it;
+                              # round 4: one launch per depth or two;
                               # the primary wave per lane instead of as a packet
-                              ({"fuse": 0}, 0), ({"fuse": 0, "ring": 4, "overlap": 1}, 0), ({"arm": 1, "ring": 4}, 0), ({"arm": 1, "fuse": 0}, 2),
+                              ({"fuse": 0}, 0), ({"fuse": 0, "ring": 4, "overlap": 1}, 0), ({"fuse": 0, "ring": 2}, 2),
                               ({"refill": 7, "sample_group": 64}, 0), ({"refill": 0}, 0)):
         img = _pipelined(pkg, make_emu(), scene, 64, 48, dict(base, **extra), 6, wait_every)
         assert np.array_equal(img, ref), (extra, wait_every)
@@ -435,31 +435,6 @@ def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geo
     _run(pkg, [e, o], pkg.scenes.cornell(96, 64, geometric_emitter=geometric_emitter), 96, 64, {"integrator": "parity", "jitter": "center"})
     a, b = e.primary_hits(), o.primary_hits()
     assert (a["inst"] != b["inst"]).sum() == 0 and (a["prim"] != b["prim"]).sum() == 0
-
-
-def test_speculative_traversal_changes_no_hit_record(pkg, emu_lib):
-    """`-DRT_SPECULATE=1` (rt_core.h: a lane takes its first triangle leaf in hand and walks on; measured as a loss on the MI355X and
-    off by default) only changes WHEN a leaf is tested relative to the nodes popped after it, never the order of the leaves: image,
-    primary hits and wave sizes of a variant library built with it equal the default build's bit for bit, through instances,
-    sentinels and shadow rays."""
-    import ctypes
-    import build_emu
-    spec = ctypes.CDLL(build_emu.build(defines=("-DRT_SPECULATE=1",), tag="_spec"))
-    for scene, w, h in ((pkg.scenes.cornell(70, 51, geometric_emitter=True), 70, 51), (pkg.scenes.atrium(96, 64), 96, 64)):
-        out = []
-        for lib in (emu_lib, spec):
-            c = pkg._binding.CoreBinding(lib, "rfwhip_", 0, 0, 1)
-            c.init(w, h)
-            scene.upload(c)
-            for k, v in {"integrator": "pt", "spp": 4, "max_depth": 3}.items():
-                c.set_setting(k, v)
-            c.render_frame(scene.camera, pkg.RESET)
-            st = c.get_stats()
-            out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
-        assert np.array_equal(out[0][0], out[1][0])
-        for k in ("inst", "prim", "t"):
-            assert np.array_equal(out[0][1][k], out[1][1][k]), k
-        assert out[0][2] == out[1][2]
 
 
 def _no_survivor_scene(pkg, w, h):

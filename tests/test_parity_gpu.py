@@ -494,9 +494,9 @@ def test_image_is_independent_of_how_calls_are_scheduled_gpu(pkg, make_hip, inte
                               ({"streams": 4, "sub_batch_paths": 1}, 0), ({"streams": 3, "sub_batch_paths": 1, "overlap": 1}, 2),
                               ({"sample_group": 1}, 0), ({"sample_group": 2, "ring": 2}, 0), ({"sample_group": 64}, 1),
                               ({"sample_group": 4, "streams": 2, "sub_batch_paths": 1}, 0),
-                              # round 4: one launch per depth or two; the primary kernel re-arming the counters or a launch for it;
+                              # round 4: one launch per depth or two;
                               # the primary wave per lane instead of as a packet
-                              ({"fuse": 0}, 0), ({"fuse": 0, "ring": 4, "overlap": 1}, 0), ({"arm": 1, "ring": 4}, 0), ({"arm": 1, "fuse": 0}, 2),
+                              ({"fuse": 0}, 0), ({"fuse": 0, "ring": 4, "overlap": 1}, 0), ({"fuse": 0, "ring": 2}, 2),
                               ({"refill": 7, "sample_group": 64}, 0), ({"refill": 0}, 0)):
         img = _pipelined(pkg, make_hip(), scene, 480, 272, dict(base, **extra), 8, wait_every)
         assert np.array_equal(img, ref), (extra, wait_every)
