@@ -45,6 +45,13 @@ RFWHIP_API const char *rfwhip_version(void);
  * (s / world) odd ? world - 1 - s % world : s % world — NOT plain s % world (rows get dearer down an image of terrain
  * under sky, and the serpentine cancels that gradient).  A host that gathers local framebuffers itself de-interleaves
  * with rfwhip_deinterleave_*; rfwhip_group_* / rfwhip_comm_* below do the whole gather.  world = 1 renders everything. */
+#define RFWHIP_STRIP_ROWS 8
+/* the rank (of `world`) that owns image row y: the rule above, for hosts that route per-pixel queries (the probe) themselves */
+static inline int rfwhip_row_owner(int y, int world)
+{
+	const int strip = y / RFWHIP_STRIP_ROWS, k = strip / world, pos = strip % world;
+	return (k & 1) ? world - 1 - pos : pos;
+}
 RFWHIP_API int rfwhip_create(int device_ordinal, int rank, int world, rfwhip_context **out);
 /* RenderContext::cleanup() (context.h:93).  Idempotent: the reference calls it twice on unload
  * (system.cpp:160-178 + EmbreeRT/src/Context.cpp:30). */

@@ -1210,12 +1210,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) __attribute__((am
 			connect_skip_item(pa, i);
 	if (count_e == 0u && count_a == 0u)
 		return;
-	clock_in(pe.wv.counters, pe.depth);
 	const Params &p = pe; // (the stack declaration reads the LDS node range from `p`)
 	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
-	if (count_e)
+	if (count_e) // (the device clock of the extend stage covers extension rays only: no near-empty span for a launch without any)
+	{
+		clock_in(pe.wv.counters, pe.depth);
 		stream_rays<STREAM_EXT, COUNT>(pe, count_e, ctx);
-	clock_out(pe.wv.counters, pe.depth);
+		clock_out(pe.wv.counters, pe.depth);
+	}
 	if (count_a)
 		stream_rays<STREAM_ANY, COUNT>(pa, count_a, ctx);
 }

@@ -256,10 +256,8 @@ class Context final : public rfw::RenderContext
 		// only the rank that owns the probe pixel's 8-row strip has a record for it (every context keeps its last valid one:
 		// asking the others would hand back the hit of wherever the probe was before)
 		{
-			const unsigned world = (unsigned)m_Cores.size();
-			const unsigned strip = m_ProbeY / 8u, k = strip / world, pos = strip % world;
-			const unsigned owner = (k & 1u) ? world - 1u - pos : pos; // rfwhip.h: serpentine strip ownership
-			HIPRT_CHECK(rfwhip_get_probe_results(m_Cores[owner], &inst, &prim, &dist));
+			const int owner = rfwhip_row_owner((int)m_ProbeY, (int)m_Cores.size()); // rfwhip.h: serpentine strip ownership
+			HIPRT_CHECK(rfwhip_get_probe_results(m_Cores[(size_t)owner], &inst, &prim, &dist));
 		}
 		if (instanceIndex)
 			*instanceIndex = inst;

@@ -419,7 +419,9 @@ struct rfwhip_context
 	bool scene_dirty = true;
 
 	// scene (device side)
-	DevBuf d_nodes4f; // float form of d_nodes4 (rt::Node4f), refreshed at the end of every rfwhip_update
+	DevBuf d_nodes4f; // float form of d_nodes4 (rt::Node4f), refreshed at the end of every rfwhip_update that may need it
+	bool nodes4f_current = false; // ... which is when the packet form of the primary wave can run (packet_ok, refill bit 3)
+	size_t nodes4_live = 0;		  // 4-wide nodes in use: all mesh trees + the top-level tree
 	DevBuf d_nodes, d_nodes4, d_nodes4_src, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
 	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
@@ -1230,6 +1232,20 @@ extern "C" int rfwhip_morph_mesh(rfwhip_context *c, size_t index, const float *w
 	return RFWHIP_OK;
 }
 
+// The float copy of the traversal nodes (rt::Node4f) — written only when its one reader, the packet form of the pt primary wave,
+// can run: at the end of an update, or by the first render call after `refill` bit 3 was switched on.
+static int ensure_nodes4f(rfwhip_context *c)
+{
+	if (c->nodes4f_current || !c->packet_ok || !(c->refill & 8) || !c->nodes4_live)
+		return 0;
+	RF_TRY(c->d_nodes4f.ensure(c->node4_capacity * sizeof(rt::Node4f)));
+	rtk::launch_expand4(c->d_nodes4.as<rt::Node4c>(), c->d_nodes4f.as<rt::Node4f>(), (uint32_t)c->nodes4_live, c->stream);
+	RF_TRY(dm::last_launch_error());
+	c->sv.nodes4f = c->d_nodes4f.as<rt::Node4f>();
+	c->nodes4f_current = true;
+	return 0;
+}
+
 extern "C" int rfwhip_update(rfwhip_context *c)
 {
 	CTX_ENTER(c);
@@ -1470,9 +1486,10 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4c>() + tlas_base, tl4c.data(), tl4c.size() * sizeof(rt::Node4c), c->stream));
 	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
 	// the float form of every traversal node (mesh trees as rebuilt / refitted above + the top-level tree): one streaming pass
-	RF_TRY(c->d_nodes4f.ensure(c->node4_capacity * sizeof(rt::Node4f)));
+	// (only when the packet form of the primary wave — its one reader — can run: the table is twice the compressed one's size)
 	c->packet_ok = c->packet_ok && (tlas_base + tl4c.size()) * sizeof(rt::Node4f) < (1ull << 32);
-	rtk::launch_expand4(c->d_nodes4.as<rt::Node4c>(), c->d_nodes4f.as<rt::Node4f>(), (uint32_t)(tlas_base + tl4c.size()), c->stream);
+	c->nodes4_live = tlas_base + tl4c.size(), c->nodes4f_current = false;
+	RF_TRY(ensure_nodes4f(c));
 	RF_TRY(dm::last_launch_error());
 	RF_TRY(dm::sync(c->stream));
 	c->instance_count = (uint32_t)live.size();
@@ -1657,7 +1674,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 		if (big && want)
 			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, big->n4_count);
 	}
-	p.refill = (uint32_t)c->refill & (c->packet_ok ? 15u : 7u);
+	p.refill = (uint32_t)c->refill & ((c->packet_ok && c->nodes4f_current) ? 15u : 7u);
 	p.textured = c->textured ? 1u : 0u;
 }
 
@@ -1739,6 +1756,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	const size_t paths = (size_t)c->fr.slots * (size_t)c->spp;
 	if (paths >= (1ull << 31))
 		return set_error(RFWHIP_ERR_UNSUPPORTED, "spp batch too large: %zu path slots (limit 2^31)", paths);
+	if (c->integrator == 1 && !c->nodes4f_current && c->packet_ok && (c->refill & 8))
+	{
+		// (`refill` bit 3 came on after the last update: the packet form's float node table is written now, once)
+		RF_TRY(ensure_nodes4f(c));
+		RF_TRY(dm::sync(c->stream));
+	}
 	// Sub-batches: a call is cut into up to `streams` concurrent sub-batches only when that leaves every one at least
 	// `sub_batch_paths` path slots and there are four of them: since the bounce / shadow / primary kernels keep their lanes
 	// filled themselves, ONE sub-batch whose calls alternate between two sets of wave buffers / streams / counters (so that
@@ -2577,6 +2600,7 @@ extern "C" int rfwhip_trace_rays(rfwhip_context *c, size_t n, const float *org, 
 }
 
 static_assert(RFWHIP_KAT_IN == 24 && RFWHIP_KAT_OUT == 8, "kat_item's record layout (kernels.hip)");
+static_assert(RFWHIP_STRIP_ROWS == (int)rt::STRIP_ROWS, "rfwhip.h: rfwhip_row_owner() restates rt::strip_owner()");
 extern "C" int rfwhip_kat(rfwhip_context *c, int function, size_t n, const float *in, float *out)
 {
 	CTX_ENTER(c);

@@ -432,6 +432,11 @@ int gather(rfwhip_group *g, void *full_out)
 				if (e.rank != 0)
 				{
 					GR_TRY(dev_use(e.device));
+					// (the root's de-interleave of the PREVIOUS frame must have read this rank's chunk of the staging image before the
+					// push overwrites it: the event is recorded behind that de-interleave, step 3, and re-recorded only after this
+					// wait has been enqueued — with frames in flight the push of frame k + 1 would otherwise race the read of frame k)
+					if (g->staging_read_valid)
+						GR_TRY(stream_wait(e.stream, g->staging_read));
 					GR_TRY(copy_async((char *)g->staging + (size_t)e.rank * chunk, root->device, e.local_fb, e.device, chunk, e.stream));
 					GR_TRY(event_record(e.sent, e.stream));
 				}

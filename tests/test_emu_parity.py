@@ -437,6 +437,35 @@ def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geo
     assert (a["inst"] != b["inst"]).sum() == 0 and (a["prim"] != b["prim"]).sum() == 0
 
 
+def test_product_shapes_against_the_reference_shaped_oracle(pkg, make_emu, make_oracle):
+    """The oracle's `arith=reference` form (triangle test, pt primary ray and sky lookup as the reference's text shapes them,
+    first triangle reached wins) against the product's fixed shapes, on libm arithmetic: a terrain cut at 4 spp.  What the
+    fixed shapes and the total order on (t, prim) change is a handful of last-bit decisions — same triangle everywhere, t to
+    1e-6 relative, at most 1 % of the pixels beyond 1e-3."""
+    scene = pkg.scenes.terrain(n=96, width=96, height_px=64)
+    emu, ref = make_emu(), make_oracle()
+    try:
+        ref.set_setting("arith", "reference")
+        for ctx in (emu, ref):
+            ctx.init(96, 64)
+            scene.upload(ctx)
+            for k, v in {"integrator": "pt", "spp": 1, "max_depth": 2}.items():
+                ctx.set_setting(k, v)
+            ctx.render_frame(scene.camera, pkg.RESET)
+        ha, hb = emu.primary_hits(), ref.primary_hits()  # (one sample per pixel: the record of THAT sample on both sides)
+        assert (ha["prim"] != hb["prim"]).sum() == 0 and (ha["inst"] != hb["inst"]).sum() == 0
+        hit = ha["prim"] >= 0
+        assert (np.abs(ha["t"][hit] - hb["t"][hit]) <= 1e-6 * hb["t"][hit]).all()
+        for ctx in (emu, ref):
+            ctx.set_setting("spp", 4)
+            ctx.render_frame(scene.camera, pkg.RESET)
+        a, b = emu.framebuffer(), ref.framebuffer()
+        d = np.sqrt(((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum(-1))
+        assert (d > 1e-3).mean() <= 1e-2, (d > 1e-3).mean()
+    finally:
+        ref.set_setting("arith", "product")  # (process-wide in the oracle)
+
+
 def _no_survivor_scene(pkg, w, h):
     """Cornell with every reflecting material given a negative red channel: each first vertex still connects to a light
     (Kernels.cu:702-755 has no sign test) but its throughput goes negative and the path ends (Kernels.cu:786) — depth 1 has no

@@ -79,3 +79,41 @@ def test_strict_hip_equals_strict_emulation_bit_for_bit(pkg, emu_strict_lib, mak
         frac = float((image_stats(emu[0], ora[0], 1e-3)[2] > 1e-3).mean())
         print("bench_terrain: strict emulation vs oracle (glibc): %.4f of the pixels beyond 1e-3" % frac)
         assert frac <= 3e-2, frac
+
+
+@pytest.mark.gpu
+def test_shipped_kernels_move_shading_not_geometry(pkg, make_hip):
+    """The SHIPPED kernels against the strict build on the bench workload (480 x 270, 8 samples, pt depth 2), sample by sample:
+    the shipped arithmetic (v_rcp_f32 in the triangle test and the slab set-up, v_sin / v_cos / v_exp, 1-ulp division and square
+    root behind the hit record) may flip shading DECISIONS — at most 3 % of the pixels differ at all — but it must not move
+    GEOMETRY: every primary ray of every sample finds the same triangle of the same instance at a distance within 5e-7 relative,
+    barycentrics within 3e-7.  A future fast-math change that lets a ray through a crack would show here as another triangle, where
+    the image tolerances would have absorbed it."""
+    w, h, spp = 480, 270, 8
+    scene = pkg.scenes.terrain(n=708, width=w, height_px=h)
+    strict_so = os.path.join(ROOT, "tests", "_strict", "librfwhip_strict.so")
+    assert os.path.exists(strict_so), "build it with __graft_entry__.build() (build.py: build_strict)"
+    out = []
+    for ctx in (make_hip(), pkg._binding.CoreBinding(ctypes.CDLL(strict_so), "rfwhip_", 0, 0, 1)):
+        ctx.init(w, h)
+        scene.upload(ctx)
+        for k, v in {"integrator": "pt", "spp": 1, "max_depth": 2}.items():
+            ctx.set_setting(k, v)
+        hits = []
+        for s in range(spp):  # one sample per call: the hit records of sample s, the image accumulates
+            ctx.render_frame(scene.camera, pkg.RESET if s == 0 else pkg.CONVERGE)
+            hits.append(ctx.primary_hits())
+        out.append((ctx.framebuffer(), hits))
+        ctx.destroy()
+    (img_a, hits_a), (img_b, hits_b) = out
+    differing = np.abs(img_a[..., :3] - img_b[..., :3]).max(-1) > 0
+    print("shipped vs strict: %.4f of the pixels differ, %.4f beyond 1e-3" % (differing.mean(), (np.abs(img_a[..., :3] - img_b[..., :3]).max(-1) > 1e-3).mean()))
+    assert (np.abs(img_a[..., :3] - img_b[..., :3]).max(-1) > 1e-3).mean() <= 3e-2
+    other = 0
+    for a, b in zip(hits_a, hits_b):
+        same = (a["prim"] == b["prim"]) & (a["inst"] == b["inst"])
+        other += int((~same).sum())
+        hit = same & (a["prim"] >= 0)
+        assert (np.abs(a["t"][hit] - b["t"][hit]) <= 5e-7 * b["t"][hit]).all()
+        assert np.abs(a["u"][hit] - b["u"][hit]).max() <= 3e-7 and np.abs(a["v"][hit] - b["v"][hit]).max() <= 3e-7
+    assert other == 0, "%d of %d primary rays found another triangle" % (other, w * h * spp)
