@@ -239,8 +239,13 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  Changes which path sits where, never the image
  *   flat_instances = "1" (default): an instance with the identity transform whose mesh no other instance uses is linked
  *                  into the top-level tree directly (rays reach its triangles without an instance switch; hit records,
- *                  images and counters are unchanged); "0": every instance behind a top-level leaf.  Takes effect with
- *                  the next rfwhip_update()
+ *                  images and counters are unchanged), and static instances that are transformed or share their mesh are
+ *                  written out in world space under one tree (the WORLD TREE, flatten_bytes); "0": every instance behind
+ *                  a top-level leaf, the reference's two-level walk.  Takes effect with the next rfwhip_update()
+ *   flatten_bytes = default 1073741824: the world tree is built as long as the world-space copy of its members' triangles
+ *                  (every instance of a host-built mesh that is not animated) stays below this many bytes; "0": never.
+ *                  The hit is the same triangle of the same instance at the same t as the two-level walk's up to rounding
+ *                  (M p is tested instead of M^-1 o).  Animated meshes always keep the two-level walk
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 3: three chains + the main stream
  *                  are the HIP runtime's four hardware queues; a host that keeps four frames in flight with

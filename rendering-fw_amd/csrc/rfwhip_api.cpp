@@ -316,6 +316,8 @@ struct MeshRec
 	bool resident = false; // placed in the global arrays by the last update()
 	bool dirty = true;	   // host staging newer than the global arrays
 	bool refit_pending = false;
+	uint32_t generation = 0; // counts the (re)builds of this mesh (the world tree's cache key)
+	uint32_t refits = 0;	 // same-topology rfwhip_set_mesh calls since the last build: an animated mesh (never written into the world tree)
 	// device skinning (rfwhip_set_mesh_skin / rfwhip_pose_mesh)
 	bool skinned = false, posed = false;
 	DevBuf d_base_verts, d_base_normals, d_joints, d_weights, d_vnormals, d_joint_mats;
@@ -332,6 +334,23 @@ struct InstRec
 	size_t mesh = 0;
 	float transform[16];
 	float normal[9];
+};
+
+// The WORLD TREE (rfwhip_update): the triangles of the static instances written out in world space under ONE tree.
+struct WorldRec
+{
+	bool valid = false;
+	std::vector<uint32_t> key;		   // what it was built from: (instance, mesh, mesh generation, transform) per member
+	std::vector<uint8_t> member;	   // per instance: its triangles are in the tree
+	std::vector<uint8_t> mesh_member;  // per mesh: its instances are (all of them, or none: membership is a property of the mesh)
+	std::vector<rt::Node4> n4;		   // relative entries, like MeshRec::n4
+	std::vector<f4> leaf_verts;		   // 3 per leaf slot: v0.w = primitive id (mesh order), v1.w = instance index
+	uint32_t root_first = 0, root_count = 0; // the root when it is a leaf (n4 empty)
+	size_t tris = 0;
+	int stack_need = 0;
+	float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+	uint32_t n4_base = 0, tri_base = 0;
+	bool resident = false; // placed in the scene-wide arrays by the last layout
 };
 
 enum KernelFamily
@@ -404,7 +423,10 @@ struct rfwhip_context
 	bool packet_ok = false; // the scene's trees fit the packet kernel's stack and its 32-bit node offsets
 	int streams = 4; // sub-batches of one render call that run concurrently on their own HIP streams
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
-	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly
+	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
+							// static instances that are used several times or transformed are written out in world space (world tree)
+	long long flatten_bytes = 1ll << 30; // ... as long as the world-space copy stays below this many bytes
+	WorldRec wtree;
 	int sample_group = 64; // slot layout: up to this many samples of a pixel share a wave (rt_core.h; the largest power of two
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample;
 						   // 64 = a wave is ONE pixel: primary wave 3.67 instead of 4.01 ms per 32 spp, depth-0 shadow wave -7 %)
@@ -647,7 +669,7 @@ extern "C" int rfwhip_cleanup(rfwhip_context *c)
 	if (c->stream)
 		(void)sync_all(c); // every stream of the context and a present still pending on a caller's stream
 	free_all(c);
-	c->meshes.clear(), c->instances.clear();
+	c->meshes.clear(), c->instances.clear(), c->wtree = WorldRec();
 	c->cleaned = true;
 	return RFWHIP_OK;
 }
@@ -881,6 +903,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	const f4 *V = (const f4 *)mesh->vertices;
 	if (same_topology)
 	{
+		m.refits++;
 		// animated mesh: same counts => refit on the device (EmbreeRT/src/Mesh.cpp:33-35, top_level_bvh.cpp:26)
 		for (size_t i = 0; i < mesh->triangleCount; i++)
 		{
@@ -932,6 +955,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 	// ... and until the build below has succeeded it describes NO tree (an error return leaves a mesh rfwhip_update() refuses,
 	// not the counts of the previous build beside freed or half-written arrays)
 	m.built = false, m.device_built = false, m.node_count2 = m.n4_count = 0, m.stack_need = 0;
+	m.generation++, m.refits = 0;
 	const size_t n = mesh->triangleCount;
 	bool device_built = false;
 	if (c->builder == 1 && n > (size_t)BLAS_MAX_LEAF)
@@ -1246,6 +1270,127 @@ static int ensure_nodes4f(rfwhip_context *c)
 	return 0;
 }
 
+// ---- the WORLD TREE -------------------------------------------------------------------------------------------------------------
+// The reference walks two levels for every ray: top-level leaf -> instance -> the ray in object space -> mesh tree -> back
+// (top_level_bvh.cpp:104-168).  A static instance needs none of that at run time: its triangles can be written out in WORLD space
+// once, per update, and then ALL static geometry hangs under ONE tree built over all of it — no instance switch (ray transform,
+// three reciprocals, a leaf phase in and one out per instance a ray's box test passes), no top-level tree over boxes that contain
+// each other (a room around its columns), one top-of-tree cache in LDS instead of several trees' tops.  Semantics kept: the hit
+// is the same triangle of the same instance at the same t (directions are not renormalised in the two-level walk, so t is shared;
+// here the triangle simply moved instead of the ray); primitive ids stay mesh-relative (v0.w) and the instance index travels in
+// v1.w, so shading still goes through the instance's record (normal matrix, shading records in object space).  For an instance
+// whose matrix is the identity the world-space vertices ARE the object-space ones and nothing a ray computes changes; for a
+// transformed one the triangle test sees M p instead of M^-1 o: the same numbers up to rounding.
+// Members: every instance of a mesh that was built on the host and is not animated (skinned, morphed, posed, or re-set with the same
+// topology since its build), as long as the copy stays below `flatten_bytes`.  When every member is an identity instance of a
+// singly used mesh the mesh trees are linked into the top-level tree instead (flat instances, below): same effect, no copy.
+// Animated meshes and meshes built on the device keep the two-level walk.  The tree is rebuilt only when its key — members, their
+// meshes' build generations, their matrices — changes (an animated scene's per-frame update leaves it alone).
+constexpr uint32_t WORLD_ID = 0xFFFFFFFFu;
+static int prepare_world(rfwhip_context *c, bool &changed)
+{
+	WorldRec &w = c->wtree;
+	changed = false;
+	std::vector<uint8_t> member(c->instances.size(), 0), mesh_member(c->meshes.size(), 0);
+	std::vector<uint32_t> key;
+	size_t tris = 0;
+	bool worth = false;
+	if (c->flat_instances != 0)
+	{
+		std::vector<uint32_t> uses(c->meshes.size(), 0u);
+		for (const InstRec &in : c->instances)
+			if (in.used && in.mesh < c->meshes.size() && c->meshes[in.mesh].used)
+				uses[in.mesh]++;
+		static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+		for (size_t i = 0; i < c->instances.size(); i++)
+		{
+			const InstRec &in = c->instances[i];
+			if (!in.used || in.mesh >= c->meshes.size() || !c->meshes[in.mesh].used)
+				continue;
+			const MeshRec &m = c->meshes[in.mesh];
+			if (!m.built || m.device_built || m.skinned || m.morphed || m.posed || m.refits != 0u || m.leaf_verts.size() != 3 * m.triCount || !m.triCount)
+				continue;
+			member[i] = 1, mesh_member[in.mesh] = 1, tris += m.triCount;
+			if (memcmp(in.transform, ident, sizeof(ident)) != 0 || uses[in.mesh] > 1u)
+				worth = true;
+			key.push_back((uint32_t)i), key.push_back((uint32_t)in.mesh), key.push_back(m.generation);
+			for (int k = 0; k < 16; k++)
+			{
+				uint32_t b;
+				memcpy(&b, &in.transform[k], 4);
+				key.push_back(b);
+			}
+		}
+	}
+	const unsigned long long bytes = (unsigned long long)tris * (3 * sizeof(f4) + sizeof(rt::Node4c)); // (at most one 4-wide node per triangle)
+	if (!worth || !tris || bytes > (unsigned long long)c->flatten_bytes)
+	{
+		std::fill(member.begin(), member.end(), 0), std::fill(mesh_member.begin(), mesh_member.end(), 0);
+		key.clear(), tris = 0;
+	}
+	if (key == w.key && w.member.size() == member.size())
+		return 0; // as built (or, if that build was refused, as refused)
+	changed = true;
+	w = WorldRec();
+	w.key = key;
+	w.member.assign(member.size(), 0), w.mesh_member.assign(mesh_member.size(), 0);
+	if (key.empty())
+		return 0;
+	// the members' triangles in world space (leaf order of their meshes: any order does), with what a hit record needs
+	std::vector<f4> verts(3 * tris);
+	std::vector<float> bmin(3 * tris), bmax(3 * tris);
+	size_t t = 0;
+	for (size_t i = 0; i < c->instances.size(); i++)
+	{
+		if (!member[i])
+			continue;
+		const InstRec &in = c->instances[i];
+		const MeshRec &m = c->meshes[in.mesh];
+		const float *M = in.transform; // column-major 4x4, like the instance boxes below
+		const uint32_t ii = (uint32_t)i;
+		float iw;
+		memcpy(&iw, &ii, 4);
+		for (size_t s = 0; s < m.triCount; s++, t++)
+		{
+			for (int k = 0; k < 3; k++)
+			{
+				const f4 &p = m.leaf_verts[3 * s + k];
+				f4 q;
+				q.x = M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12];
+				q.y = M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13];
+				q.z = M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14];
+				q.w = k == 0 ? p.w : (k == 1 ? iw : 1.0f); // v0.w: primitive id (mesh order), v1.w: instance
+				verts[3 * t + k] = q;
+			}
+			const f4 &a = verts[3 * t], &b = verts[3 * t + 1], &d = verts[3 * t + 2];
+			// per-triangle box grown by 1e-5 (bvh_tree.cpp:407-412), as rfwhip_set_mesh does
+			bmin[3 * t + 0] = std::min(a.x, std::min(b.x, d.x)) - 1e-5f, bmax[3 * t + 0] = std::max(a.x, std::max(b.x, d.x)) + 1e-5f;
+			bmin[3 * t + 1] = std::min(a.y, std::min(b.y, d.y)) - 1e-5f, bmax[3 * t + 1] = std::max(a.y, std::max(b.y, d.y)) + 1e-5f;
+			bmin[3 * t + 2] = std::min(a.z, std::min(b.z, d.z)) - 1e-5f, bmax[3 * t + 2] = std::max(a.z, std::max(b.z, d.z)) + 1e-5f;
+		}
+	}
+	bvh::Result tree;
+	bvh::build(bmin.data(), bmax.data(), tris, BLAS_MAX_LEAF, BLAS_DEPTH_LIMIT, tree);
+	const bool inner = bvh::collapse4(tree, false, w.n4);
+	w.stack_need = bvh::stack_need4(w.n4);
+	if (w.stack_need > BLAS_STACK_BUDGET)
+	{
+		// (a tree this deep is refused like a mesh's would be; the instances keep the two-level walk.  The key stays: no retry per update)
+		w.n4.clear(), w.stack_need = 0;
+		return 0;
+	}
+	if (!inner)
+		w.root_first = (uint32_t)tree.nodes[0].left_first, w.root_count = (uint32_t)tree.nodes[0].count;
+	w.leaf_verts.resize(3 * tris);
+	for (size_t s = 0; s < tris; s++)
+		for (int k = 0; k < 3; k++)
+			w.leaf_verts[3 * s + k] = verts[3 * (size_t)tree.order[s] + k];
+	for (int a = 0; a < 3; a++)
+		w.bmin[a] = tree.nodes[0].bmin[a], w.bmax[a] = tree.nodes[0].bmax[a];
+	w.tris = tris, w.member = member, w.mesh_member = mesh_member, w.valid = true;
+	return 0;
+}
+
 extern "C" int rfwhip_update(rfwhip_context *c)
 {
 	CTX_ENTER(c);
@@ -1264,10 +1409,15 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	for (auto &in : c->instances)
 		if (in.used)
 			live_instances++;
-	const size_t tlas_reserve = live_instances + 2; // a 4-wide tree over n single-instance leaves has < n inner nodes
+	const size_t tlas_reserve = live_instances + 3; // a 4-wide tree over n single-instance leaves (+ the world tree's) has < n inner nodes
 	for (auto &m : c->meshes)
 		if (m.used && m.dirty)
 			relayout = true;
+	bool world_changed = false;
+	RF_TRY(prepare_world(c, world_changed));
+	if (world_changed)
+		relayout = true;
+	WorldRec &world = c->wtree;
 	if (c->blas_nodes4 + tlas_reserve > c->node4_capacity)
 		relayout = true; // the TLAS lives behind the BLAS nodes in the same array: grow it together
 	if (relayout)
@@ -1280,6 +1430,14 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				m.n4_base = (uint32_t)nodes4;
 				nodes += m.node_count2, tris += m.triCount, nodes4 += m.n4_count;
 			}
+		// the world tree's nodes and world-space triangles follow the meshes' (shading records stay per mesh, in object space)
+		const size_t mesh_tris = tris, mesh_nodes4 = nodes4;
+		world.resident = false;
+		if (world.valid)
+		{
+			world.n4_base = (uint32_t)nodes4, world.tri_base = (uint32_t)tris;
+			nodes4 += world.n4.size(), tris += world.tris;
+		}
 		if (tris > rt::ENTRY_FIRST_MASK)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^27 triangles in the scene");
 		c->blas_nodes4 = nodes4;
@@ -1288,9 +1446,9 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 			return set_error(RFWHIP_ERR_UNSUPPORTED, "more than 2^26 4-wide nodes (the traversal addresses them by 32-bit byte offsets)");
 		RF_TRY(c->d_nodes.ensure(nodes * sizeof(rt::Node)));
 		RF_TRY(c->d_nodes4.ensure(c->node4_capacity * sizeof(rt::Node4c)));
-		RF_TRY(c->d_nodes4_src.ensure(4 * nodes4 * sizeof(uint32_t)));
+		RF_TRY(c->d_nodes4_src.ensure(4 * mesh_nodes4 * sizeof(uint32_t)));
 		RF_TRY(c->d_tri_verts.ensure(3 * tris * sizeof(f4)));
-		RF_TRY(c->d_tri_shade.ensure(tris * sizeof(rt::TriShade)));
+		RF_TRY(c->d_tri_shade.ensure(mesh_tris * sizeof(rt::TriShade)));
 		// One mesh at a time.  Device form everywhere: left_first / entries carry ready-made stack entries (rt::make_entry)
 		// with ABSOLUTE indices — node index into the scene-wide arrays, leaf-ordered triangle index into tri_verts.
 		std::vector<rt::Node> nodes2;
@@ -1348,6 +1506,28 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				RF_TRY(dm::sync(c->stream)); // the staging vectors are reused by the next mesh
 			}
 			RF_TRY(dm::h2d(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.shade.data(), m.shade.size() * sizeof(rt::TriShade), c->stream));
+		}
+		if (world.valid)
+		{
+			nodes4c.resize(world.n4.size());
+			for (size_t k = 0; k < world.n4.size(); k++)
+			{
+				rt::Node4 nd = world.n4[k];
+				for (int j = 0; j < 4; j++)
+				{
+					const uint32_t e = nd.entry[j];
+					if (e == rt::ENTRY_EMPTY)
+						continue;
+					if (e & rt::ENTRY_LEAF)
+						nd.entry[j] = (e & ~rt::ENTRY_FIRST_MASK) | (((e & rt::ENTRY_FIRST_MASK) + world.tri_base) & rt::ENTRY_FIRST_MASK);
+					else
+						nd.entry[j] = e + world.n4_base;
+				}
+				nodes4c[k] = compress4(nd);
+			}
+			RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4c>() + world.n4_base, nodes4c.data(), nodes4c.size() * sizeof(rt::Node4c), c->stream));
+			RF_TRY(dm::h2d(c->d_tri_verts.as<f4>() + 3ull * world.tri_base, world.leaf_verts.data(), world.leaf_verts.size() * sizeof(f4), c->stream));
+			world.resident = true;
 		}
 		RF_TRY(dm::sync(c->stream));
 		// meshes that had been refit since their build are re-refit from their device vertices after the move
@@ -1408,6 +1588,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				lo[r] = std::min(lo[r], w), hi[r] = std::max(hi[r], w);
 			}
 		}
+		if (world.valid && world.member[i])
+			continue; // its triangles hang in the world tree: no top-level leaf of its own
 		for (int r = 0; r < 3; r++)
 		{
 			const float pad = 1e-4f + 1e-5f * std::max(std::fabs(lo[r]), std::fabs(hi[r]));
@@ -1415,6 +1597,15 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		}
 		live.push_back((uint32_t)i);
 	}
+	if (world.valid)
+	{
+		for (int r = 0; r < 3; r++)
+			bmin.push_back(world.bmin[r]), bmax.push_back(world.bmax[r]);
+		live.push_back(WORLD_ID); // ONE top-level leaf for all of it, replaced by the entry of the world tree's root below
+	}
+	const uint32_t world_root_entry = !world.valid		 ? 0u
+									  : !world.n4.empty() ? rt::make_entry((int)world.n4_base, -1, false)
+														  : rt::make_entry((int)(world.root_first + world.tri_base), (int)world.root_count, false);
 	bvh::Result tl;
 	bvh::build(bmin.data(), bmax.data(), live.size(), 1, TLAS_DEPTH_LIMIT, tl);
 	std::vector<uint32_t> tprims(std::max<size_t>(1, live.size()), 0u);
@@ -1424,9 +1615,10 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	const bool tl_inner = bvh::collapse4(tl, true, tl4);
 	{
 		const int tlas_need = bvh::stack_need4(tl4);
-		int blas_need = 0;
+		int blas_need = world.valid ? world.stack_need : 0;
 		for (uint32_t i : live)
-			blas_need = std::max(blas_need, c->meshes[c->instances[i].mesh].stack_need);
+			if (i != WORLD_ID)
+				blas_need = std::max(blas_need, c->meshes[c->instances[i].mesh].stack_need);
 		// the packet form of the primary wave keeps ONE stack of PACKET_STACK entries per wave (kernels.hip: PacketStack)
 		c->packet_ok = tlas_need + 1 + blas_need <= (int)rtk::PACKET_STACK;
 		if (tlas_need + 1 + blas_need > rt::STACK_CAPACITY)
@@ -1446,10 +1638,13 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	{
 		std::vector<uint32_t> uses(c->meshes.size(), 0u);
 		for (uint32_t i : live)
-			uses[c->instances[i].mesh]++;
+			if (i != WORLD_ID)
+				uses[c->instances[i].mesh]++;
 		static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 		for (uint32_t i : live)
 		{
+			if (i == WORLD_ID)
+				continue;
 			bool id = uses[c->instances[i].mesh] == 1u && c->flat_instances != 0;
 			for (int k = 0; k < 12 && id; k++)
 				id = inst[i].inv[k] == ident[k];
@@ -1460,6 +1655,8 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		if (e == rt::ENTRY_EMPTY || !(e & rt::ENTRY_LEAF))
 			return e;
 		const uint32_t ii = tprims[e & rt::ENTRY_FIRST_MASK];
+		if (ii == WORLD_ID)
+			return world_root_entry;
 		return flat[ii] ? inst[ii].root_entry : e;
 	};
 	for (rt::Node4 &nd : tl4)
@@ -1471,7 +1668,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				nd.entry[j] = flat_entry(nd.entry[j]);
 		}
 	for (uint32_t i : live)
-		if (flat[i])
+		if (i != WORLD_ID && flat[i])
 		{
 			const MeshRec &m = c->meshes[c->instances[i].mesh];
 			rtk::launch_stamp_instance(c->d_tri_verts.as<f4>() + 3ull * m.tri_base, (uint32_t)m.triCount, i, c->stream);
@@ -1484,7 +1681,11 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	for (size_t k = 0; k < tl4.size(); k++)
 		tl4c[k] = compress4(tl4[k]);
 	RF_TRY(dm::h2d(c->d_nodes4.as<rt::Node4c>() + tlas_base, tl4c.data(), tl4c.size() * sizeof(rt::Node4c), c->stream));
-	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims.data(), tprims.size() * 4, c->stream));
+	std::vector<uint32_t> tprims_dev = tprims; // (the world tree's top-level slot is never looked up: its leaf entry was replaced above)
+	for (uint32_t &tp : tprims_dev)
+		if (tp == WORLD_ID)
+			tp = 0u;
+	RF_TRY(dm::h2d(c->d_tlas_prims.p, tprims_dev.data(), tprims_dev.size() * 4, c->stream));
 	// the float form of every traversal node (mesh trees as rebuilt / refitted above + the top-level tree): one streaming pass
 	// (only when the packet form of the primary wave — its one reader — can run: the table is twice the compressed one's size)
 	c->packet_ok = c->packet_ok && (tlas_base + tl4c.size()) * sizeof(rt::Node4f) < (1ull << 32);
@@ -1665,14 +1866,21 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	// LDS top-of-tree cache: the first nodes (breadth-first top, bvh::collapse4) of the BLAS with the most nodes
 	p.lds_first = 0, p.lds_count = 0;
 	{
-		const MeshRec *big = nullptr;
-		for (const auto &m : c->meshes)
-			if (m.used && m.n4_count && (!big || m.n4_count > big->n4_count))
-				big = &m;
+		// (... among the trees the rays walk: the meshes whose instances went into the world tree are not among them; that tree is)
+		uint32_t big_base = 0, big_count = 0;
+		for (size_t mi = 0; mi < c->meshes.size(); mi++)
+		{
+			const MeshRec &m = c->meshes[mi];
+			const bool in_world = c->wtree.valid && mi < c->wtree.mesh_member.size() && c->wtree.mesh_member[mi];
+			if (m.used && !in_world && m.n4_count > big_count)
+				big_base = (uint32_t)m.n4_base, big_count = m.n4_count;
+		}
+		if (c->wtree.valid && c->wtree.resident && c->wtree.n4.size() > big_count)
+			big_base = c->wtree.n4_base, big_count = (uint32_t)c->wtree.n4.size();
 		const uint32_t cap = rtk::max_lds_nodes();
 		const uint32_t want = c->lds_nodes < 0 ? cap : std::min<uint32_t>((uint32_t)c->lds_nodes, cap);
-		if (big && want)
-			p.lds_first = (uint32_t)big->n4_base, p.lds_count = std::min<uint32_t>(want, big->n4_count);
+		if (big_count && want)
+			p.lds_first = big_base, p.lds_count = std::min<uint32_t>(want, big_count);
 	}
 	p.refill = (uint32_t)c->refill & ((c->packet_ok && c->nodes4f_current) ? 15u : 7u);
 	p.textured = c->textured ? 1u : 0u;
@@ -2258,7 +2466,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "fuse"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2326,6 +2534,11 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->refill = atoi(value) & 15;
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
+	else if (k == "flatten_bytes")
+	{
+		c->flatten_bytes = std::max(0ll, atoll(value));
+		c->scene_dirty = true;
+	}
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);
@@ -2401,6 +2614,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->fuse);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
+	else if (k == "flatten_bytes")
+		snprintf(value, cap, "%lld", c->flatten_bytes);
 	else if (k == "sub_batch_paths")
 		snprintf(value, cap, "%lld", c->sub_batch_paths);
 	else if (k == "ring")

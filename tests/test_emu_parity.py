@@ -413,13 +413,15 @@ def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geo
     """An identity-transform instance of a singly used mesh is linked into the top-level tree directly (rfwhip_update, "flat"
     instances): image, primary hits with their instance ids and wave counts are those of the two-level walk, in a scene that
     mixes such instances (the room, the emitter quad) with transformed instances of a shared mesh (the boxes); the oracle
-    always walks two levels."""
+    always walks two levels.  With the world tree (round 5, the default) the boxes' triangles are written out in world space."""
     scene = pkg.scenes.cornell(70, 51, geometric_emitter=geometric_emitter)
     out = []
-    for flat in (1, 0):
+    # (flatten_bytes = 0: no world tree — the transformed boxes keep the two-level walk, only the identity instances are linked)
+    for flat, flatten in ((1, 0), (0, 0), (1, 1 << 30)):
         c = make_emu()
         c.init(70, 51)
         c.set_setting("flat_instances", flat)
+        c.set_setting("flatten_bytes", flatten)
         scene.upload(c)
         for k, v in {"integrator": "pt", "spp": 6, "max_depth": 3}.items():
             c.set_setting(k, v)
@@ -431,6 +433,17 @@ def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geo
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
     assert out[0][2] == out[1][2]
     assert 0 in set(np.unique(out[0][1]["inst"])) and {1, 2} <= set(np.unique(out[0][1]["inst"]))
+    # The WORLD TREE (the default): the static instances' triangles in world space under one tree.  Same triangle of the same
+    # instance everywhere; the transformed boxes' hits are computed on M p instead of M^-1 o, so t agrees to rounding, not to
+    # the bit, and a path here and there decides differently.
+    w = out[2]
+    assert np.array_equal(w[1]["inst"], out[1][1]["inst"]) and np.array_equal(w[1]["prim"], out[1][1]["prim"])
+    hit = w[1]["prim"] >= 0
+    assert (np.abs(w[1]["t"][hit] - out[1][1]["t"][hit]) <= 2e-6 * out[1][1]["t"][hit]).all()
+    d = np.sqrt(((w[0][..., :3].astype(np.float64) - out[1][0][..., :3]) ** 2).sum(-1))
+    assert (d > 1e-3).mean() <= 2e-2, (d > 1e-3).mean()
+    for x, y in zip(w[2], out[1][2]):
+        assert abs(x - y) <= 3e-3 * max(y, 1), (w[2], out[1][2])
     e, o = make_emu(), make_oracle()
     _run(pkg, [e, o], pkg.scenes.cornell(96, 64, geometric_emitter=geometric_emitter), 96, 64, {"integrator": "parity", "jitter": "center"})
     a, b = e.primary_hits(), o.primary_hits()

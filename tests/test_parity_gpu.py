@@ -596,21 +596,23 @@ def test_flat_instances_leave_every_result_alone_on_the_gpu(pkg, make_hip, scene
     """Identity instances linked into the top-level tree directly (rfwhip_update, "flat" instances) against the two-level walk
     of every instance, on the device: atrium = an identity room beside 45 transformed instances of shared meshes, terrain = the
     bench scene's two identity instances.  Image, primary hits (instance ids included) and wave sizes are bit-equal; a mesh
-    refit in between (it rewrites the triangle records that carry the instance index) changes nothing either."""
+    refit in between (it rewrites the triangle records that carry the instance index) changes nothing either.  Then the world
+    tree (below)."""
     w, h = 480, 270
     scene = pkg.scenes.atrium(w, h) if scene_name == "atrium" else pkg.scenes.terrain(n=200, width=w, height_px=h)
     out = []
-    for flat in (1, 0):
+    for flat, flatten in ((1, 0), (0, 0), (1, 1 << 30)):  # (flatten_bytes = 0: no world tree, identity instances linked only)
         c = make_hip()
         c.init(w, h)
         c.set_setting("flat_instances", flat)
+        c.set_setting("flatten_bytes", flatten)
         scene.upload(c)
         for k, v in {"integrator": "pt", "spp": 8, "max_depth": 3}.items():
             c.set_setting(k, v)
         c.render_frame(scene.camera, pkg.RESET)
         st = c.get_stats()
         out.append((c.framebuffer(), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
-        if flat:  # same vertices again = a refit of a flat instance's mesh (unchanged counts): the image must not move
+        if flat and not flatten:  # same vertices again = a refit of a flat instance's mesh (unchanged counts): the image must not move
             uses = [sum(1 for i in scene.instances if i["mesh"] == k) for k in range(len(scene.meshes))]
             mi = next(i["mesh"] for i in scene.instances if uses[i["mesh"]] == 1 and np.array_equal(i["transform"], np.eye(4)))
             m = scene.meshes[mi]
@@ -625,6 +627,29 @@ def test_flat_instances_leave_every_result_alone_on_the_gpu(pkg, make_hip, scene
     assert out[0][2] == out[1][2]
     insts = set(np.unique(out[0][1]["inst"])) - {-1}
     assert len(insts) >= 2, insts
+    # The world tree (round 5, the default): static instances written out in world space under one tree.  The terrain's two
+    # identity instances are linked as before (bit-equal); the atrium's 45 transformed columns are tested as M p instead of through
+    # M^-1 o: the same triangle of the same instance on all but a handful of silhouette pixels, t to rounding, the image to the
+    # statistics of a path tracer whose decisions see last-bit differences.
+    wt, two = out[2], out[1]
+    if scene_name != "atrium":
+        assert np.array_equal(wt[0], two[0]) and wt[2] == two[2]
+    else:
+        same = (wt[1]["inst"] == two[1]["inst"]) & (wt[1]["prim"] == two[1]["prim"])
+        assert (~same).mean() <= 2e-4, (~same).sum()
+        hit = same & (wt[1]["prim"] >= 0)
+        rel = np.abs(wt[1]["t"][hit] - two[1]["t"][hit]) / two[1]["t"][hit]
+        print("world tree vs two-level walk: %d of %d primary hits on another triangle, t within %.2e relative" % ((~same).sum(), same.size, rel.max()))
+        # (grazing hits are ill-conditioned: a last-bit difference of the vertices moves their t by far more than a last bit)
+        assert np.quantile(rel, 0.999) <= 5e-6 and rel.max() <= 1e-3, (np.quantile(rel, 0.999), rel.max())
+        frac3, rmse, d = image_stats(wt[0], two[0], 3e-2)
+        # (most pixels of this scene see a transformed instance, at depth 3: 6 % of them hold a path that decided differently
+        # somewhere — a texel, a light, a survival test; 0.3 % moved by more than 3e-2; nothing is biased, below)
+        print("world tree vs two-level walk: %.4f of the pixels beyond 1e-3, %.4f beyond 3e-2" % ((d > 1e-3).mean(), frac3))
+        assert (d > 1e-3).mean() <= 8e-2 and frac3 <= 1e-2, ((d > 1e-3).mean(), frac3)
+        assert abs(wt[0][..., :3].mean() - two[0][..., :3].mean()) <= 2e-3 * two[0][..., :3].mean()
+        for x, y in zip(wt[2], two[2]):
+            assert abs(x - y) <= 2e-3 * max(y, 1), (wt[2], two[2])
 
 
 def test_skipped_depth0_connections_leave_no_stale_terms_on_the_gpu(pkg, make_hip, make_oracle):
