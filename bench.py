@@ -30,6 +30,8 @@ import argparse
 import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -47,8 +49,38 @@ LANE_LOADS_PEAK = 600.0e9
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 NODE_BYTES = 64.0  # rt::Node4c: four 16-byte rows (csrc/rt_types.h) — also SURVEY §8(d)'s "64 B per popped inner node"
 NODE_ROWS = 4.0
-STAGE_KERNELS = {"primary": "k_primary_packet<false>", "bounce": "k_trace_stream<false, false>",
-                 "shadow": "k_trace_stream<true, false>", "shade": "k_shade_pt<false>"}
+def stage_kernels(ctx, sample_group):
+    """The kernels a pt render call launches for each stage, from what the library says about its variants (read-only settings):
+    the textured shade kernel when some material carries a map, the packet form of the primary wave when the scene's trees fit its
+    stack and the samples of a pixel sit side by side (sample groups >= 2).  bounce / shadow: the kernels of the un-fused launches
+    (fuse=0: the per-stage table and the counter passes); the default launches both bodies as ONE kernel per depth, `fused`."""
+    textured = ctx.get_setting("textured") == "1"
+    packet = ctx.get_setting("packet") == "1" and sample_group >= 2
+    return {"primary": "k_primary_packet<false>" if packet else "k_extend<1, false>", "bounce": "k_trace_stream<false, false>",
+            "shadow": "k_trace_stream<true, false>", "shade": "k_shade_pt<true>" if textured else "k_shade_pt<false>",
+            "fused": "k_trace_fused<false>"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def oracle_flags():
+    """Compiler and flags of the cpu_baseline's library, from oracle/Makefile (no -march=native: the prebuilt .so travels to the GPU box)."""
+    try:
+        txt = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        cc = re.search(r"^CC\s*\?=\s*(\S+)", txt, re.M).group(1)
+        fl = re.search(r"^CFLAGS\s*\?=\s*(.+)$", txt, re.M).group(1).strip()
+        ver = subprocess.run([cc, "-dumpfullversion"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.strip()
+        return "%s %s %s" % (cc, ver, fl)
+    except Exception:
+        return None
 
 
 def usable_cores():
@@ -352,11 +384,14 @@ def main():
                 ctx.deinterleave_device(gathered_flat.data_ptr(), full_fb.data_ptr())
             gather_ms.append((time.perf_counter() - t) * 1e3)
 
+    local_done = [0.0]  # when THIS rank's own work of the region was done (before it waits for the others at the barrier)
+
     def fence():
         ctx.wait()
         if comm is not None:
             comm.wait()
         torch.cuda.synchronize()
+        local_done[0] = time.perf_counter()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -373,10 +408,39 @@ def main():
         step(k, k == 0)
     fence()
     elapsed = time.perf_counter() - t_start
+    ranks_info = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # so that a bad first scaling curve explains itself in one run: every rank's OWN time per step (its renders, its send,
+        # on the root the receives and the de-interleave — up to where it starts waiting for the others), and the gather alone
+        own = torch.zeros(world, dtype=torch.float64, device="cpu" if one_device else dev)
+        own[rank] = (local_done[0] - t_start) / args.steps * 1e3
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+        own = [round(float(x), 4) for x in own.tolist()]
+        probe = None
+        if comm is not None:
+            # the gather of a finished frame, enqueue to done, with nothing else in flight: present + send on every rank,
+            # world - 1 receives + the de-interleave on the root (xGMI: 33 MB / world per peer link)
+            times = []
+            for _ in range(3):
+                ctx.render_async(scene.camera, pkg.CONVERGE)
+                ctx.wait()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                comm.gather(full_fb.data_ptr() if rank == 0 else 0)
+                comm.wait()
+                times.append((time.perf_counter() - t0) * 1e3)
+            pg = torch.zeros(world, dtype=torch.float64, device="cpu" if one_device else dev)
+            pg[rank] = sorted(times)[1]
+            dist.all_reduce(pg, op=dist.ReduceOp.SUM)
+            probe = [round(float(x), 4) for x in pg.tolist()]
+        ranks_info = {"ms_per_step_own": own, "ms_per_step_own_min": min(own), "ms_per_step_own_max": max(own),
+                      "note": "a rank's own time per step up to its fence (before the barrier); ms_per_step is the max over ranks of the time to the barrier",
+                      "gather_enqueue_to_done_ms": probe,
+                      "gather_note": "median of 3: gather of a finished frame alone (present + ncclSend per rank; root: world - 1 ncclRecv + de-interleave), per rank" if probe else None}
     if world == 1:
         ctx.read_framebuffer_device(full_fb.data_ptr())
     kernel_times = {name: ctx.get_kernel_time(name) for name in ctx.KERNELS}
@@ -454,6 +518,27 @@ def main():
         ctx.set_setting("fuse", int(extra.get("fuse", 1)))
         ser = {"primary": acc["primaryTime"], "bounce": acc["secondaryTime"] + acc["deepTime"], "shadow": acc["shadowTime"],
                "shade": acc["shadeTime"], "resolve": acc["finalizeTime"]}
+        # ... and once more as the product launches them: extension rays of depth d + 1 and shadow rays of depth d in ONE kernel per
+        # depth (k_trace_fused; its time is billed to the extend stage of depth d + 1: secondaryTime + deepTime), still one
+        # sub-batch alone on the chip — what the default command's kernel trace shows per kernel, without the other sub-batches
+        fused_ms = None
+        if int(extra.get("fuse", 1)) and (args.refill & 3) == 3 and args.max_depth >= 1:
+            ctx.set_setting("streams", 1)
+            ctx.set_setting("spp", sub_spp)
+            ctx.set_setting("overlap", 0)
+            ctx.set_setting("fuse", 1)
+            ctx.render_frame(scene.camera, pkg.RESET)
+            facc = {}
+            for k in range(ser_frames):
+                ctx.render_frame(scene.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+                st1 = ctx.get_stats().as_dict()
+                for key in ("primaryTime", "secondaryTime", "deepTime", "shadowTime", "shadeTime", "finalizeTime"):
+                    facc[key] = facc.get(key, 0.0) + st1[key] / ser_frames
+            ctx.set_setting("streams", args.streams)
+            ctx.set_setting("spp", args.spp)
+            ctx.set_setting("overlap", args.overlap)
+            fused_ms = {"primary": facc["primaryTime"], "fused": facc["secondaryTime"] + facc["deepTime"] + facc["shadowTime"],
+                        "shade": facc["shadeTime"], "resolve": facc["finalizeTime"]}
         frac_of_step = 1.0 / subs  # one sub-batch = 1 / subs of a step's samples
         algo = {"primary": algo_primary * frac_of_step, "bounce": algo_bounce * frac_of_step,
                 "shadow": algo_shadow * frac_of_step, "shade": algo_shade * frac_of_step}
@@ -462,6 +547,7 @@ def main():
         # served from LDS / L1 / L2 / the Infinity Cache (their algorithmic byte rate exceeds the HBM peak: "cache_served"); the
         # shade kernel streams the path state and is the one stage whose time is HBM bytes
         bound = {"primary": "valu", "bounce": "valu", "shadow": "valu", "shade": "hbm"}
+        STAGE_KERNELS = stage_kernels(ctx, int(ctx.get_setting("sample_group")))
         pm, fresh = load_stage_counters(args.stage_json, scene.name, args.spp, args.streams)
         source = None
         if pm:
@@ -516,12 +602,16 @@ def main():
         if kres and kres.get("hbm_bytes_per_dispatch") and chip_hbm_bytes_per_step is not None:
             chip_hbm_bytes_per_step += kres["hbm_bytes_per_dispatch"]
 
-        # ---- the headline: the largest kernel by time — the shade kernel — against the HBM roofline ------------------------------
-        # achieved = algorithmic bytes per launch / mean duration of a launch, hipEvents on the launch's own stream, measured live in
-        # this process with every launch ALONE on the chip (the serialised leg above: one 64-spp sub-batch per call on one stream,
-        # the host waiting per frame) — the roofline of the kernel.  Inside the timed region four sub-batches are in flight: a launch
-        # shares the chip, its duration stretches with the company it has, and the durations of a step add up to more than the
-        # step; those figures are reported beside it (`in_timed_region`), and the chip as a whole below (`chip`).
+        # ---- the headline: the kernel that DOMINATES the default command, by the time its launches take alone on the chip ------------
+        # (round 4's verdict: the shade kernel was "largest" only because the measurement leg un-fused the kernel the product really
+        # runs).  Candidates are the kernels as the product launches them — the packet primary wave, k_trace_fused (extension rays of
+        # depth d + 1 and shadow rays of depth d: one launch per depth), the shade kernel, the resolve — timed one sub-batch at a time
+        # with hipEvents on the launch's own stream (the fused serialised leg above; the same kernels under rocprofv3 --kernel-trace
+        # of the default command: profiles/r05*_kernel_stats.md).  On the bench scene that is k_trace_fused: bound by VALU issue at
+        # half-full waves, its bytes served by LDS / L1 / L2 / the Infinity Cache — `achieved` (algorithmic bytes per launch over the
+        # launch's duration) EXCEEDS the HBM peak, `cache_served`, and says nothing about how good the kernel is; what does is in
+        # `valu`: wave-instructions per second against the issue ceilings, lanes per instruction, and the counters' HBM bytes.
+        # The one stage whose time IS bytes, the shade kernel, keeps round 4's figures under `hbm_kernel`.
         shade_ms_total, shade_launches = kernel_times["shade"]
         launches_per_step = shade_launches / max(1, args.steps)
         bytes_per_launch = algo_shade / max(1.0, launches_per_step)
@@ -533,28 +623,75 @@ def main():
         busy_ms = sum(kernel_times[name][0] for name in ctx.KERNELS)
         step_ms = elapsed / args.steps * 1e3
         kernel_share = {k: round(v / max(1e-9, sum(ser.values())), 4) for k, v in ser.items()}
-        roofline = {
-            "bound": "hbm", "kernel": "k_shade_pt<false> — the largest kernel by time (%.0f %% of a sub-batch's serialised kernel time)" % (100 * kernel_share["shade"]),
+        hbm_kernel = {
+            "bound": "hbm", "kernel": STAGE_KERNELS["shade"],
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": source,
+            "traffic": traffic,
             "traffic_frac_of_peak": round(traffic / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and ms_per_launch > 0) else None,
             "traffic_over_algorithmic": round(traffic / bytes_per_launch, 3) if traffic else None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": round(ms_per_launch, 4),
-            "ms_per_launch_clock": "hip events on the launch's stream; %d-spp sub-batch, every launch alone on the chip (streams=1, host waits per frame), this process" % sub_spp,
             "launches_per_step": launches_per_step,
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 5),
             "in_timed_region": {"ms_per_launch": round(ms_in_region, 4), "launches_timed": shade_launches,
                                 "achieved": round(bytes_per_launch / (ms_in_region * 1e-3) / 1e9, 2) if ms_in_region > 0 else None,
-                                "frac": round(bytes_per_launch / (ms_in_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_in_region > 0 else None,
-                                "kernels_in_flight": round(busy_ms / (elapsed * 1e3), 3) if elapsed > 0 else None,
-                                "note": "%d sub-batches in flight: the launch shares the chip (what rocprofv3 --kernel-trace of the default command shows)" % subs},
+                                "frac": round(bytes_per_launch / (ms_in_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_in_region > 0 else None},
+            "cross_checks": {"kernel_ms_per_step": round(ms_per_launch * launches_per_step, 3),
+                             "kernel_time_fits_step": bool(ms_per_launch * launches_per_step <= step_ms),
+                             "algorithmic_gbs_over_the_step": round(algo_shade / (step_ms * 1e-3) / 1e9, 1),
+                             "algorithmic_rate_below_peak": bool(algo_shade / (step_ms * 1e-3) / 1e9 <= HBM_PEAK_GBS)}}
+        # the candidates' times per sub-batch, alone on the chip, as the product launches them
+        cand = dict(fused_ms) if fused_ms else {"primary": ser["primary"], "bounce": ser["bounce"], "shadow": ser["shadow"],
+                                                "shade": ser["shade"], "resolve": ser["resolve"]}
+        dom = max(cand, key=lambda k: cand[k])
+        dom_kernel = {"primary": STAGE_KERNELS["primary"], "fused": STAGE_KERNELS["fused"], "bounce": STAGE_KERNELS["bounce"],
+                      "shadow": STAGE_KERNELS["shadow"], "shade": STAGE_KERNELS["shade"], "resolve": "k_resolve"}[dom]
+        dom_launches = {"primary": 1, "fused": args.max_depth, "bounce": args.max_depth, "shadow": args.max_depth,
+                        "shade": args.max_depth + 1, "resolve": 1}[dom]
+        dom_parts = {"fused": ("bounce", "shadow")}.get(dom, (dom,))  # the stage entries whose bodies the kernel runs
+        dom_algo = sum(algo.get(q, 0.0) for q in dom_parts)          # algorithmic bytes per sub-batch
+        dom_ms = cand[dom]
+        dom_bound = "hbm" if dom in ("shade", "resolve") else "valu"
+        ent_of = {e["stage"]: e for e in stages}
+        dom_hbm = sum((ent_of[q].get("counter_hbm_bytes_per_sub_batch") or 0.0) for q in dom_parts if q in ent_of) or None
+        dom_insts = sum((ent_of[q].get("valu_wave_insts_per_sub_batch") or 0.0) for q in dom_parts if q in ent_of) or None
+        dom_lane_insts = sum((ent_of[q].get("valu_wave_insts_per_sub_batch") or 0.0) * (ent_of[q].get("valu_lanes_active_of_64") or 0.0)
+                             for q in dom_parts if q in ent_of) or None
+        dom_ach = dom_algo / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom_rate = dom_insts / (dom_ms * 1e-3) if (dom_insts and dom_ms > 0) else None
+        roofline = {
+            "bound": dom_bound,
+            "kernel": "%s — the largest kernel of the default command by time: %.0f %% of a sub-batch's kernel time, every launch alone on the chip (%s)" % (
+                dom_kernel, 100.0 * dom_ms / max(1e-9, sum(cand.values())),
+                ", ".join("%s %.2f ms" % (k, v) for k, v in sorted(cand.items(), key=lambda kv: -kv[1]))),
+            "achieved": round(dom_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 5),
+            # above the HBM peak: the bytes the algorithm asks for come out of LDS, L1, L2 and the Infinity Cache
+            "cache_served": bool(dom_ach > HBM_PEAK_GBS),
+            "traffic": int(dom_hbm / dom_launches) if dom_hbm else None, "traffic_source": source,
+            "traffic_frac_of_peak": round(dom_hbm / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (dom_hbm and dom_ms > 0) else None,
+            "traffic_over_algorithmic": round(dom_hbm / dom_algo, 3) if (dom_hbm and dom_algo > 0) else None,
+            "algorithmic_bytes_per_launch": dom_algo / dom_launches, "ms_per_launch": round(dom_ms / dom_launches, 4),
+            "ms_per_launch_clock": "hip events on the launch's stream; %d-spp sub-batch, every launch alone on the chip (streams=1, host waits per frame), this process" % sub_spp,
+            "launches_per_step": dom_launches * subs,
+            # what the kernel is bound by when it is not bytes: VALU wave-instructions (counter passes, un-fused bodies summed) over
+            # the launch time against the issue ceilings (tools/dev/micro/inst_rate3.hip: a wave64 instruction of the 2-clock class
+            # every 2.5 clocks per SIMD when mixed, one of the 4-clock class every 4.3 whatever it is mixed with), and the lanes
+            # that did work in them
+            "valu": {"wave_insts_per_launch": dom_insts / dom_launches if dom_insts else None,
+                     "issue_frac_of_2_cycle_rate": round(dom_rate / VALU_ISSUE_PEAK, 4) if dom_rate else None,
+                     "lanes_active_of_64": round(dom_lane_insts / dom_insts, 2) if (dom_insts and dom_lane_insts) else None,
+                     "lane_weighted_issue_frac_of_2_cycle_rate": round(dom_rate / VALU_ISSUE_PEAK * dom_lane_insts / dom_insts / 64.0, 4) if (dom_rate and dom_lane_insts) else None,
+                     "busy_frac_by_stage": {q: ent_of[q].get("valu_busy_frac") for q in dom_parts if q in ent_of}} if dom_bound == "valu" else None,
+            "candidates_ms_per_sub_batch": {k: round(v, 4) for k, v in cand.items()},
+            "hbm_kernel": hbm_kernel,
+            "in_timed_region": {"kernels_in_flight": round(busy_ms / (elapsed * 1e3), 3) if elapsed > 0 else None,
+                                "note": "%d sub-batches in flight: a launch shares the chip and stretches with its company (what rocprofv3 --kernel-trace of the default command shows per launch)" % subs},
             # both must hold for the headline to be physical: the kernel's launches of a step fit into the step, and the bytes it
             # is billed for do not exceed what HBM can deliver in that time
             "cross_checks": {
-                "kernel_ms_per_step": round(ms_per_launch * launches_per_step, 3), "ms_per_step": round(step_ms, 3),
-                "kernel_time_fits_step": bool(ms_per_launch * launches_per_step <= step_ms),
-                "algorithmic_gbs_over_the_step": round(algo_shade / (step_ms * 1e-3) / 1e9, 1),
-                "algorithmic_rate_below_peak": bool(algo_shade / (step_ms * 1e-3) / 1e9 <= HBM_PEAK_GBS),
+                "kernel_ms_per_step": round(dom_ms * subs, 3), "ms_per_step": round(step_ms, 3),
+                "kernel_time_fits_step": bool(dom_ms * subs <= step_ms),
+                "counter_hbm_gbs_over_the_step": round(dom_hbm * subs / (step_ms * 1e-3) / 1e9, 1) if dom_hbm else None,
+                "counter_hbm_rate_below_peak": bool(dom_hbm * subs / (step_ms * 1e-3) / 1e9 <= HBM_PEAK_GBS) if dom_hbm else None,
                 "all_stages_ms_per_step": round(sum(ser.values()) * subs, 3),
                 "all_stages_over_step": round(sum(ser.values()) * subs / step_ms, 3)},
             # the whole chip over the timed region: HBM bytes of every kernel of a step by the counters / the step time
@@ -653,7 +790,7 @@ def main():
         ctx.set_setting("integrator", args.integrator)
         cpu_parity_value = float(W) * H * pdone / pspent / 1e6
         cpu_parity = {"value": round(cpu_parity_value, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                      "embree": embree_note, "gpu_value": round(gpu_parity, 2), "gpu_over_cpu": round(gpu_parity / cpu_parity_value, 1),
+                      "cpu_model": cpu_model(), "flags": oracle_flags(), "embree": embree_note, "gpu_value": round(gpu_parity, 2), "gpu_over_cpu": round(gpu_parity / cpu_parity_value, 1),
                       "sample": "%d full %dx%d frame(s) at 1 spp, parity integrator (EmbreeRT/src/Context.cpp:104-300 restated: 1 primary "
                                 "ray + one shadow ray per light per sample), oracle/rfw_oracle.c with OpenMP, %.1f s; GPU: %d steps of 16 spp, "
                                 "same scene and camera" % (pdone, W, H, pspent, psteps)}
@@ -661,6 +798,9 @@ def main():
         done, spent = oracle_rate(args.integrator, args.cpu_seconds, 64)
         cpu_value = float(W) * H * done / spent / 1e6
         cpu_baseline = {"value": round(cpu_value, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                        # CPU model string, compiler + flags beside the number (no -march=native: the prebuilt
+                        # library travels to the GPU box; the reference itself builds with -ffast-math -mavx2)
+                        "cpu_model": cpu_model(), "flags": oracle_flags(),
                         # an Embree harness would be the first choice; none is installed on the box, so the
                         # oracle port is the only CPU line
                         "embree": embree_note,
@@ -728,6 +868,7 @@ def main():
                                    (None if world > 1 else 0.0)),
             "setup_s": {"scene": round(t_scene, 2), "upload_and_bvh": round(t_upload, 2)},
             "image_mean": float(full_fb[..., :3].mean().item()),
+            "ranks": ranks_info,
         }
         print(json.dumps(out))
     if comm is not None:

@@ -260,6 +260,8 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   fuse         = "1" (default): the extension rays of depth d + 1 and the shadow rays of depth d share ONE launch (both
  *                  queues are complete when the shade stage of depth d has finished; one kernel tail per depth instead of
  *                  two: 1-spp frames 1.34 -> 1.21 ms); "0": a launch each.  Never changes the image
+ *   rfwhip_get_setting also answers three read-only keys: "textured" (the textured shade kernel variant is in use), "packet" (the
+ *   pt primary wave can run in packet form) and "world_tree" (triangles in the world tree of the last update; 0: none).
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

@@ -2626,6 +2626,13 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->sample_group);
 	else if (k == "flat_instances")
 		snprintf(value, cap, "%d", c->flat_instances);
+	// read-only: which kernel variants the render calls launch (for hosts that label their measurements: bench.py)
+	else if (k == "textured") // some material carries a texture / normal map: k_shade_pt<true>
+		snprintf(value, cap, "%d", c->textured ? 1 : 0);
+	else if (k == "packet") // the pt primary wave runs in packet form (k_primary_packet) for sample groups >= 2 or large launches
+		snprintf(value, cap, "%d", (c->packet_ok && (c->refill & 8)) ? 1 : 0);
+	else if (k == "world_tree") // triangles in the world tree of the last rfwhip_update (0: none)
+		snprintf(value, cap, "%zu", c->wtree.valid ? c->wtree.tris : (size_t)0);
 	else
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "unknown setting \"%s\"", key);
 	return RFWHIP_OK;
