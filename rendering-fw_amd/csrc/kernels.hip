@@ -71,6 +71,10 @@ constexpr int KAT_IN = 24, KAT_OUT = 8; // = RFWHIP_KAT_IN / RFWHIP_KAT_OUT (sta
 #ifndef RT_MISS_QUEUE
 #define RT_MISS_QUEUE 1
 #endif
+// (Round 5: the scan's primitive ids asked for one chunk ahead with global_load_lds_dword — straight into the wave's LDS, no register
+// in flight — so that a scan is not a memory round trip with nothing beside it (13 % of a wave's time by the clock): bit-identical,
+// and slower, 8.22 -> 8.63 ms per sub-batch — the plain kernel went from 10 to 18 spilled registers.  Like every change to this
+// kernel's body since round 4.)
 #ifndef RT_SHADE_WAVES_PLAIN
 #define RT_SHADE_WAVES_PLAIN 5 // the shade kernel of scenes without textures: 111 registers unbounded; 4 / 5 / 6 waves ->
 								// 2492 / 2589 / 2584 Msamples/s (96 registers + a few spilled dwords at 5)
@@ -1328,10 +1332,15 @@ struct PacketSpace
 	const char *row_n[3]; // wave-uniform: the node table offset to the near / far plane row of a Node4f per axis — a row is
 	const char *row_f[3]; // fetched as s_load_dwordx4 dst, row, node_byte_offset with no address arithmetic
 	bool mixed;			  // the lanes disagree about a direction sign on some axis
-	__device__ __forceinline__ void enter(f3 o_, f3 d_, unsigned long long act, const char *nodes)
+	// t_hit: the lane's hit distance — 1/d and -o/d are NORMALISED by k = norm_k(t_hit) (rt_core.h, RT_NORM_T: the interval a box
+	// must meet becomes [0, 1], which the clamp modifier of v_max3 / v_min3 folds into the slab test)
+	__device__ __forceinline__ void enter(f3 o_, f3 d_, float t_hit, unsigned long long act, const char *nodes)
 	{
 		o = o_, d = d_;
-		id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+		id = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+#if RT_NORM_T
+		id = id * norm_k(t_hit);
+#endif
 		noid = mk3(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
 		const unsigned long long mx = __ballot(id.x < 0.0f) & act, my = __ballot(id.y < 0.0f) & act, mz = __ballot(id.z < 0.0f) & act;
 		mixed = (mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act);
@@ -1354,14 +1363,14 @@ template <bool COUNT>
 __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool active, const f3 O, const f3 D, const float t_min, Hit &hit, TStat &st)
 {
 	const unsigned long long act = __ballot(active);
-	// a lane without a ray never enters a box (tmin < hit.t fails) and never takes a hit (t > tt fails)
+	// a lane without a ray never enters a box (its bit of every ballot is masked: `act`) and never takes a hit (t > tt fails)
 	hit.t = active ? hit.t : -3.0e38f;
 	if (act == 0ull)
 		return;
 	const int ref_lane = __ffsll((long long)act) - 1;
 	PacketSpace sp;
 	const char *const nodes = (const char *)sc.nodes4f; // (the table stays below 4 GiB: 32-bit byte offsets)
-	sp.enter(O, D, act, nodes);
+	sp.enter(O, D, hit.t, act, nodes);
 	PacketStack stk;
 	int cur_inst = -1;
 	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
@@ -1391,10 +1400,16 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 				{
+#if RT_NORM_T
+					tk[k] = max3_clamp01(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y), fmaf(r.nz[k], sp.id.z, sp.noid.z));
+					const float tmax = min3_clamp01(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y), fmaf(r.fz[k], sp.id.z, sp.noid.z));
+					m[k] = __ballot(tk[k] < tmax) & act;
+#else
 					const float tmin = fmaxf(fmaxf(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y)), fmaf(r.nz[k], sp.id.z, sp.noid.z));
 					const float tmax = fminf(fminf(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y)), fmaf(r.fz[k], sp.id.z, sp.noid.z));
 					tk[k] = fmaxf(tmin, 0.0f);
 					m[k] = __ballot(tk[k] < fminf(tmax, hit.t));
+#endif
 				}
 			}
 			else
@@ -1408,11 +1423,17 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 					const float ax = fmaf(lx[k], sp.id.x, sp.noid.x), bx = fmaf(hx[k], sp.id.x, sp.noid.x);
 					const float ay = fmaf(ly[k], sp.id.y, sp.noid.y), by = fmaf(hy[k], sp.id.y, sp.noid.y);
 					const float az = fmaf(lz[k], sp.id.z, sp.noid.z), bz = fmaf(hz[k], sp.id.z, sp.noid.z);
+					// (min / max per plane pair turn the inverted box of an unused slot into a huge one: asked for by its entry)
+#if RT_NORM_T
+					tk[k] = max3_clamp01(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+					const float tmax = min3_clamp01(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
+					m[k] = ent[k] != ENTRY_EMPTY ? (__ballot(tk[k] < tmax) & act) : 0ull;
+#else
 					const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 					const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 					tk[k] = fmaxf(tmin, 0.0f);
-					// (min / max per plane pair turn the inverted box of an unused slot into a huge one: asked for by its entry)
 					m[k] = ent[k] != ENTRY_EMPTY ? __ballot(tk[k] < fminf(tmax, hit.t)) : 0ull;
+#endif
 				}
 			}
 			if (COUNT)
@@ -1457,7 +1478,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			break;
 		if (cur == ENTRY_SENTINEL)
 		{
-			sp.enter(O, D, act, nodes); // leaving an instance: back to the world-space ray
+			sp.enter(O, D, hit.t, act, nodes); // leaving an instance: back to the world-space ray
 			cur_inst = -1;
 			cur = stk.pop();
 			continue;
@@ -1473,7 +1494,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			stk.push(ENTRY_SENTINEL);
 			const float m0[4] = {r0[0], r0[1], r0[2], r0[3]}, m1[4] = {r1[0], r1[1], r1[2], r1[3]}, m2[4] = {r2[0], r2[1], r2[2], r2[3]};
 			sp.enter(mk3(row_point_r(m0, O), row_point_r(m1, O), row_point_r(m2, O)), mk3(row_dir_r(m0, D), row_dir_r(m1, D), row_dir_r(m2, D)),
-					 act, nodes);
+					 hit.t, act, nodes);
 			cur_inst = (int)ii;
 			cur = root;
 			continue;
@@ -1482,6 +1503,9 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 		{
 			const uint32_t first = cur & ENTRY_FIRST_MASK, count = ((cur >> 27) & 7u) + 1u;
 			const char *const tb = (const char *)sc.tri_verts + (size_t)first * 48u;
+#if RT_NORM_T
+			const float t_before = hit.t;
+#endif
 			for (uint32_t i = 0; i < count; i++)
 			{
 				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
@@ -1492,6 +1516,13 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 					hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
 				}
 			}
+#if RT_NORM_T
+			if (hit.t != t_before) // the lane's hit moved: rescale its normalised 1/d and -o/d (Traverser::renormalise)
+			{
+				const float r = norm_k(hit.t) * fast_rcp(norm_k(t_before)) * 0.99999952f;
+				sp.id = sp.id * r, sp.noid = sp.noid * r;
+			}
+#endif
 			cur = stk.pop();
 		}
 	}
