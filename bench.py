@@ -592,6 +592,9 @@ def main():
                     # share of SIMD cycles a VALU instruction occupied, by instruction class: (2 x (FMA + MUL + ADD_F32) + 8 x transcendentals
                     # + 4 x the rest) / SIMD cycles (profiles/summarize.py; validated on a pure v_fma_f32 kernel: traffic_source.valu_busy_validation)
                     "valu_busy_frac": k.get("valu_busy_frac"), "valu_2_cycle_share": k.get("valu_2_cycle_share"),
+                    # round 5's non-additive model (tools/dev/micro/inst_rate3.hip): time ~ max(4.3 x 4-clock instructions + 8.6 x
+                    # transcendentals, 2.5 x all VALU instructions) over the SIMD cycles
+                    "valu_slow_pipe_frac": k.get("valu_slow_pipe_frac"), "valu_issue_frac": k.get("valu_issue_frac"),
                     "valu_transcendental_share": k.get("valu_transcendental_share"),
                 })
             else:

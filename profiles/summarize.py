@@ -103,7 +103,14 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
         fast = t.get("SQ_INSTS_VALU_FMA_F32", 0.0) + t.get("SQ_INSTS_VALU_MUL_F32", 0.0) + t.get("SQ_INSTS_VALU_ADD_F32", 0.0)
         trans = t.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
         slow = max(0.0, t["SQ_INSTS_VALU"] - fast - trans)
-        return (2.0 * fast + 8.0 * trans + 4.0 * slow) / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), fast / t["SQ_INSTS_VALU"], trans / t["SQ_INSTS_VALU"]
+        cyc = t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0
+        # Round 5 (tools/dev/micro/inst_rate3.hip, mixes): the classes are not additive — a 4-clock instruction occupies its pipe for 4.3
+        # clocks whatever it is mixed with, a 2-clock one issues in the gaps down to 2.5 clocks per instruction overall, v_rcp / v_sqrt
+        # take 8.6 and do not overlap.  VALU time ~ max(4.3 x slow + 8.6 x trans, 2.5 x all); the additive figure stays beside it.
+        # (Upper bounds both: the counters class only FMA / MUL / ADD_F32 as fast, not v_add_u32 / v_and / v_mov / v_lshrrev.)
+        pipe = (4.3 * slow + 8.6 * trans) / cyc
+        issue = 2.5 * t["SQ_INSTS_VALU"] / cyc
+        return (2.0 * fast + 8.0 * trans + 4.0 * slow) / cyc, fast / t["SQ_INSTS_VALU"], trans / t["SQ_INSTS_VALU"], pipe, issue
     # validation: the model on a kernel that is nothing but independent v_fma_f32 at 8 waves per SIMD (must read ~1)
     import os
     calib = None
@@ -142,6 +149,8 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
             if mv:
                 e["valu_2_cycle_share"] = round(mv[1], 4)
                 e["valu_transcendental_share"] = round(mv[2], 4)
+                e["valu_slow_pipe_frac"] = round(mv[3], 4)  # 4.3 clocks per 4-clock-class instruction, 8.6 per transcendental
+                e["valu_issue_frac"] = round(mv[4], 4)      # 2.5 clocks per VALU instruction of any class
         if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t and t["SQ_WAVE_CYCLES"] > 0:
             e["wave_cycles_waiting_frac"] = round(t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"], 4)
         out["kernels"][k] = e
@@ -149,7 +158,8 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
                          "--no-roofline` (tools/evidence.sh); per dispatch averages; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
                          "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = (2 x (FMA + MUL + ADD_F32) + 8 x TRANS_F32 + 4 x the other VALU instructions) / "
                          "(GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs): the share of SIMD cycles a VALU instruction occupied, by instruction class "
-                         "(valu_busy_validation: the same model on a pure v_fma_f32 kernel); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
+                         "(valu_busy_validation: the same model on a pure v_fma_f32 kernel); valu_slow_pipe_frac / valu_issue_frac: round 5's non-additive model, "
+                         "max(4.3 x slow + 8.6 x trans, 2.5 x all) / SIMD cycles (tools/dev/micro/inst_rate3.hip); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
     print(json.dumps(out, indent=1))
 
 

@@ -1282,8 +1282,8 @@ static int ensure_nodes4f(rfwhip_context *c)
 // whose matrix is the identity the world-space vertices ARE the object-space ones and nothing a ray computes changes; for a
 // transformed one the triangle test sees M p instead of M^-1 o: the same numbers up to rounding.
 // Members: every instance of a mesh that was built on the host and is not animated (skinned, morphed, posed, or re-set with the same
-// topology since its build), as long as the copy stays below `flatten_bytes`.  When every member is an identity instance of a
-// singly used mesh the mesh trees are linked into the top-level tree instead (flat instances, below): same effect, no copy.
+// topology since its build), as long as the copy stays below `flatten_bytes`.  A single member that is an identity instance of a
+// singly used mesh has its mesh tree linked into the top-level tree instead (flat instances, below): same effect, no copy.
 // Animated meshes and meshes built on the device keep the two-level walk.  The tree is rebuilt only when its key — members, their
 // meshes' build generations, their matrices — changes (an animated scene's per-frame update leaves it alone).
 constexpr uint32_t WORLD_ID = 0xFFFFFFFFu;
@@ -1322,6 +1322,8 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 			}
 		}
 	}
+	if (key.size() > 19) // (two members or more: one tree over all of them beats a top-level tree over theirs even when every one of
+		worth = true;	 // them is an identity instance — terrain + light quads of the bench scene: +0.9 %)
 	const unsigned long long bytes = (unsigned long long)tris * (3 * sizeof(f4) + sizeof(rt::Node4c)); // (at most one 4-wide node per triangle)
 	if (!worth || !tris || bytes > (unsigned long long)c->flatten_bytes)
 	{
