@@ -334,6 +334,11 @@ struct InstRec
 	size_t mesh = 0;
 	float transform[16];
 	float normal[9];
+	// world-tree membership (prepare_world): an instance whose matrix changed in one of the last few updates is being animated
+	// through its matrix and keeps the two-level walk — writing it out in world space would rebuild the world tree per frame
+	float prev_transform[16];
+	bool has_prev = false;
+	uint32_t moving = 0; // updates left before it may (re)join the world tree
 };
 
 // The WORLD TREE (rfwhip_update): the triangles of the static instances written out in world space under ONE tree.
@@ -1282,7 +1287,7 @@ static int ensure_nodes4f(rfwhip_context *c)
 // whose matrix is the identity the world-space vertices ARE the object-space ones and nothing a ray computes changes; for a
 // transformed one the triangle test sees M p instead of M^-1 o: the same numbers up to rounding.
 // Members: every instance of a mesh that was built on the host and is not animated (skinned, morphed, posed, or re-set with the same
-// topology since its build), as long as the copy stays below `flatten_bytes`.  A single member that is an identity instance of a
+// topology since its build) whose own matrix has not changed in the last eight updates, as long as the copy stays below `flatten_bytes`.  A single member that is an identity instance of a
 // singly used mesh has its mesh tree linked into the top-level tree instead (flat instances, below): same effect, no copy.
 // Animated meshes and meshes built on the device keep the two-level walk.  The tree is rebuilt only when its key — members, their
 // meshes' build generations, their matrices — changes (an animated scene's per-frame update leaves it alone).
@@ -1304,8 +1309,15 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 		static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 		for (size_t i = 0; i < c->instances.size(); i++)
 		{
-			const InstRec &in = c->instances[i];
+			InstRec &in = c->instances[i];
 			if (!in.used || in.mesh >= c->meshes.size() || !c->meshes[in.mesh].used)
+				continue;
+			if (in.has_prev && memcmp(in.prev_transform, in.transform, sizeof(in.transform)) != 0)
+				in.moving = 8u; // (stable for eight updates before it rejoins: one rebuild when an animation starts, one after it ends)
+			else if (in.moving)
+				in.moving--;
+			memcpy(in.prev_transform, in.transform, sizeof(in.transform)), in.has_prev = true;
+			if (in.moving)
 				continue;
 			const MeshRec &m = c->meshes[in.mesh];
 			if (!m.built || m.device_built || m.skinned || m.morphed || m.posed || m.refits != 0u || m.leaf_verts.size() != 3 * m.triCount || !m.triCount)

@@ -450,6 +450,54 @@ def test_flat_instances_leave_every_result_alone(pkg, make_emu, make_oracle, geo
     assert (a["inst"] != b["inst"]).sum() == 0 and (a["prim"] != b["prim"]).sum() == 0
 
 
+def test_an_instance_that_moves_leaves_the_world_tree(pkg, make_emu):
+    """The world tree holds static instances only: an instance whose MATRIX changes between updates (the reference's way of moving
+    an object, set_instance + update) keeps the two-level walk from then on — the tree is rebuilt once, without it — and every
+    frame equals the frame of a fresh context that was handed the final transforms with the world tree switched off (same
+    triangles, same instances; t of the boxes that stayed in the tree to rounding)."""
+    import ctypes
+
+    def world_tris(ctx):  # rfwhip_get_setting("world_tree"): triangles in the world tree of the last update
+        buf = ctypes.create_string_buffer(64)
+        f = ctx._fn("get_setting")
+        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        assert f(ctx._ctx, b"world_tree", buf, 64) == 0
+        return int(buf.value.decode())
+
+    scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
+    settings = {"integrator": "pt", "spp": 1, "max_depth": 2}
+    a = make_emu()
+    a.init(64, 48)
+    scene.upload(a)
+    for k, v in settings.items():
+        a.set_setting(k, v)
+    a.render_frame(scene.camera, pkg.RESET)
+    assert world_tris(a) > 0
+    mover = next(i for i, ins in enumerate(scene.instances) if not np.array_equal(ins["transform"], np.eye(4)))
+    n_before = world_tris(a)
+    for step in range(3):
+        t = np.array(scene.instances[mover]["transform"], np.float32).copy()
+        t[:3, 3] += np.float32(0.05) * (step + 1)  # (maths convention: the translation is the last column)
+        scene.instances[mover]["transform"] = t
+        a.set_instance(mover, scene.instances[mover]["mesh"], t)
+        a.update()
+        a.render_frame(scene.camera, pkg.RESET)
+        assert world_tris(a) < n_before  # the mover's triangles are no longer in it
+        b = make_emu()
+        b.init(64, 48)
+        b.set_setting("flatten_bytes", 0)
+        scene.upload(b)
+        for k, v in settings.items():
+            b.set_setting(k, v)
+        b.render_frame(scene.camera, pkg.RESET)
+        ha, hb = a.primary_hits(), b.primary_hits()
+        assert np.array_equal(ha["inst"], hb["inst"]) and np.array_equal(ha["prim"], hb["prim"]), step
+        hit = ha["prim"] >= 0
+        assert (np.abs(ha["t"][hit] - hb["t"][hit]) <= 2e-6 * hb["t"][hit]).all()
+        moved = ha["inst"] == mover
+        assert moved.any() and np.array_equal(ha["t"][moved], hb["t"][moved])  # the mover itself: the two-level walk, bit for bit
+
+
 def test_product_shapes_against_the_reference_shaped_oracle(pkg, make_emu, make_oracle):
     """The oracle's `arith=reference` form (triangle test, pt primary ray and sky lookup as the reference's text shapes them,
     first triangle reached wins) against the product's fixed shapes, on libm arithmetic: a terrain cut at 4 spp.  What the

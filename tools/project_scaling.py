@@ -13,7 +13,8 @@ W, H = 1920, 1080
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 streams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 pipeline = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-scene = pkg.scenes.terrain(n=708, width=W, height_px=H)
+# PROJ_WORKLOAD=atrium: BASELINE config 4 (the config the reference shards over 8 GPUs) instead of the bench terrain
+scene = pkg.scenes.atrium(W, H) if os.environ.get("PROJ_WORKLOAD") == "atrium" else pkg.scenes.terrain(n=708, width=W, height_px=H)
 
 def run(rank, world, steps=10, warm=3):
     ctx = pkg.RenderContext(0, rank, world); ctx.init(W, H); scene.upload(ctx)
