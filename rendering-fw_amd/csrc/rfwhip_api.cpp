@@ -337,6 +337,8 @@ struct InstRec
 	// world-tree membership (prepare_world): an instance whose matrix changed in one of the last few updates is being animated
 	// through its matrix and keeps the two-level walk — writing it out in world space would rebuild the world tree per frame
 	float prev_transform[16];
+	size_t prev_mesh = 0;
+	uint32_t prev_generation = 0;
 	bool has_prev = false;
 	uint32_t moving = 0; // updates left before it may (re)join the world tree
 };
@@ -1312,11 +1314,16 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 			InstRec &in = c->instances[i];
 			if (!in.used || in.mesh >= c->meshes.size() || !c->meshes[in.mesh].used)
 				continue;
-			if (in.has_prev && memcmp(in.prev_transform, in.transform, sizeof(in.transform)) != 0)
+			// (another mesh, or the same one rebuilt: a new object in this slot, not a moving one)
+			const bool same_object = in.has_prev && in.prev_mesh == in.mesh && in.prev_generation == c->meshes[in.mesh].generation;
+			if (!same_object)
+				in.moving = 0u;
+			else if (memcmp(in.prev_transform, in.transform, sizeof(in.transform)) != 0)
 				in.moving = 8u; // (stable for eight updates before it rejoins: one rebuild when an animation starts, one after it ends)
 			else if (in.moving)
 				in.moving--;
-			memcpy(in.prev_transform, in.transform, sizeof(in.transform)), in.has_prev = true;
+			memcpy(in.prev_transform, in.transform, sizeof(in.transform));
+			in.prev_mesh = in.mesh, in.prev_generation = c->meshes[in.mesh].generation, in.has_prev = true;
 			if (in.moving)
 				continue;
 			const MeshRec &m = c->meshes[in.mesh];
