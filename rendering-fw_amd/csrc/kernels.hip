@@ -1920,10 +1920,19 @@ void launch_expand4(const Node4c *nodes4, Node4f *out, uint32_t count4, stream_t
 #ifndef RT_GRID_CHUNKS_PER_BLOCK
 #define RT_GRID_CHUNKS_PER_BLOCK 32u // a workgroup should find about this many 256-item chunks to be worth launching
 #endif
-static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID_BLOCKS_PER_CU)
+// Round 5: the SMALLEST grid of a queue-fed kernel (traversal, shade) is 2-3 workgroups per CU, not a full chip's worth: a 1-spp
+// 1080p frame is ten launches over 2 M items or fewer, three frames' chains are in flight, and a wave of a full persistent grid then
+// finds ~300 rays — five refills — before it idles through the launch's tail; with a quarter of the waves each keeps its lanes
+// filled four times as long and the kernels of the other chains fill the CUs (pipelined 1-spp frames 1.195 -> 0.815 ms; a lower
+// bound of 1 / 2 / 3 / 4 per CU: 1.04 / 0.82 / 0.81 / 0.96).  The streaming kernels (resolve, present, de-interleave) keep a full
+// grid: they want every CU's memory pipeline (with the lower bound on them too, 8-spp steps lose 4.6 %).
+#ifndef RT_GRID_LO_PER_CU
+#define RT_GRID_LO_PER_CU 3u
+#endif
+static inline uint32_t persistent_grid(uint32_t items, uint32_t per_cu = RT_GRID_BLOCKS_PER_CU, uint32_t lo_per_cu = RT_GRID_LO_PER_CU)
 {
 	const uint32_t chunks = (items + BLOCK - 1) / BLOCK;
-	const uint32_t lo = (uint32_t)g_cus * (per_cu < 8u ? per_cu : 8u), hi = (uint32_t)g_cus * per_cu;
+	const uint32_t lo = (uint32_t)g_cus * (per_cu < lo_per_cu ? per_cu : lo_per_cu), hi = (uint32_t)g_cus * per_cu;
 	uint32_t blocks = chunks / RT_GRID_CHUNKS_PER_BLOCK;
 	blocks = blocks < lo ? lo : (blocks > hi ? hi : blocks);
 	if (blocks > chunks)
@@ -2097,19 +2106,19 @@ void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t
 
 void launch_resolve(const Params &p, stream_t s)
 {
-	hipLaunchKernelGGL(k_resolve, dim3(persistent_grid(p.fr.W * p.fr.local_rows)), dim3(BLOCK), 0, (hipStream_t)s, p);
+	hipLaunchKernelGGL(k_resolve, dim3(persistent_grid(p.fr.W * p.fr.local_rows, RT_GRID_BLOCKS_PER_CU, 8u)), dim3(BLOCK), 0, (hipStream_t)s, p);
 }
 
 void launch_present(const Params &p, f4 *out, float scale, int full, stream_t s)
 {
-	hipLaunchKernelGGL(k_present, dim3(persistent_grid(p.fr.W * p.fr.local_rows)), dim3(BLOCK), 0, (hipStream_t)s, p,
+	hipLaunchKernelGGL(k_present, dim3(persistent_grid(p.fr.W * p.fr.local_rows, RT_GRID_BLOCKS_PER_CU, 8u)), dim3(BLOCK), 0, (hipStream_t)s, p,
 					   out, scale, full);
 }
 
 void launch_deinterleave(const f4 *gathered, f4 *out, uint32_t W, uint32_t H, uint32_t local_rows, uint32_t world,
 						 stream_t s)
 {
-	hipLaunchKernelGGL(k_deinterleave, dim3(persistent_grid(W * H)), dim3(BLOCK), 0, (hipStream_t)s, gathered, out, W, H,
+	hipLaunchKernelGGL(k_deinterleave, dim3(persistent_grid(W * H, RT_GRID_BLOCKS_PER_CU, 8u)), dim3(BLOCK), 0, (hipStream_t)s, gathered, out, W, H,
 					   local_rows, world);
 }
 

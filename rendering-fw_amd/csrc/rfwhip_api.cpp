@@ -1964,6 +1964,33 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 	return 0;
 }
 
+// How many items the launches of depth d of a pt call should be SIZED for (grids only: every kernel reads its real count on the
+// device and works through whatever it finds).  The host never reads a counter between bounces, so every launch used to get a grid
+// for the primary count — for the deeper waves of a small call a chip-wide persistent grid whose waves find a few dozen rays each.
+// Paths per primary at depth d: from the counts of the last frame this context waited for (rfwhip_get_stats; same scene, any spp),
+// with a quarter of headroom; before there is one, a half per depth.  extend = false: the traversal launch of depth d — extension
+// rays of depth d and the shadow rays of depth d - 1 beside them; true: the shade launch of depth d.
+static uint32_t depth_items(const rfwhip_context *c, uint32_t n, int d, bool shade)
+{
+	if (d <= 0)
+		return n;
+	const rfwhip_render_stats &st = c->stats;
+	double ext = 1.0, prev = 1.0, shadow_per_path = 0.8;
+	if (st.primaryCount > 0)
+	{
+		const double p = (double)st.primaryCount, r1 = (double)st.secondaryCount / p, rdeep = (double)st.deepCount / p;
+		// (deepCount adds up every depth >= 2: taken as the bound for each of them)
+		ext = d == 1 ? r1 : rdeep, prev = d == 1 ? 1.0 : (d == 2 ? r1 : rdeep);
+		shadow_per_path = std::min(1.0, (double)st.shadowCount / std::max(1.0, p * (0.7 + r1 + rdeep))) + 0.1;
+	}
+	else
+		for (int k = 0; k < d; k++)
+			prev = ext, ext *= 0.5;
+	const double want = shade ? ext : std::max(ext, prev * shadow_per_path);
+	const double items = std::min(1.0, 1.25 * want + 0.02) * (double)n;
+	return (uint32_t)std::max(1.0, items);
+}
+
 // One render call = `spp` samples per pixel.  The samples are cut into up to `streams` sub-batches that run the whole
 // wavefront pipeline concurrently on their own HIP streams (own slices of the path buffers, own device counters):
 // every traversal kernel ends with a tail in which a few long rays keep a handful of waves busy — a chain of ~150
@@ -2181,16 +2208,18 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				p.wv.sh_org = c->d_sh_org[d & 1].as<f4>() + off, p.wv.sh_dir = c->d_sh_dir[d & 1].as<f4>() + off;
 				p.wv.sh_rad = c->d_sh_rad[d & 1].as<f4>() + off;
 				StageTimer te(c, KF_EXTEND, d, s);
+				// (grid sizes of the deeper launches: from the paths EXPECTED there, not from the primary count — depth_items)
+				const uint32_t n_ext = depth_items(c, n, d, false), n_shade = depth_items(c, n, d, true);
 				if (pa_pending)
-					rtk::launch_trace_fused(p, pa, count, n, s); // extension rays of depth d + shadow rays of depth d - 1
+					rtk::launch_trace_fused(p, pa, count, n_ext, s); // extension rays of depth d + shadow rays of depth d - 1
 				else
-					rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, n, s);
+					rtk::launch_extend(p, d == 0 ? rtk::GEN_PT : rtk::GEN_BUFFER, count, d == 0 ? n : n_ext, s);
 				pa_pending = false;
 				te.stop();
 				if (side && d >= 2 && d < c->max_depth) // connect(d - 2) read the buffers shade(d) is about to write
 					RF_TRY(dm::stream_wait_event(s, c->ev_conn[i][d - 2]));
 				StageTimer ts(c, KF_SHADE, -1, s);
-				rtk::launch_shade_pt(p, n, s);
+				rtk::launch_shade_pt(p, n_shade, s);
 				ts.stop();
 				// The connection wave of depth d runs beside extend / shade of depth d + 1 on its own stream (it adds into
 				// rad_nee, they into rad).  The connections of the last shade call are never traced
@@ -2210,7 +2239,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 					}
 					p.group = 16u, p.queue = queue++;
 					StageTimer tc(c, KF_CONNECT, -1, sc);
-					rtk::launch_connect(p, count, n, sc);
+					rtk::launch_connect(p, count, depth_items(c, n, d + 1, false), sc);
 					tc.stop();
 					if (side)
 					{
