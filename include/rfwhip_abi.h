@@ -270,6 +270,7 @@ enum rfwhip_kat_function
 	RFWHIP_KAT_BLUE_NOISE = 8,		   /* tools.h:163-181, [0..3] = x, y, sample, dimension (ints) -> value */
 	RFWHIP_KAT_HASH = 9,			   /* tools.h:218-235, [0] = seed -> WangHash bits, RandomFloat, state bits */
 	RFWHIP_KAT_FASTDIV = 11,		   /* the slot -> pixel mapping's division by per-frame constants (rt_types.h: fast_div): [0..7] = four (n, d) pairs, n < 2^31, 0 < d < 2^31 (ints) -> four quotients (ints) */
+	RFWHIP_KAT_TEX_WRAP = 12,		   /* the wrap of a texel coordinate (getShadingData.h:33-41: `% width`, `% height`; rt_core.h: tex_wrap): [0..7] = four (x, w) pairs, 0 <= x < 2^31, 1 <= w < 2^31 (ints) -> four remainders (ints) */
 	RFWHIP_KAT_HALF_TO_FLOAT = 10	   /* half -> float as the shade kernels read materials (structs.h:88-117): [0..7] = 8 half bit patterns (ints) -> 8 floats */
 };
 

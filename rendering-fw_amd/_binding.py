@@ -293,7 +293,7 @@ class CoreBinding:
 
     # known-answer hook: RFWHIP_KAT_* (include/rfwhip_abi.h)
     KAT = {"bsdf_eval": 0, "bsdf_pdf": 1, "bsdf_sample": 2, "tangent_space": 3, "pack_normal": 4,
-           "random_barycentrics": 5, "point_on_light": 6, "light_pick_prob": 7, "blue_noise": 8, "hash": 9, "half_to_float": 10, "fastdiv": 11}
+           "random_barycentrics": 5, "point_on_light": 6, "light_pick_prob": 7, "blue_noise": 8, "hash": 9, "half_to_float": 10, "fastdiv": 11, "tex_wrap": 12}
 
     def kat(self, function, records):
         """One of the path tracer's functions on n records (n x 24 float32, integers as bit patterns) -> n x 8 float32."""

@@ -578,6 +578,10 @@ RT_FN void kat_item(const Params &p, int function, const float *in, float *out, 
 		for (int k = 0; k < 4; k++)
 			o[k] = ubits(fast_div(fbits(r[2 * k]), make_fastdiv(fbits(r[2 * k + 1]))));
 		break;
+	case 12: // tex_wrap (rt_core.h): four (x, w) pairs per record, 0 <= x, 1 <= w -> x % w
+		for (int k = 0; k < 4; k++)
+			o[k] = ubits((uint32_t)tex_wrap((int)fbits(r[2 * k]), (int)fbits(r[2 * k + 1])));
+		break;
 	default:
 		break;
 	}

@@ -2878,7 +2878,7 @@ extern "C" int rfwhip_kat(rfwhip_context *c, int function, size_t n, const float
 	CTX_ENTER(c);
 	if (n && (!in || !out))
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: null records");
-	if (function < 0 || function > RFWHIP_KAT_FASTDIV)
+	if (function < 0 || function > RFWHIP_KAT_TEX_WRAP)
 		return set_error(RFWHIP_ERR_INVALID_ARGUMENT, "rfwhip_kat: unknown function %d", function);
 	if ((function == RFWHIP_KAT_POINT_ON_LIGHT || function == RFWHIP_KAT_LIGHT_PICK_PROB) && c->scene_dirty)
 		return set_error(RFWHIP_ERR_STATE, "rfwhip_kat: the light functions use the lights of the last rfwhip_update()");

@@ -498,6 +498,39 @@ def test_an_instance_that_moves_leaves_the_world_tree(pkg, make_emu):
         assert moved.any() and np.array_equal(ha["t"][moved], hb["t"][moved])  # the mover itself: the two-level walk, bit for bit
 
 
+def test_the_world_tree_respects_its_budget(pkg, make_emu):
+    """`flatten_bytes` is a budget on the world-space copy (48 B of vertices + at most one 64-byte node per triangle): one byte
+    below what the scene's static instances need, no world tree is built and the frame is the two-level walk's, bit for bit;
+    at the budget, the tree holds every static instance's triangles."""
+    import ctypes
+
+    def world_tris(ctx):
+        buf = ctypes.create_string_buffer(64)
+        f = ctx._fn("get_setting")
+        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        assert f(ctx._ctx, b"world_tree", buf, 64) == 0
+        return int(buf.value.decode())
+
+    scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
+    total = sum(int(scene.meshes[ins["mesh"]]["triangles"].shape[0]) for ins in scene.instances)
+    need = total * (48 + 64)
+    frames = {}
+    for budget in (0, need - 1, need):
+        c = make_emu()
+        c.init(64, 48)
+        c.set_setting("flatten_bytes", budget)
+        scene.upload(c)
+        for k, v in {"integrator": "pt", "spp": 2, "max_depth": 2}.items():
+            c.set_setting(k, v)
+        c.render_frame(scene.camera, pkg.RESET)
+        frames[budget] = (c.framebuffer(), c.primary_hits(), world_tris(c))
+    assert frames[0][2] == 0 and frames[need - 1][2] == 0 and frames[need][2] == total
+    assert np.array_equal(frames[0][0], frames[need - 1][0])
+    for k in ("inst", "prim", "t"):
+        assert np.array_equal(frames[0][1][k], frames[need - 1][1][k]), k
+    assert np.array_equal(frames[need][1]["prim"], frames[0][1]["prim"]) and np.array_equal(frames[need][1]["inst"], frames[0][1]["inst"])
+
+
 def test_product_shapes_against_the_reference_shaped_oracle(pkg, make_emu, make_oracle):
     """The oracle's `arith=reference` form (triangle test, pt primary ray and sky lookup as the reference's text shapes them,
     first triangle reached wins) against the product's fixed shapes, on libm arithmetic: a terrain cut at 4 spp.  What the
