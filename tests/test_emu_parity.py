@@ -498,6 +498,77 @@ def test_an_instance_that_moves_leaves_the_world_tree(pkg, make_emu):
         assert moved.any() and np.array_equal(ha["t"][moved], hb["t"][moved])  # the mover itself: the two-level walk, bit for bit
 
 
+def test_a_mesh_that_is_set_again_leaves_or_rejoins_the_world_tree(pkg, make_emu):
+    """set_mesh on a member of the world tree: with the SAME topology it is a refit — an animated mesh from then on, out of the
+    tree, two-level walk — and with another topology a new build, which rejoins.  Either way the next frame is the frame of a
+    fresh context that was handed the final geometry with the world tree off."""
+    import ctypes
+
+    def world_tris(ctx):
+        buf = ctypes.create_string_buffer(64)
+        f = ctx._fn("get_setting")
+        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        assert f(ctx._ctx, b"world_tree", buf, 64) == 0
+        return int(buf.value.decode())
+
+    def fresh(scene):
+        b = make_emu()
+        b.init(64, 48)
+        b.set_setting("flatten_bytes", 0)
+        scene.upload(b)
+        for k, v in settings.items():
+            b.set_setting(k, v)
+        b.render_frame(scene.camera, pkg.RESET)
+        return b.primary_hits()
+
+    def same(ha, hb):
+        assert np.array_equal(ha["inst"], hb["inst"]) and np.array_equal(ha["prim"], hb["prim"])
+        hit = ha["prim"] >= 0
+        assert (np.abs(ha["t"][hit] - hb["t"][hit]) <= 2e-6 * hb["t"][hit]).all()
+
+    scene = pkg.scenes.cornell(64, 48, geometric_emitter=True)
+    settings = {"integrator": "pt", "spp": 1, "max_depth": 2}
+    a = make_emu()
+    a.init(64, 48)
+    scene.upload(a)
+    for k, v in settings.items():
+        a.set_setting(k, v)
+    a.render_frame(scene.camera, pkg.RESET)
+    n0 = world_tris(a)
+    shared = next(ins["mesh"] for ins in scene.instances if not np.array_equal(ins["transform"], np.eye(4)))
+    users = [i for i, ins in enumerate(scene.instances) if ins["mesh"] == shared]
+    m = scene.meshes[shared]
+    n_tri = int(m["triangles"].shape[0])
+    # the same topology, every vertex pulled 10 % towards the mesh's centre: a refit
+    v = np.array(m["vertices"], np.float32).copy()
+    ctr = v[:, :3].mean(0)
+    v[:, :3] = ctr + (v[:, :3] - ctr) * np.float32(0.9)
+    tri = m["triangles"].copy()
+    for k, name in enumerate(("vertex0", "vertex1", "vertex2")):
+        if name in tri.dtype.names:
+            q = np.array(tri[name], np.float32)
+            q[:, :3] = ctr + (q[:, :3] - ctr) * np.float32(0.9)
+            tri[name] = q
+    m["vertices"], m["triangles"] = v, tri
+    a.set_mesh(shared, v, tri, m["indices"])
+    a.update()
+    a.render_frame(scene.camera, pkg.RESET)
+    assert world_tris(a) == n0 - n_tri * len(users)
+    ha, hb = a.primary_hits(), fresh(scene)
+    same(ha, hb)
+    on_it = np.isin(ha["inst"], users) & (ha["prim"] >= 0)
+    assert on_it.any() and np.array_equal(ha["t"][on_it], hb["t"][on_it])  # the refit mesh: two levels on both sides
+    # another topology (the last triangle dropped): a new build, static again
+    tri2 = tri[:-1].copy()
+    idx2 = None if m["indices"] is None else np.asarray(m["indices"])[:-1].copy()
+    m["triangles"], m["indices"] = tri2, idx2
+    a.set_mesh(shared, v, tri2, idx2)
+    a.update()
+    a.render_frame(scene.camera, pkg.RESET)
+    assert world_tris(a) == n0 - len(users)
+    same(a.primary_hits(), fresh(scene))
+
+
 def test_the_world_tree_respects_its_budget(pkg, make_emu):
     """`flatten_bytes` is a budget on the world-space copy (48 B of vertices + at most one 64-byte node per triangle): one byte
     below what the scene's static instances need, no world tree is built and the frame is the two-level walk's, bit for bit;
