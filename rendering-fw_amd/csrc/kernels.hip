@@ -999,9 +999,16 @@ __global__ void __launch_bounds__(BLOCK, RT_PRIMARY_WAVES) k_extend(const Params
 #ifndef RT_PRIMARY_PACKET_MIN
 #define RT_PRIMARY_PACKET_MIN (16u << 20)
 #endif
-// rays a wave takes from the launch's queue per atomic (0: one atomic per refill, exactly the idle lanes)
+// rays a wave takes from the launch's queue per atomic (0: one atomic per refill, exactly the idle lanes).  Round 5, per kernel
+// (MI355X, serialised ms per 64-spp sub-batch at 128 / 256 / 512 / 1024): extension rays of depth 1 6.09 / 5.96 / 6.02 / 6.27, of
+// depth 2 1.72 / 1.72 / 1.75 / 1.76, shadow rays 9.24 / 7.49 / 7.72 / 7.88 — short runs spread a queue's neighbourhoods over more
+// waves while their nodes are still in the L2s, too short ones pay in atomics.  The packet kernel's runs are its own
+// (RT_PACKET_CHUNK).
 #ifndef RT_STREAM_CHUNK
-#define RT_STREAM_CHUNK 512
+#define RT_STREAM_CHUNK 256
+#endif
+#ifndef RT_STREAM_CHUNK_ANY
+#define RT_STREAM_CHUNK_ANY RT_STREAM_CHUNK
 #endif
 #ifndef RT_LEAF_VOTE_ANY
 #define RT_LEAF_VOTE_ANY 40
@@ -1060,7 +1067,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	uint32_t q_next = 0, q_end = 0; // wave-uniform: the rest of the run this wave owns
 	// run length: RT_STREAM_CHUNK for big launches, down to 64 when the launch has fewer than ~4 runs per wave
 	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
-	constexpr uint32_t RUN_MAX = (uint32_t)RT_STREAM_CHUNK;
+	constexpr uint32_t RUN_MAX = MODE == STREAM_ANY ? (uint32_t)RT_STREAM_CHUNK_ANY : (uint32_t)RT_STREAM_CHUNK;
 	run = run > RUN_MAX ? RUN_MAX : (run < 64u ? 64u : run);
 #endif
 	uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE_EXT;
@@ -1537,6 +1544,12 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #ifndef RT_PACKET_WAVES
 #define RT_PACKET_WAVES 8
 #endif
+// path slots a wave takes from the queue per atomic: a run is 64-slot groups of neighbouring pixels, and the wave that walks
+// them one after the other finds the previous group's nodes and triangles in the scalar cache: 256 / 512 / 1024 / 2048 / 4096
+// slots per run -> 6.27 / 4.90 / 4.49 / 4.65 / 5.59 ms per 64-spp primary wave (longer runs leave too few of them per wave).
+#ifndef RT_PACKET_CHUNK
+#define RT_PACKET_CHUNK 1024
+#endif
 
 // The kernel's Params read afresh from the kernarg segment (the first argument sits at offset 0).  The packet kernel asks for
 // them once per stage of a group — generation, traversal, hit store: read once at kernel entry, the ~60 scalars of camera,
@@ -1556,7 +1569,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 	uint32_t *const head = &p.wv.counters->work[p.queue][0];
 	const uint32_t lane = __lane_id();
 	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
-	run = run > (uint32_t)RT_STREAM_CHUNK ? (uint32_t)RT_STREAM_CHUNK : (run < 64u ? 64u : (run & ~63u));
+	run = run > (uint32_t)RT_PACKET_CHUNK ? (uint32_t)RT_PACKET_CHUNK : (run < 64u ? 64u : (run & ~63u));
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
 	uint32_t nrays = 0;
