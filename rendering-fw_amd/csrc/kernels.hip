@@ -627,7 +627,7 @@ RT_FN void resolve_item(const Params &p, uint32_t li)
 	const uint32_t x = li % p.fr.W, yl = li / p.fr.W;
 	if (local_to_global_row(p.fr, yl) >= p.fr.H)
 		return;
-	const uint32_t tile = (yl / TILE) * p.fr.tiles_x + x / TILE, pix = (yl % TILE) * TILE + (x % TILE);
+	const uint32_t tile = (yl / TILE) * p.fr.tiles_x + x / TILE, pix = tile_pix(x % TILE, yl % TILE);
 	f4 a = p.wv.acc[li];
 	const uint32_t g = 1u << p.fr.sgroup_log2;
 	for (uint32_t s0 = 0; s0 < p.fr.spp; s0 += g)

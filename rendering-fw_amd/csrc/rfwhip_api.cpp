@@ -2791,7 +2791,7 @@ extern "C" int rfwhip_read_primary_hits(rfwhip_context *c, float *t, int32_t *pr
 			if (parity && (x >= (c->W / 4u) * 4u || y >= (c->H / 2u) * 2u))
 				continue;
 			const uint32_t tile = (yl / rt::TILE) * c->fr.tiles_x + x / rt::TILE;
-			const size_t slot = (size_t)rt::pixel_to_slot(fr, tile, (yl % rt::TILE) * rt::TILE + (x % rt::TILE), 0u);
+			const size_t slot = (size_t)rt::pixel_to_slot(fr, tile, rt::tile_pix(x % rt::TILE, yl % rt::TILE), 0u);
 			const size_t o = (size_t)y * c->W + x;
 			int pr;
 			memcpy(&pr, &h[slot].w, 4);

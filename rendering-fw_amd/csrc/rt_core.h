@@ -292,7 +292,7 @@ RT_FN float random_float(uint32_t &s)
 // pixel <-> path-slot mapping.  Within one sample, pixels run over 8x8 tiles, tiles row-major over the rank's compacted local
 // image.  Samples of a batch are laid out in GROUPS of g = 2^sgroup_log2 (g <= 64, every sub-batch of a call is a multiple
 // of g): one group of one tile is 64 g consecutive slots, pixel-major —
-//     slot = sgroup * (g * slots) + tile * 64 g + pix * g + si,        sample = sgroup * g + si, pix = 0..63 row-major,
+//     slot = sgroup * (g * slots) + tile * 64 g + pix * g + si,        sample = sgroup * g + si, pix = 0..63 in Z order (tile_pix),
 // so a wave (64 consecutive slots) holds the g samples of 64 / g neighbouring pixels.  g = 1 is the plain layout (slot =
 // s * slots + tile * 64 + pix: a wave = one 8x8 tile of one sample).  With g = 32 a wave is 2 neighbouring pixels x 32
 // samples: its primary rays differ by sub-pixel jitter only, walk the same nodes and reach the same leaves in step — the
@@ -321,8 +321,8 @@ RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
 	const uint32_t tile = rem >> (6u + gl), pix = (rem >> gl) & 63u;
 	p.sample = (sgroup << gl) + (rem & ((1u << gl) - 1u));
 	const uint32_t ty = fast_div(tile, fr.div_tiles_x), tx = tile - ty * fr.tiles_x;
-	p.x = tx * TILE + (pix & 7u);
-	const uint32_t yl = ty * TILE + (pix >> 3);
+	p.x = tx * TILE + tile_pix_x(pix);
+	const uint32_t yl = ty * TILE + tile_pix_y(pix);
 	p.y = local_to_global_row(fr, yl);
 	p.local = yl * fr.W + p.x;
 	p.valid = p.x < fr.W && p.y < fr.H;
