@@ -1075,8 +1075,11 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	// wave of the shadow rays the first vertices emit walks the same nodes in step — are refilled only as a whole: a partial
 	// refill mixes rays at different stages into the wave and the two phases of the traversal fall out of step again (MI355X,
 	// 32 samples per group: depth-0 shadow wave 6.40 -> 5.63 ms per 32-spp launch; the vote threshold stays: 48 / 64 lose 2-7 %)
+#ifndef RT_REFILL_ANY0
+#define RT_REFILL_ANY0 48u
+#endif
 	if (MODE == STREAM_ANY && p.depth == 0 && p.fr.sgroup_log2 >= 3u)
-		REFILL = 64u;
+		REFILL = RT_REFILL_ANY0;
 	constexpr int VOTE = MODE == STREAM_ANY ? RT_LEAF_VOTE_ANY : RT_LEAF_VOTE_EXT;
 	for (;;)
 	{
@@ -1670,7 +1673,14 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	ClkProbe clk;
 	clk.last = __builtin_readcyclecounter(), clk.acc = s_clk[wave];
 #endif
-	uint32_t c = blockIdx.x * (BLOCK / 64u) + wave; // this wave's next chunk
+#ifndef RT_SHADE_RUN
+#define RT_SHADE_RUN 32u
+#endif
+	// a wave walks RUNS of consecutive chunks (fewer when the launch has less than four runs per wave)
+	uint32_t srun = nchunks / (nwaves * 4u);
+	srun = srun > RT_SHADE_RUN ? RT_SHADE_RUN : (srun ? srun : 1u);
+	uint32_t c = (blockIdx.x * (BLOCK / 64u) + wave) * srun; // this wave's next chunk
+	uint32_t c_left = srun;									 // chunks left of the wave's run
 	uint32_t nq = 0;								// queued hits (wave-uniform)
 	uint32_t nm = 0;								// queued misses (RT_MISS_QUEUE)
 	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
@@ -1703,7 +1713,10 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		else if (!drain)
 		{
 			idx = c * 64u + lane;
-			c += nwaves;
+			if (--c_left)
+				c++;
+			else
+				c += (nwaves - 1u) * srun + 1u, c_left = srun;
 			bool valid = idx < count;
 			if (p.depth == 0 && valid)
 				valid = slot_to_pixel(p.fr, idx).valid;
