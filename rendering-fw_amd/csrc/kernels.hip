@@ -343,62 +343,67 @@ __device__ unsigned long long g_shade_clk[32];
 #define RT_ITEM_CLK
 #define RT_ITEM_TICK(K)
 #endif
-template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, Ctx &ctx RT_ITEM_CLK)
+// What pt_shade hands out while it runs (rt_core.h): the shadow ray — queue slot and stores at once, so that its registers are free
+// for the BSDF sampling — and the probe pixel's hit.
+struct ShadeSink
+{
+	const Params &p;
+	Ctx &ctx;
+	uint32_t slot;
+	RT_FN void probe(const Hit &h) const
+	{
+		WaveCounters *c = p.wv.counters;
+		c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
+	}
+	RT_FN void shadow(bool emit, const f4 &so, const f4 &sd, const f4 &se)
+	{
+		const uint32_t si = ctx.alloc(ctx.q_shadow, emit, &p.wv.counters->shadow_n[p.depth]);
+		if (emit)
+		{
+			p.wv.sh_org[si] = so;
+			p.wv.sh_dir[si] = sd;
+			// Depth 0 with a connection buffer: the slot's connection term starts as what the shadow ray of this vertex would add if
+			// the light is visible — 0 + e: the bits an accumulation onto a zeroed slot produces — and the connection wave of depth 0
+			// only ZEROES it for an occluded light (connect_finish): that wave then retires a ray without reading anything (the
+			// contribution record and the wait for it were 8 % of a shadow wave's time), and no contribution record is written here.
+			if (p.depth != 0 || !p.wv.rad_nee)
+				p.wv.sh_rad[si] = se;
+			else
+				p.wv.rad_nee[slot] = mk4(0.0f + se.x, 0.0f + se.y, 0.0f + se.z, 0.0f);
+		}
+	}
+};
+
+// One entry of the wave of depth p.depth.  `active` = the lane holds a path (the device kernel's scan has checked that the entry is
+// a path's: not void, at depth 0 a real pixel's slot); h4 / hi = its hit record (the device kernel's scan has read them already).
+template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool active, const f4 &h4, int hi, Ctx &ctx RT_ITEM_CLK)
 {
 	RT_ITEM_TICK(0);
 	const uint32_t b = p.depth & 1u, nb = b ^ 1u;
 	ShadeOut out;
-	out.radiance = mk3(0, 0, 0);
-	out.emit_shadow = false, out.emit_ext = false;
-	uint32_t slot = 0;
-	bool write_rad = false;
-	// the primary wave has one entry per path slot, including the padding slots of partial tiles / strips whose
-	// records were never written: validity comes from the slot index, not from the buffers
-	PixelRef pr;
-	pr.x = 0, pr.y = 0, pr.local = 0, pr.sample = 0, pr.valid = false;
-	if (p.depth == 0 && active)
-	{
-		pr = slot_to_pixel(p.fr, i); // (the primary wave's entry i IS path slot i: no second mapping below)
-		active = pr.valid;
-	}
+	PathIn in;
+	in.O = mk3(0, 0, 0), in.D = mk3(0, 0, 1), in.T = mk3(1, 1, 1), in.bsdfPdf = 1.0f;
+	in.slot = 0, in.flags = 0, in.packedN = 0, in.depth = p.depth;
+	Hit h;
+	h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = hi;
 	if (active)
 	{
 		// (depth 0 behind a pinhole camera: no origin record was written — the origin is the camera, the slot is the entry)
 		const f4 o4 = (p.depth == 0 && p.cam.aperture == 0.0f) ? mk4(p.cam.pos.x, p.cam.pos.y, p.cam.pos.z, ubits((i << 1) | 1u)) : p.wv.org[b][i];
 		const f4 d4 = p.wv.dir[b][i];
-		const f4 h4 = (p.depth == 0 ? p.wv.hit0 : p.wv.hit)[i];
-		const int hi = (p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst)[i];
-		PathIn in;
 		in.O = xyz(o4), in.D = xyz(d4);
 		const uint32_t ow = fbits(o4.w);
 		in.slot = ow >> 1, in.flags = ow & 1u, in.packedN = fbits(d4.w);
-		slot = in.slot;
-		if (p.depth == 0)
-			in.T = mk3(1, 1, 1), in.bsdfPdf = 1.0f;
-		else
+		if (p.depth != 0)
 		{
 			const f4 t4 = p.wv.thr[b][i];
 			in.T = xyz(t4), in.bsdfPdf = t4.w;
 		}
-		if (p.depth != 0)
-			pr = slot_to_pixel(p.fr, in.slot);
-		{
-			in.pixel = pr.y * p.fr.W + pr.x;
-			in.px = pr.x, in.py = pr.y;
-			in.sampleIdx = p.fr.sample_base + pr.sample;
-			in.depth = p.depth;
-			Hit h;
-			h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = hi;
-			if (p.depth == 0 && h.prim >= 0 && pr.sample == 0 && in.pixel == p.fr.probe_pixel)
-			{
-				WaveCounters *c = p.wv.counters;
-				c->probe_inst = (uint32_t)h.inst, c->probe_prim = (uint32_t)h.prim, c->probe_dist = h.t, c->probe_valid = 1u;
-			}
-			pt_shade<TEX>(p.sc, p.cam, p.max_depth, in, h, out, ctx.pot RT_CLK_ARG);
-			write_rad = true;
-		}
 	}
-	if (write_rad)
+	const uint32_t slot = in.slot;
+	ShadeSink sink{p, ctx, slot};
+	pt_shade<TEX>(p.sc, p.cam, p.fr, p.max_depth, active, in, h, out, ctx.pot, sink RT_CLK_ARG);
+	if (active)
 	{
 		// depth 0 initialises the slot (no clear pass); later depths accumulate.  One path per slot => no race.
 		if (p.depth == 0)
@@ -408,14 +413,9 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 			// 16 bytes less written here and 16 less read there for every such path (two in five on the terrain).
 			const bool ends = p.wv.rad_nee && !out.emit_shadow && !out.emit_ext;
 			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, ends ? -1.0f : 1.0f);
-			// The slot's connection term starts as what the shadow ray of this vertex would add if the light is visible — 0 + e: the
-			// bits an accumulation onto a zeroed slot produces — and the connection wave of depth 0 only ZEROES it for an occluded
-			// light (connect_finish): that wave then retires a ray without reading anything (the contribution record and the wait for
-			// it were 8 % of a shadow wave's time), and no contribution record is written here.  Paths that emit no shadow ray but
-			// go on start theirs at zero.
-			if (p.wv.rad_nee && out.emit_shadow)
-				p.wv.rad_nee[slot] = mk4(0.0f + out.se.x, 0.0f + out.se.y, 0.0f + out.se.z, 0.0f);
-			else if (p.wv.rad_nee && out.emit_ext)
+			// (a path with a shadow ray: ShadeSink::shadow has stored its connection term)  Paths that emit no shadow ray but go on
+			// start theirs at zero.
+			if (p.wv.rad_nee && out.emit_ext && !out.emit_shadow)
 				p.wv.rad_nee[slot] = mk4(0, 0, 0, 0);
 		}
 		else if (out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
@@ -428,16 +428,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		}
 	}
 	RT_ITEM_TICK(7);
-	WaveCounters *c = p.wv.counters;
-	const uint32_t si = ctx.alloc(ctx.q_shadow, out.emit_shadow, &c->shadow_n[p.depth]);
-	if (out.emit_shadow)
-	{
-		p.wv.sh_org[si] = out.so;
-		p.wv.sh_dir[si] = out.sd;
-		if (p.depth != 0 || !p.wv.rad_nee) // (depth 0 with a connection buffer: the term already waits in its slot, above)
-			p.wv.sh_rad[si] = out.se;
-	}
-	const uint32_t ei = ctx.alloc(ctx.q_ext, out.emit_ext, &c->ext_n[p.depth + 1]);
+	const uint32_t ei = ctx.alloc(ctx.q_ext, out.emit_ext, &p.wv.counters->ext_n[p.depth + 1]);
 	if (out.emit_ext)
 	{
 		p.wv.org[nb][ei] = out.eo;
@@ -1654,10 +1645,20 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	// No workgroup barrier anywhere (round 1's per-256 compaction parked the waves without hits at a barrier, holding
 	// their SIMD slots, while the others shaded), and the expensive path always runs with all lanes.  Which lane shades a
 	// path does not affect its result.
-	__shared__ uint32_t s_hits[BLOCK / 64][RT_MISS_QUEUE ? 256 : 128];
+	// Round 6: the queues are RINGS of 128 entries (nothing moves down when a wave of entries leaves), and a queued hit keeps the hit
+	// record and instance the scan has read beside its entry — the scan's loads are coalesced and fetched the whole records' lines
+	// anyway; the shading then starts at "instance -> shading record" instead of at a second, gathered read of both.
+	constexpr uint32_t QN = 128u, QM = QN - 1u;
+	__shared__ f4 s_qhit[BLOCK / 64][QN];
+	__shared__ uint32_t s_qidx[BLOCK / 64][QN];
+	__shared__ int s_qinst[BLOCK / 64][QN];
+	__shared__ uint32_t s_qmiss[BLOCK / 64][QN];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t *const q = s_hits[wave];
+	f4 *const qhit = s_qhit[wave];
+	uint32_t *const qidx = s_qidx[wave], *const qmiss = s_qmiss[wave];
+	int *const qinst = s_qinst[wave];
 	const f4 *const hits = p.depth == 0 ? p.wv.hit0 : p.wv.hit;
+	const int *const insts = p.depth == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
 	const uint32_t nchunks = (count + 63u) / 64u;
 	const uint32_t nwaves = gridDim.x * (BLOCK / 64u);
 	// queue block: QUEUE_BLOCK slots for big launches; a launch so small that a wave would leave most of a block empty
@@ -1681,34 +1682,32 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	srun = srun > RT_SHADE_RUN ? RT_SHADE_RUN : (srun ? srun : 1u);
 	uint32_t c = (blockIdx.x * (BLOCK / 64u) + wave) * srun; // this wave's next chunk
 	uint32_t c_left = srun;									 // chunks left of the wave's run
-	uint32_t nq = 0;								// queued hits (wave-uniform)
-	uint32_t nm = 0;								// queued misses (RT_MISS_QUEUE)
+	uint32_t hq = 0, nq = 0;						// hit queue: first entry, entries (wave-uniform)
+	uint32_t mq = 0, nm = 0;						// miss queue
 	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
-	// (fetching a chunk's primitive ids one chunk ahead, so that a scan is not a memory round trip with nothing beside it, costs
-	// a register the shading needs: shade alone 8.55 -> 9.0 ms per sub-batch, 4640 -> 4540 Msamples/s.  Not done.)
 #pragma nounroll
 	for (;;)
 	{
 		uint32_t idx = 0;
 		bool act = false;
+		f4 h4 = mk4(0, 0, 0, ubits((uint32_t)-1));
+		int hi = -1;
 		const bool drain = c >= nchunks;
 		const bool take_hits = nq >= 64u || (drain && nq > 0u);
-		if (take_hits || (RT_MISS_QUEUE && (nm >= 64u || (drain && nm > 0u))))
+		if (take_hits)
 		{
-			// one wave of queued paths (hits before misses); the rest of that queue moves down
-			uint32_t *const qq = (RT_MISS_QUEUE && !take_hits) ? q + 128 : q;
-			const uint32_t have = take_hits ? nq : nm;
-			const uint32_t n = have < 64u ? have : 64u, rest = have - n;
-			nshaded += take_hits ? n : 0u;
+			const uint32_t n = nq < 64u ? nq : 64u, e = (hq + lane) & QM;
+			nshaded += n;
 			act = lane < n;
-			idx = act ? qq[lane] : 0u;
-			const uint32_t moved = lane < rest ? qq[64u + lane] : 0u;
-			if (lane < rest)
-				qq[lane] = moved;
-			if (take_hits)
-				nq = rest;
-			else
-				nm = rest;
+			idx = qidx[e], h4 = qhit[e], hi = qinst[e];
+			hq = (hq + n) & QM, nq -= n;
+		}
+		else if (nm >= 64u || (drain && nm > 0u))
+		{
+			const uint32_t n = nm < 64u ? nm : 64u;
+			act = lane < n;
+			idx = qmiss[(mq + lane) & QM];
+			mq = (mq + n) & QM, nm -= n;
 		}
 		else if (!drain)
 		{
@@ -1720,32 +1719,33 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			bool valid = idx < count;
 			if (p.depth == 0 && valid)
 				valid = slot_to_pixel(p.fr, idx).valid;
-			const int prim = valid ? (int)fbits(hits[idx].w) : HIT_VOID;
+			if (valid)
+				h4 = hits[idx], hi = insts[idx];
+			const int prim = valid ? (int)fbits(h4.w) : HIT_VOID;
 			const bool is_hit = prim >= 0;
 			const unsigned long long m = __ballot(is_hit);
 			if (is_hit)
-				q[nq + wave_prefix(m)] = idx;
-			nq += (uint32_t)__popcll(m);
-			act = prim == -1; // a miss; HIT_VOID entries (unfilled queue slots) are nobody's path
-			const unsigned long long mm = __ballot(act);
-			if (RT_MISS_QUEUE)
 			{
-				// the misses of a bounce wave are mixed lane by lane with its hits as well: they wait for a full wave too
-				if (act)
-					q[128u + nm + wave_prefix(mm)] = idx;
-				nm += (uint32_t)__popcll(mm);
-				continue;
+				const uint32_t e = (hq + nq + wave_prefix(m)) & QM;
+				qidx[e] = idx, qhit[e] = h4, qinst[e] = hi;
 			}
-			if (mm == 0ull)
-				continue;
+			nq += (uint32_t)__popcll(m);
+			// a miss; HIT_VOID entries (unfilled queue slots) and HIT_MISS_SHADED ones (finished by the primary kernel) are nobody's
+			// path.  The misses of a bounce wave are mixed lane by lane with its hits: they wait for a full wave too.
+			const bool is_miss = prim == -1;
+			const unsigned long long mm = __ballot(is_miss);
+			if (is_miss)
+				qmiss[(mq + nm + wave_prefix(mm)) & QM] = idx;
+			nm += (uint32_t)__popcll(mm);
+			continue;
 		}
 		else
 			break;
 		__builtin_amdgcn_wave_barrier();
 #if defined(RT_DIAG_SHADE_CLOCK)
-		shade_pt_item<TEX>(p, idx, act, ctx, &clk);
+		shade_pt_item<TEX>(p, idx, act, h4, hi, ctx, &clk);
 #else
-		shade_pt_item<TEX>(p, idx, act, ctx);
+		shade_pt_item<TEX>(p, idx, act, h4, hi, ctx);
 #endif
 	}
 #if defined(RT_DIAG_SHADE_CLOCK)

@@ -301,6 +301,7 @@ struct MeshRec
 	uint32_t n4_base = 0;
 	std::vector<f4> leaf_verts;		   // 3 per leaf slot (host staging for (re)upload)
 	std::vector<rt::TriShade> shade;   // mesh order
+	std::vector<rt::TriUV> uv;		   // mesh order (texture coordinates: rt_types.h)
 	float bounds_min[3] = {0, 0, 0}, bounds_max[3] = {0, 0, 0};
 	DevBuf d_verts, d_indices;		   // raw vertices / indices (kept for refit)
 	DevBuf d_parents, d_flags;		   // refit helpers
@@ -451,7 +452,7 @@ struct rfwhip_context
 	DevBuf d_nodes4f; // float form of d_nodes4 (rt::Node4f), refreshed at the end of every rfwhip_update that may need it
 	bool nodes4f_current = false; // ... which is when the packet form of the primary wave can run (packet_ok, refill bit 3)
 	size_t nodes4_live = 0;		  // 4-wide nodes in use: all mesh trees + the top-level tree
-	DevBuf d_nodes, d_nodes4, d_nodes4_src, d_tri_verts, d_tri_shade, d_tlas_prims, d_instances;
+	DevBuf d_nodes, d_nodes4, d_nodes4_src, d_tri_verts, d_tri_shade, d_tri_uv, d_tlas_prims, d_instances;
 	size_t blas_nodes4 = 0, node4_capacity = 0; // d_nodes4 = [all BLAS 4-wide nodes | TLAS 4-wide nodes | spare]
 	DevBuf d_materials, d_textures, d_tex_u32, d_tex_f4, d_sky, d_area, d_point, d_spot, d_dir;
 	uint32_t material_count = 0, texture_count = 0, sky_w = 0, sky_h = 0;
@@ -625,7 +626,7 @@ static void free_all(rfwhip_context *c)
 	}
 	c->d_lbvh_scratch.free_(), c->d_blue_noise.free_();
 	c->have_blue_noise = false;
-	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4f, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tlas_prims, &c->d_instances,
+	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4f, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tri_uv, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
 					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org[0], &c->d_sh_org[1],
@@ -829,6 +830,7 @@ extern "C" int rfwhip_set_materials(rfwhip_context *c, const rfwhip_material *ma
 static void fill_shade_records(MeshRec &m, const rfwhip_triangle *tris)
 {
 	m.shade.resize(m.triCount);
+	m.uv.resize(m.triCount);
 	m.max_material = 0;
 	for (size_t i = 0; i < m.triCount; i++)
 	{
@@ -839,9 +841,9 @@ static void fill_shade_records(MeshRec &m, const rfwhip_triangle *tris)
 		s.n2 = f4{t.vN2[0], t.vN2[1], t.vN2[2], t.Nz};
 		float lt, mt;
 		memcpy(&lt, &t.lightTriIdx, 4), memcpy(&mt, &t.material, 4);
-		s.tu = f4{t.u0, t.u1, t.u2, lt};
-		s.tv = f4{t.v0, t.v1, t.v2, mt};
-		s.ex = f4{t.area, t.LOD, 0.0f, 0.0f};
+		s.ex = f4{t.area, t.LOD, lt, mt};
+		m.uv[i].tu = f4{t.u0, t.u1, t.u2, 0.0f};
+		m.uv[i].tv = f4{t.v0, t.v1, t.v2, 0.0f};
 		m.max_material = std::max(m.max_material, t.material);
 	}
 }
@@ -928,6 +930,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		for (int a = 0; a < 3; a++)
 			m.bounds_min[a] -= 2e-5f, m.bounds_max[a] += 2e-5f;
 		RF_TRY(dm::h2d(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.shade.data(), m.shade.size() * sizeof(rt::TriShade), c->stream));
+		RF_TRY(dm::h2d(c->d_tri_uv.as<rt::TriUV>() + m.shade_base, m.uv.data(), m.uv.size() * sizeof(rt::TriUV), c->stream));
 		dm::event_t ea, eb;
 		const bool timed = c->stage_timing != 0;
 		if (timed)
@@ -1470,6 +1473,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 		RF_TRY(c->d_nodes4_src.ensure(4 * mesh_nodes4 * sizeof(uint32_t)));
 		RF_TRY(c->d_tri_verts.ensure(3 * tris * sizeof(f4)));
 		RF_TRY(c->d_tri_shade.ensure(mesh_tris * sizeof(rt::TriShade)));
+		RF_TRY(c->d_tri_uv.ensure(mesh_tris * sizeof(rt::TriUV)));
 		// One mesh at a time.  Device form everywhere: left_first / entries carry ready-made stack entries (rt::make_entry)
 		// with ABSOLUTE indices — node index into the scene-wide arrays, leaf-ordered triangle index into tri_verts.
 		std::vector<rt::Node> nodes2;
@@ -1527,6 +1531,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 				RF_TRY(dm::sync(c->stream)); // the staging vectors are reused by the next mesh
 			}
 			RF_TRY(dm::h2d(c->d_tri_shade.as<rt::TriShade>() + m.shade_base, m.shade.data(), m.shade.size() * sizeof(rt::TriShade), c->stream));
+		RF_TRY(dm::h2d(c->d_tri_uv.as<rt::TriUV>() + m.shade_base, m.uv.data(), m.uv.size() * sizeof(rt::TriUV), c->stream));
 		}
 		if (world.valid)
 		{
@@ -1723,6 +1728,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	sv.nodes4 = c->d_nodes4.as<rt::Node4c>(), sv.nodes4f = c->d_nodes4f.as<rt::Node4f>();
 	sv.nodes = c->d_nodes.as<rt::Node>(), sv.tri_verts = c->d_tri_verts.as<f4>();
 	sv.tri_shade = c->d_tri_shade.as<rt::TriShade>();
+	sv.tri_uv = c->d_tri_uv.as<rt::TriUV>();
 	sv.tlas_prims = c->d_tlas_prims.as<uint32_t>();
 	sv.instances = c->d_instances.as<rt::Instance>();
 	sv.tlas_root_entry = c->tlas_root_entry, sv.instance_count = c->instance_count;

@@ -1114,15 +1114,16 @@ RT_FN f4 parity_shade(const SceneView &sc, f3 O, f3 D, const Hit &h, TravStack &
 	const TriShade &ts = sc.tri_shade[in.shade_base + (uint32_t)h.prim];
 	const f3 bary = mk3(1.0f - h.u - h.v, h.u, h.v);
 	const f3 p = O + D * h.t;
-	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, tv4 = ts.tv;
-	const MaterialRec &mat = sc.materials[fbits(tv4.w)];
+	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
+	const MaterialRec &mat = sc.materials[fbits(ts.ex.w)];
 	const f3 iNl = (xyz(n0) * bary.x + xyz(n1) * bary.y) + xyz(n2) * bary.z;
 	const f3 iN = normalize_ieee(mul_normal(in, iNl));
 	f3 color = material_color(mat);
 	const uint32_t mflags = mat.flags;
 	if (mat_flag(mflags, MF_DIFFUSE_MAP))
 	{
-		const f4 tu4 = ts.tu;
+		const TriUV &uv = sc.tri_uv[in.shade_base + (uint32_t)h.prim];
+		const f4 tu4 = uv.tu, tv4 = uv.tv;
 		const float tu = bary.x * tu4.x + bary.y * tu4.y + bary.z * tu4.z;
 		const float tv = bary.x * tv4.x + bary.y * tv4.y + bary.z * tv4.z;
 		const float uu = (tu + half_to_float(mat.map[0].uoffs)) * half_to_float(mat.map[0].uscale);
@@ -1724,59 +1725,59 @@ struct PathIn
 	f3 O, D, T;
 	float bsdfPdf;
 	uint32_t slot, flags, packedN;
-	uint32_t pixel;		// global pixel id y*W + x (RNG key)
-	uint32_t px, py;	// the same pixel as coordinates (blue-noise tile lookup)
-	uint32_t sampleIdx; // global sample index (RNG key)
-	uint32_t depth;		// pathLength
+	uint32_t depth; // pathLength
 };
 struct ShadeOut
 {
 	f3 radiance; // to add to the path's slot
 	bool emit_shadow, emit_ext;
-	f4 so, sd, se; // shadow ray: origin|slot, dir|tmax, contribution
 	f4 eo, ed, et; // extension ray: origin|slot<<1|flags, dir|packedN, throughput|pdf
 };
 
-// the surface at a hit: shading record, material, barycentric weights, geometric / shading normal in world space, tangent frame
+// the surface at a hit: shading record, material, barycentric weights, geometric / shading normal in world space
 struct Surface
 {
-	f4 tu4, tv4, ex;
+	float area, lod;
+	int ltri;
+	uint32_t shade_idx; // index of the triangle's records in tri_shade / tri_uv
 	const MaterialRec *mat;
-	const Instance *inst;
 	uint32_t mflags;
 	float bw0, bw1, bw2;
-	f3 N, iN, Tg, Bt;
+	f3 N, iN;
 };
 RT_FN void pt_surface(const SceneView &sc, const Hit &h, Surface &sf)
 {
-	sf.inst = &sc.instances[h.inst];
-	const TriShade &ts = sc.tri_shade[sf.inst->shade_base + (uint32_t)h.prim];
-	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
-	sf.tu4 = ts.tu, sf.tv4 = ts.tv, sf.ex = ts.ex;
-	sf.mat = &sc.materials[fbits(sf.tv4.w)];
+	const Instance &inst = sc.instances[h.inst];
+	sf.shade_idx = inst.shade_base + (uint32_t)h.prim;
+	const TriShade &ts = sc.tri_shade[sf.shade_idx];
+	const f4 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2, ex = ts.ex;
+	sf.area = ex.x, sf.lod = ex.y, sf.ltri = (int)fbits(ex.z);
+	sf.mat = &sc.materials[fbits(ex.w)];
 	sf.mflags = sf.mat->flags;
 	// getShadingData.h:100-217 (its u,v,w weight vertex 0,1,2)
 	sf.bw0 = 1.0f - h.u - h.v, sf.bw1 = h.u, sf.bw2 = h.v;
 	f3 N = mk3(n0.w, n1.w, n2.w), iN = N;
 	if (mat_flag(sf.mflags, MF_SMOOTH_NORMALS))
 		iN = normalize((xyz(n0) * sf.bw0 + xyz(n1) * sf.bw1) + xyz(n2) * sf.bw2);
-	sf.N = normalize(mul_normal(*sf.inst, N));
-	sf.iN = normalize(mul_normal(*sf.inst, iN));
-	create_tangent_space(sf.iN, sf.Tg, sf.Bt);
+	sf.N = normalize(mul_normal(inst, N));
+	sf.iN = normalize(mul_normal(inst, iN));
 }
 RT_FN bool pt_has_textures(const SceneView &sc, const Surface &sf)
 {
 	return mat_flag(sf.mflags, MF_DIFFUSE_MAP) && sf.mat->map[0].addr < sc.texture_count;
 }
-// the texture layers of a textured hit: color = the material's colour on entry
+// the texture layers of a textured hit: color = the material's colour on entry; Tg / Bt = the tangent frame of the unperturbed
+// shading normal (tools.h:204-211)
 RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, const Surface &sf, f3 &color, f3 &iN, bool &alpha_skip)
 {
 	const MaterialRec &mat = *sf.mat;
 	const uint32_t mflags = sf.mflags;
-	const float tu = sf.bw0 * sf.tu4.x + sf.bw1 * sf.tu4.y + sf.bw2 * sf.tu4.z;
-	const float tv = sf.bw0 * sf.tv4.x + sf.bw1 * sf.tv4.y + sf.bw2 * sf.tv4.z;
+	const TriUV &uv = sc.tri_uv[sf.shade_idx];
+	const f4 tu4 = uv.tu, tv4 = uv.tv;
+	const float tu = sf.bw0 * tu4.x + sf.bw1 * tu4.y + sf.bw2 * tu4.z;
+	const float tv = sf.bw0 * tv4.x + sf.bw1 * tv4.y + sf.bw2 * tv4.z;
 	const float coneWidth = cam.spread_angle * t;
-	const float lambda = sf.ex.y + m_log2f(coneWidth * m_rcp(fabsf(dot(D * -1.0f, sf.N))));
+	const float lambda = sf.lod + m_log2f(coneWidth * m_rcp(fabsf(dot(D * -1.0f, sf.N))));
 	// map slots: 0-2 diffuse layers, 3-5 normal-map layers (structs.h:98-115)
 #define RT_LAYER(K) \
 	fetch_trilinear(sc, sc.textures[mat.map[K].addr], lambda,                                          \
@@ -1811,7 +1812,9 @@ RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, c
 			if (mat_flag(mflags, MF_3RD_NORMAL_MAP) && mat.map[4].addr < sc.texture_count)
 				sn = sn + RT_NORMAL_LAYER(4);
 			sn = normalize(sn);
-			iN = normalize((sf.Tg * sn.x + sf.Bt * sn.y) + iN * sn.z); // tangentToWorld, tools.h:214
+			f3 Tg, Bt;
+			create_tangent_space(sf.iN, Tg, Bt);
+			iN = normalize((Tg * sn.x + Bt * sn.y) + iN * sn.z); // tangentToWorld, tools.h:214
 		}
 		// getShadingData.h:150 and :206 both multiply by the texel
 		color = color * xyz(texel);
@@ -1819,156 +1822,199 @@ RT_FN void pt_textures(const SceneView &sc, const CamView &cam, f3 D, float t, c
 #undef RT_LAYER
 #undef RT_NORMAL_LAYER
 }
+// One path vertex, in PHASES every lane of the calling wave passes through together (round 6: until then the function returned from
+// half a dozen places and handed both of its rays back at the end — the shadow ray's twelve registers stayed live across the BSDF
+// sampling, the tangent frame and the absorption across the light sampling):
+//   1. surface: sky for a miss; shading record, material, texture layers; alpha pass-through and emitters end here;
+//   2. next-event estimation (Kernels.cu:702-755) -> the shadow ray, handed to `sink.shadow()` AT ONCE — the kernel allocates its
+//      queue slot and stores it there and then (a wave-wide ballot: every lane calls it, with emit = false when it has no ray);
+//   3. BSDF sampling (Kernels.cu:758-793) -> the extension ray in `out`.  What only this phase needs is produced here: the tangent
+//      frame (from the unperturbed shading normal: flip * flip = 1 takes the plain kernel back to it exactly), the absorption
+//      (re-read from the material for a back-facing hit of a transmissive one), SafeOrigin (the same point as the shadow ray's).
 // TEX = false: the scene has no material with a texture or normal map (the host knows: rfwhip_set_materials) — the texture
 // layers, their descriptors and the level-of-detail arithmetic are compiled out, which frees a fifth of the registers.
-template <bool TEX>
-RT_FN void pt_shade(const SceneView &sc, const CamView &cam, uint32_t max_depth, const PathIn &in, const Hit &h,
-					ShadeOut &out, float *pot_cache RT_CLK_PARAM)
+template <bool TEX, class Sink>
+RT_FN void pt_shade(const SceneView &sc, const CamView &cam, const FrameView &fr, uint32_t max_depth, bool active, const PathIn &in,
+					const Hit &h, ShadeOut &out, float *pot_cache, Sink &sink RT_CLK_PARAM)
 {
 	out.radiance = mk3(0, 0, 0);
 	out.emit_shadow = false, out.emit_ext = false;
-	const f3 O = in.O, D = in.D;
+	const f3 D = in.D;
 	f3 T = in.T;
 	RT_TICK(1);
-	if (h.prim < 0)
-	{
-		f3 contribution = (T * m_rcp(in.bsdfPdf)) * pt_sky(sc, D);
-		if (any_nan(contribution))
-			return;
-		out.radiance = clamp_intensity(contribution, cam.clamp_value);
-		RT_TICK(2);
-		return;
-	}
-	const f3 I = O + D * h.t;
-	Surface sf;
-	pt_surface(sc, h, sf);
-	RT_TICK(3);
-	const MaterialRec &mat = *sf.mat;
-	const f4 tu4 = sf.tu4, ex = sf.ex;
+	// state of a path that goes on from a surface (phases 2 and 3)
+	bool regular = false;
+	f3 I = mk3(0, 0, 0), N = mk3(0, 0, 1), iN = mk3(0, 0, 1), iN0 = mk3(0, 0, 1);
 	Shading sd;
-	sd.color = material_color(mat);
-	sd.absorption = mk3(half_to_float(mat.transmittance[0]), half_to_float(mat.transmittance[1]),
-						half_to_float(mat.transmittance[2]));
-	sd.p0 = mat.parameters[0], sd.p1 = mat.parameters[1], sd.p2 = mat.parameters[2];
-	f3 N = sf.N, iN = sf.iN;
-	const f3 Tg = sf.Tg, Bt = sf.Bt;
-	bool alpha_skip = false;
-	if (TEX && pt_has_textures(sc, sf))
-		pt_textures(sc, cam, D, h.t, sf, sd.color, iN, alpha_skip);
-	// alpha pass-through (Kernels.cu:633-647): the path continues behind the surface, state untouched
-	if (alpha_skip)
+	sd.color = mk3(0, 0, 0), sd.absorption = mk3(0, 0, 0), sd.p0 = 0, sd.p1 = 0, sd.p2 = 0;
+	const MaterialRec *matp = nullptr;
+	uint32_t flags = in.flags, seed = 0;
+	float flip = 1.0f;
+	f4 so = mk4(0, 0, 0, 0), sdir = mk4(0, 0, 0, 0), se = mk4(0, 0, 0, 0);
+	bool emit_shadow = false;
+	if (!active)
 	{
-		if (in.depth < max_depth && !any_nan(T))
-		{
-			const f3 eo = I + D * 1e-5f;
-			out.emit_ext = true;
-			out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (in.flags & 1u)));
-			out.ed = mk4(D.x, D.y, D.z, ubits(in.packedN));
-			out.et = mk4(T.x, T.y, T.z, in.bsdfPdf);
-		}
-		return;
+		// (a lane without a path: it only takes part in the wave-wide steps)
 	}
-	// emissive surface: Kernels.cu:650-692
-	if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f)
+	else if (h.prim < 0)
 	{
-		const float DdotNL = -dot(D, N);
-		f3 contribution = mk3(0, 0, 0);
-		if (DdotNL > 0)
+		const f3 contribution = (T * m_rcp(in.bsdfPdf)) * pt_sky(sc, D);
+		if (!any_nan(contribution))
+			out.radiance = clamp_intensity(contribution, cam.clamp_value);
+		RT_TICK(2);
+	}
+	else
+	{
+		I = in.O + D * h.t;
+		Surface sf;
+		pt_surface(sc, h, sf);
+		RT_TICK(3);
+		const MaterialRec &mat = *sf.mat;
+		matp = sf.mat;
+		sd.color = material_color(mat);
+		sd.p0 = mat.parameters[0], sd.p1 = mat.parameters[1], sd.p2 = mat.parameters[2];
+		N = sf.N, iN = sf.iN, iN0 = sf.iN;
+		bool alpha_skip = false;
+		if (TEX && pt_has_textures(sc, sf))
+			pt_textures(sc, cam, D, h.t, sf, sd.color, iN, alpha_skip);
+		// the path's pixel and sample: the key of its random numbers (and the probe pixel of the primary wave)
+		const PixelRef pr = slot_to_pixel(fr, in.slot);
+		const uint32_t pixel = pr.y * fr.W + pr.x, sampleIdx = fr.sample_base + pr.sample;
+		if (in.depth == 0 && pr.sample == 0 && pixel == fr.probe_pixel)
+			sink.probe(h);
+		if (alpha_skip)
 		{
-			if (in.depth == 0)
-				contribution = sd.color;
-			else if (in.flags & 1u)
-				contribution = (T * sd.color) * m_rcp(in.bsdfPdf);
-			else
+			// alpha pass-through (Kernels.cu:633-647): the path continues behind the surface, state untouched
+			if (in.depth < max_depth && !any_nan(T))
 			{
-				const f3 lastN = unpack_normal(in.packedN);
-				const float lightPdf = m_div(h.t * h.t, -dot(D, N) * ex.x); // lights.h:78-81
-				const int ltri = (int)fbits(tu4.w);
-				// the reference reads the material id as light index (device_structs.h:37,40); lightTriIdx is meant
-				const float pickProb =
-					(ltri >= 0 && (uint32_t)ltri < sc.n_area) ? light_pick_prob(sc, ltri, O, lastN, I) : 0.0f;
-				if ((in.bsdfPdf + lightPdf * pickProb) <= 0)
-					return;
-				contribution = (T * sd.color) * m_rcp(in.bsdfPdf + lightPdf * pickProb);
+				const f3 eo = I + D * 1e-5f;
+				out.emit_ext = true;
+				out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (in.flags & 1u)));
+				out.ed = mk4(D.x, D.y, D.z, ubits(in.packedN));
+				out.et = mk4(T.x, T.y, T.z, in.bsdfPdf);
 			}
 		}
-		if (any_nan(contribution))
-			contribution = mk3(0, 0, 0);
-		out.radiance = clamp_intensity(contribution, cam.clamp_value);
-		return;
-	}
-	RT_TICK(4);
-	uint32_t flags = in.flags;
-	if (sd_roughness(sd) < 0.01f)
-		flags |= 1u;
-	else
-		flags &= ~1u;
-	uint32_t seed = wang_hash(in.pixel * 16789u + in.sampleIdx * 1791u + in.depth * 720898027u);
-	const float flip = (dot(D, N) > 0) ? -1.0f : 1.0f;
-	N = N * flip;
-	iN = iN * flip;
-	T = T * m_rcp(in.bsdfPdf);
-	const f3 wo = D * -1.0f;
-	// next-event estimation: Kernels.cu:702-755.  The connections of a shade call are traced by the NEXT iteration of the
-	// reference's host loop (CUDART/src/Context.cpp:109-120), so those of the last call (depth == max_depth) never are:
-	// they are not even computed here (the two random numbers they would consume are followed by no other draw).
-	if ((flags & 1u) == 0 && total_lights(sc) > 0 && in.depth < max_depth)
-	{
-		f3 lightColor = mk3(0, 0, 0);
-		float pickProb = 0, lightPdf = 0;
-		float q0, q1;
-		if (cam.blue_noise && in.sampleIdx < 256u) // BLUENOISE (Kernels.cu:712-719): the hash seed is not advanced
+		else if (sd.color.x > 1.0f || sd.color.y > 1.0f || sd.color.z > 1.0f)
 		{
-			q0 = blue_noise_sample(cam.blue_noise, (int)in.px, (int)in.py, (int)in.sampleIdx, 4);
-			q1 = blue_noise_sample(cam.blue_noise, (int)in.px, (int)in.py, (int)in.sampleIdx, 5);
-		}
-		else
-			q0 = random_float(seed), q1 = random_float(seed);
-		f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache RT_CLK_ARG) - I;
-		RT_TICK(12);
-		const float dist = length(L);
-		L = L * m_rcp(dist);
-		const float NdotL = dot(L, iN);
-		if (NdotL > 0 && lightPdf > 0)
-		{
-			const f3 bs = bsdf_eval(sd, iN, wo, L, 0.0f, false);
-			const float shadowPdf = bsdf_pdf(sd, iN, wo, L);
-			if (shadowPdf > 0)
+			// emissive surface: Kernels.cu:650-692
+			const float DdotNL = -dot(D, N);
+			f3 contribution = mk3(0, 0, 0);
+			bool drop = false;
+			if (DdotNL > 0)
 			{
-				f3 contribution = ((T * bs) * lightColor) * m_div(NdotL, shadowPdf + lightPdf * pickProb);
-				contribution = clamp_intensity(contribution, cam.clamp_value);
-				if (!any_nan(contribution))
+				if (in.depth == 0)
+					contribution = sd.color;
+				else if (in.flags & 1u)
+					contribution = (T * sd.color) * m_rcp(in.bsdfPdf);
+				else
 				{
-					const f3 so = I + N * 1e-5f; // SafeOrigin, tools.h:119-123
-					out.emit_shadow = true;
-					out.so = mk4(so.x, so.y, so.z, ubits(in.slot));
-					out.sd = mk4(L.x, L.y, L.z, dist - 2.0f * 1e-5f);
-					out.se = mk4(contribution.x, contribution.y, contribution.z, 0.0f);
+					const f3 lastN = unpack_normal(in.packedN);
+					const float lightPdf = m_div(h.t * h.t, -dot(D, N) * sf.area); // lights.h:78-81
+					const int ltri = sf.ltri;
+					// the reference reads the material id as light index (device_structs.h:37,40); lightTriIdx is meant
+					const float pickProb =
+						(ltri >= 0 && (uint32_t)ltri < sc.n_area) ? light_pick_prob(sc, ltri, in.O, lastN, I) : 0.0f;
+					if ((in.bsdfPdf + lightPdf * pickProb) <= 0)
+						drop = true;
+					else
+						contribution = (T * sd.color) * m_rcp(in.bsdfPdf + lightPdf * pickProb);
 				}
 			}
+			if (!drop)
+			{
+				if (any_nan(contribution))
+					contribution = mk3(0, 0, 0);
+				out.radiance = clamp_intensity(contribution, cam.clamp_value);
+			}
+		}
+		else
+		{
+			regular = true;
+			RT_TICK(4);
+			if (sd_roughness(sd) < 0.01f)
+				flags |= 1u;
+			else
+				flags &= ~1u;
+			seed = wang_hash(pixel * 16789u + sampleIdx * 1791u + in.depth * 720898027u);
+			flip = (dot(D, N) > 0) ? -1.0f : 1.0f;
+			N = N * flip;
+			iN = iN * flip;
+			T = T * m_rcp(in.bsdfPdf);
+			// next-event estimation: Kernels.cu:702-755.  The connections of a shade call are traced by the NEXT iteration of the
+			// reference's host loop (CUDART/src/Context.cpp:109-120), so those of the last call (depth == max_depth) never are:
+			// they are not even computed here (the two random numbers they would consume are followed by no other draw).
+			if ((flags & 1u) == 0 && total_lights(sc) > 0 && in.depth < max_depth)
+			{
+				const f3 wo = D * -1.0f;
+				f3 lightColor = mk3(0, 0, 0);
+				float pickProb = 0, lightPdf = 0;
+				float q0, q1;
+				if (cam.blue_noise && sampleIdx < 256u) // BLUENOISE (Kernels.cu:712-719): the hash seed is not advanced
+				{
+					q0 = blue_noise_sample(cam.blue_noise, (int)pr.x, (int)pr.y, (int)sampleIdx, 4);
+					q1 = blue_noise_sample(cam.blue_noise, (int)pr.x, (int)pr.y, (int)sampleIdx, 5);
+				}
+				else
+					q0 = random_float(seed), q1 = random_float(seed);
+				f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache RT_CLK_ARG) - I;
+				RT_TICK(12);
+				const float dist = length(L);
+				L = L * m_rcp(dist);
+				const float NdotL = dot(L, iN);
+				if (NdotL > 0 && lightPdf > 0)
+				{
+					const f3 bs = bsdf_eval(sd, iN, wo, L, 0.0f, false);
+					const float shadowPdf = bsdf_pdf(sd, iN, wo, L);
+					if (shadowPdf > 0)
+					{
+						f3 contribution = ((T * bs) * lightColor) * m_div(NdotL, shadowPdf + lightPdf * pickProb);
+						contribution = clamp_intensity(contribution, cam.clamp_value);
+						if (!any_nan(contribution))
+						{
+							const f3 o = I + N * 1e-5f; // SafeOrigin, tools.h:119-123
+							emit_shadow = true;
+							so = mk4(o.x, o.y, o.z, ubits(in.slot));
+							sdir = mk4(L.x, L.y, L.z, dist - 2.0f * 1e-5f);
+							se = mk4(contribution.x, contribution.y, contribution.z, 0.0f);
+						}
+					}
+				}
+			}
+			RT_TICK(5);
 		}
 	}
-	RT_TICK(5);
-	if (in.depth >= max_depth)
+	// ---- every lane: the shadow ray leaves the registers here ----
+	out.emit_shadow = emit_shadow;
+	sink.shadow(emit_shadow, so, sdir, se);
+	if (!regular || in.depth >= max_depth)
 		return;
-	f3 R = mk3(0, 0, 1);
-	float newPdf = 0.0f;
-	const float q3 = random_float(seed), q4 = random_float(seed);
-	bsdf_sample(sd, Tg, Bt, iN, wo, R, newPdf, q3, q4);
-	const f3 bs = bsdf_eval(sd, iN, wo, R, h.t, flip < 0);
+	// ---- phase 3: BSDF sampling ----
 	{
-		// throughput * 1.0f / SurvivalProbability(throughput) * bsdf * abs(dot(iN, R))   (Kernels.cu:783)
-		const float surv = survival_probability(T);
-		T = (m_div3(T, surv) * bs) * fabsf(dot(iN, R));
+		const f3 wo = D * -1.0f;
+		f3 Tg, Bt;
+		create_tangent_space(TEX ? iN0 : iN * flip, Tg, Bt);
+		if (flip < 0) // (the only reader of the absorption: bsdf_eval's back-facing branch)
+			sd.absorption = mk3(half_to_float(matp->transmittance[0]), half_to_float(matp->transmittance[1]),
+								half_to_float(matp->transmittance[2]));
+		f3 R = mk3(0, 0, 1);
+		float newPdf = 0.0f;
+		const float q3 = random_float(seed), q4 = random_float(seed);
+		bsdf_sample(sd, Tg, Bt, iN, wo, R, newPdf, q3, q4);
+		const f3 bs = bsdf_eval(sd, iN, wo, R, h.t, flip < 0);
+		{
+			// throughput * 1.0f / SurvivalProbability(throughput) * bsdf * abs(dot(iN, R))   (Kernels.cu:783)
+			const float surv = survival_probability(T);
+			T = (m_div3(T, surv) * bs) * fabsf(dot(iN, R));
+		}
+		if (newPdf < 1e-6f || (newPdf != newPdf) || T.x < 0.0f || T.y < 0.0f || T.z < 0.0f)
+			return;
+		const f3 eo = I + N * 1e-5f;
+		out.emit_ext = true;
+		out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (flags & 1u)));
+		out.ed = mk4(R.x, R.y, R.z, ubits(pack_normal(iN)));
+		out.et = mk4(T.x, T.y, T.z, newPdf);
+		RT_TICK(6);
 	}
-	if (newPdf < 1e-6f || (newPdf != newPdf) || T.x < 0.0f || T.y < 0.0f || T.z < 0.0f)
-		return;
-	const f3 eo = I + N * 1e-5f;
-	out.emit_ext = true;
-	out.eo = mk4(eo.x, eo.y, eo.z, ubits((in.slot << 1) | (flags & 1u)));
-	out.ed = mk4(R.x, R.y, R.z, ubits(pack_normal(iN)));
-	out.et = mk4(T.x, T.y, T.z, newPdf);
-	RT_TICK(6);
 }
 
 } // namespace rt

@@ -5,8 +5,9 @@
 //   * BVH2 nodes keep the reference's 32-byte layout (RFW/system/bvh/include/bvh/bvh_node.h:23-28) so that the two
 //     children of an inner node (always adjacent, pair-aligned to 64 B) arrive as four 16-byte loads.
 //   * Triangles are stored TWICE: `tri_verts` in BVH-leaf order for intersection (3 x float4, w of vertex 0 carries
-//     the original primitive id, so no index indirection at test time), and `tri_shade` in mesh order for shading
-//     (6 x float4 = 96 B instead of the reference's 160-byte AoS Triangle, structs.h:24-60).
+//     the original primitive id, so no index indirection at test time), and `tri_shade` (+ `tri_uv`) in mesh order for shading
+//     (4 x float4 = 64 B = one memory sector, + 32 B of texture coordinates only textured hits read, instead of the
+//     reference's 160-byte AoS Triangle, structs.h:24-60).
 //   * Ray / hit / throughput records are arrays of float4 indexed by the (compacted) path index: one 16-byte
 //     access per lane per attribute, 1 KiB per wave instruction.
 #pragma once
@@ -202,16 +203,24 @@ struct alignas(16) Instance
 	uint32_t shade_base; // first mesh-ordered shading record in SceneView::tri_shade
 };
 
-// Shading record per triangle (mesh order), 96 B.
+// Shading record per triangle (mesh order): 64 B = ONE 64-byte memory sector, never straddling two (round 6: the 96-byte record
+// of rounds 1-5 always cost the gather two sectors = 128 B of HBM traffic for 96 B used; the texture coordinates, which only a
+// textured material reads, moved into a record of their own).
 struct alignas(16) TriShade
 {
 	f4 n0; // vN0.xyz, Nx
 	f4 n1; // vN1.xyz, Ny
 	f4 n2; // vN2.xyz, Nz
-	f4 tu; // u0,u1,u2, bits(lightTriIdx)
-	f4 tv; // v0,v1,v2, bits(material)
-	f4 ex; // area, LOD, 0, 0
+	f4 ex; // area, LOD, bits(lightTriIdx), bits(material)
 };
+static_assert(sizeof(TriShade) == 64, "shading record = one memory sector");
+// Texture coordinates per triangle (mesh order), 32 B: read for hits on materials with a texture only.
+struct alignas(16) TriUV
+{
+	f4 tu; // u0,u1,u2, 0
+	f4 tv; // v0,v1,v2, 0
+};
+static_assert(sizeof(TriUV) == 32, "texture-coordinate record");
 
 struct TexDesc
 {
@@ -272,6 +281,7 @@ struct SceneView
 	const Node4f *nodes4f;	 // the same nodes with float planes (scalar-fetched by the packet traversal of the coherent waves)
 	const f4 *tri_verts;	 // 3 per leaf-ordered triangle
 	const TriShade *tri_shade;
+	const TriUV *tri_uv;		 // same index as tri_shade
 	const uint32_t *tlas_prims; // instance index per TLAS leaf slot
 	const Instance *instances;
 	uint32_t tlas_root_entry;
