@@ -242,10 +242,16 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  images and counters are unchanged), and static instances that are transformed or share their mesh are
  *                  written out in world space under one tree (the WORLD TREE, flatten_bytes); "0": every instance behind
  *                  a top-level leaf, the reference's two-level walk.  Takes effect with the next rfwhip_update()
- *   flatten_bytes = default 1073741824: the world tree is built as long as the world-space copy of its members' triangles
- *                  (every instance of a host-built mesh that is not animated) stays below this many bytes; "0": never.
- *                  The hit is the same triangle of the same instance at the same t as the two-level walk's up to rounding
- *                  (M p is tested instead of M^-1 o).  Animated meshes always keep the two-level walk
+ *   flatten_bytes = default 268435456 (2.4 M triangles): the world tree is built as long as the world-space copy of its members'
+ *                  triangles (every instance of a host-built mesh that is not animated) stays below this many bytes; "0":
+ *                  never.  The tree is built on the host INSIDE rfwhip_update() whenever its members change (~0.2 s per million
+ *                  member triangles on 16 cores): raise the budget for large static scenes, lower it where updates must stay
+ *                  short.  The hit is the same triangle of the same instance at the same t as the two-level walk's up to
+ *                  rounding (M p is tested instead of M^-1 o; the triangle test's determinant threshold is scaled by |det M|,
+ *                  so a triangle is rejected as degenerate exactly when the reference's object-space test rejects it).
+ *                  Animated meshes always keep the two-level walk; an instance whose matrix changes leaves the tree and
+ *                  rejoins after 8 updates without a change — 16, 32 ... after every further episode
+ *   arm          = retired (round 4's self-arming primary kernels): accepted and ignored
  *   ring         = render calls that are ONE sub-batch rotate through this many sets of wave buffers / streams / counters,
  *                  so that up to `ring` consecutive calls are in flight (1..4, default 3: three chains + the main stream
  *                  are the HIP runtime's four hardware queues; a host that keeps four frames in flight with

@@ -295,9 +295,11 @@ static inline int tri_test_ref(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 
 	}
 	return 0;
 }
-/* tie != 0 (closest-hit queries): of two triangles hit at bit-identical distance the lower primitive id wins — a total order on
- * (t, prim), so that the hit does not depend on the order a tree happens to present the triangles in (the reference keeps the
- * first it reaches; the product serves the same rays from several traversals and trees: csrc/rt_core.h, tri_test). */
+/* tie != 0 (closest-hit queries): of two triangles hit at bit-identical distance the lower (instance, primitive id) wins — a total
+ * order on (t, instance, prim), so that the hit does not depend on the order a tree happens to present the triangles in (the
+ * reference keeps the first it reaches; the product serves the same rays from several traversals and trees: csrc/rt_core.h,
+ * tri_test).  Instances are visited in rising order here, so a candidate replaces an equally distant hit only when that hit is of
+ * the SAME instance (tie == 1) and has the higher primitive id; tie == 2: the hit so far is of an earlier instance and stays. */
 static inline int tri_test_tie(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 p1, v3 p2, float *u_out, float *v_out, int tie, uint32_t prim,
 							   uint32_t cur_prim)
 {
@@ -319,7 +321,7 @@ static inline int tri_test_tie(v3 org, v3 dir, float t_min, float *t, v3 p0, v3 
 	if (v < 0.0f || u + v > 1.0f)
 		return 0;
 	const float tt = rounded(f * vdot_r(e2, q));
-	if (tt > t_min && (*t > tt || (tie && *t == tt && prim < cur_prim)))
+	if (tt > t_min && (*t > tt || (tie == 1 && *t == tt && prim < cur_prim)))
 	{
 		*t = tt;
 		*u_out = u;
@@ -548,7 +550,7 @@ typedef struct
 	uint64_t inner, tris;
 } tstat;
 
-static int blas_closest(const omesh *m, v3 o, v3 d, float t_min, float *t, int *prim, float *u, float *v, tstat *st)
+static int blas_closest(const omesh *m, v3 o, v3 d, float t_min, float *t, int *prim, float *u, float *v, tstat *st, int same_inst)
 {
 	int valid = 0;
 	int todo[64];
@@ -564,8 +566,8 @@ static int blas_closest(const omesh *m, v3 o, v3 d, float t_min, float *t, int *
 			{
 				const uint32_t p = m->prims[node->left_first + i];
 				st->tris++;
-				if (tri_test_tie(o, d, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, 1, p, (uint32_t)*prim))
-					valid = 1, *prim = (int)p;
+				if (tri_test_tie(o, d, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, same_inst ? 1 : 2, p, (uint32_t)*prim))
+					same_inst = 1, valid = 1, *prim = (int)p;
 			}
 		}
 		else
@@ -653,14 +655,14 @@ static int scene_closest(const rfwo_context *c, v3 o, v3 d, float t_min, float *
 			float a, b;
 			if (!slab_test(in->world.bmin, in->world.bmax, o, idir, *t, &a, &b))
 				continue;
-			if (blas_closest(m, lo, ld, t_min, t, prim, u, v, st))
+			if (blas_closest(m, lo, ld, t_min, t, prim, u, v, st, 0)) /* (the hit so far is of an earlier instance) */
 				hit = 1, *inst = (int)i;
 		}
 		else
 			for (size_t p = 0; p < m->triCount; p++)
 			{
 				st->tris++;
-				if (tri_test_tie(lo, ld, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, 1, (uint32_t)p, (uint32_t)*prim))
+				if (tri_test_tie(lo, ld, t_min, t, m->p0[p], m->p1[p], m->p2[p], u, v, (hit && *inst == (int)i) ? 1 : 2, (uint32_t)p, (uint32_t)*prim))
 					hit = 1, *inst = (int)i, *prim = (int)p;
 			}
 	}

@@ -834,7 +834,7 @@ RT_FN void refit_tris_item(f4 *tri_verts, const f4 *verts, const uint32_t *indic
 	const f4 a = verts[i0], b = verts[i1], c = verts[i2];
 	tri_verts[3ull * slot] = mk4(a.x, a.y, a.z, ubits(prim));
 	tri_verts[3ull * slot + 1] = mk4(b.x, b.y, b.z, 1.0f);
-	tri_verts[3ull * slot + 2] = mk4(c.x, c.y, c.z, 1.0f);
+	tri_verts[3ull * slot + 2] = mk4(c.x, c.y, c.z, TRI_EPS); // (w: the triangle's determinant threshold, tri_test)
 }
 RT_FN void leaf_bounds(const Node &n, const f4 *tri_verts, float mn[3], float mx[3])
 {
@@ -1514,11 +1514,12 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			for (uint32_t i = 0; i < count; i++)
 			{
 				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
+				const int tri_inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
 				if (tri_test<true>(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v,
-								   fbits(v0[3]), (uint32_t)hit.prim))
+								   v2[3], fbits(v0[3]), (uint32_t)hit.prim, (uint32_t)tri_inst, (uint32_t)hit.inst))
 				{
 					hit.prim = (int)fbits(v0[3]);
-					hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
+					hit.inst = tri_inst;
 				}
 			}
 #if RT_NORM_T
@@ -1653,7 +1654,15 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	__shared__ uint32_t s_qidx[BLOCK / 64][QN];
 	__shared__ int s_qinst[BLOCK / 64][QN];
 	__shared__ uint32_t s_qmiss[BLOCK / 64][QN];
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// (Round 6, built on this state, bit-identical, and the same speed to 1 %: (a) the scan's records asked for one scan ahead by LDS-DMA —
+	// global_load_lds_dwordx4 / _dword into staging rows of the wave, no register in flight: 7.89 against 7.93 ms per sub-batch; (b) the
+	// scan of the next chunk issued with the loads of the batch being shaded, one round trip for both, the hit's shading index looked up
+	// by the scan so that the shading record is asked for with the path records: 7.88 against 7.94; (c) hits sorted by material on
+	// textured scenes — plain variant for the hits on untextured materials, textured variant over a list of the others: atrium shade
+	// 16.7 against 15.2 ms.  A wave's time between two items is vmcnt(0) — on gfx9 one counter for loads AND stores — and what the
+	// kernel as a whole is bound by is not the length of a wave's chain of round trips.  DESIGN_LOG.md, round 6.)
+	// The wave index as a scalar (readfirstlane): the four ring bases are SGPRs, not a VGPR each — with it the kernel spills nothing.
+	const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	f4 *const qhit = s_qhit[wave];
 	uint32_t *const qidx = s_qidx[wave], *const qmiss = s_qmiss[wave];
 	int *const qinst = s_qinst[wave];
@@ -1737,6 +1746,9 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 			if (is_miss)
 				qmiss[(mq + nm + wave_prefix(mm)) & QM] = idx;
 			nm += (uint32_t)__popcll(mm);
+#if defined(RT_DIAG_SHADE_CLOCK)
+			clk_tick(clk, 14); // (a scan: from the end of the last item or scan to here)
+#endif
 			continue;
 		}
 		else
@@ -2076,7 +2088,7 @@ void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 		for (int k = 0; k < 16; k++)
 			tot += (double)h[k];
 		fprintf(stderr, "[shade clock] after %d launches:", launches);
-		for (int k = 0; k < 13; k++)
+		for (int k = 0; k < 15; k++)
 			fprintf(stderr, " %d: %.1f%% (%.0f cyc x %llu)", k, 100.0 * (double)h[k] / tot, h[16 + k] ? (double)h[k] / (double)h[16 + k] : 0.0, h[16 + k]);
 		fprintf(stderr, "\n");
 	}

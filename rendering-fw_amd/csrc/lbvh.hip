@@ -235,7 +235,7 @@ RT_FN uint32_t emit_small_subtree(Node *nodes, uint32_t root, uint32_t start, f4
 		tri_corners(verts, indices, tri, a, b, c);
 		tri_verts[3ull * pos] = mk4(a.x, a.y, a.z, ubits(tri));
 		tri_verts[3ull * pos + 1] = mk4(b.x, b.y, b.z, 1.0f);
-		tri_verts[3ull * pos + 2] = mk4(c.x, c.y, c.z, 1.0f);
+		tri_verts[3ull * pos + 2] = mk4(c.x, c.y, c.z, TRI_EPS); // (w: the triangle's determinant threshold, rt::tri_test)
 		n.left_first = (int)make_entry((int)pos, 1, false);
 		pos++;
 	}

@@ -342,6 +342,8 @@ struct InstRec
 	uint32_t prev_generation = 0;
 	bool has_prev = false;
 	uint32_t moving = 0; // updates left before it may (re)join the world tree
+	uint32_t moves = 0;	 // times it has started to move out of stillness: the waiting time doubles with each (an object that moves now
+						 // and then would otherwise cost two rebuilds of the world tree — seconds for millions of triangles — per episode)
 };
 
 // The WORLD TREE (rfwhip_update): the triangles of the static instances written out in world space under ONE tree.
@@ -350,7 +352,9 @@ struct WorldRec
 	bool valid = false;
 	std::vector<uint32_t> key;		   // what it was built from: (instance, mesh, mesh generation, transform) per member
 	std::vector<uint8_t> member;	   // per instance: its triangles are in the tree
-	std::vector<uint8_t> mesh_member;  // per mesh: its instances are (all of them, or none: membership is a property of the mesh)
+	std::vector<uint8_t> mesh_all;	   // per mesh: EVERY live instance of it is a member (no ray walks the mesh's own tree)
+	std::vector<uint8_t> mesh_member;  // per mesh: at least one of its instances is (an instance that moves keeps the two-level walk of
+									   // the same mesh: see fill_params for what that means for the LDS top-of-tree choice)
 	std::vector<rt::Node4> n4;		   // relative entries, like MeshRec::n4
 	std::vector<f4> leaf_verts;		   // 3 per leaf slot: v0.w = primitive id (mesh order), v1.w = instance index
 	uint32_t root_first = 0, root_count = 0; // the root when it is a leaf (n4 empty)
@@ -433,7 +437,9 @@ struct rfwhip_context
 	long long sub_batch_paths = 50000000; // a render call is cut into sub-batches only if each gets at least this many path slots
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
 							// static instances that are used several times or transformed are written out in world space (world tree)
-	long long flatten_bytes = 1ll << 30; // ... as long as the world-space copy stays below this many bytes
+	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
+	long long flatten_bytes = 1ll << 28; // ... as long as the world-space copy stays below this many bytes (256 MiB = 2.4 M triangles:
+										 // the tree is built on the host inside rfwhip_update, ~0.2 s per million triangles on 16 cores)
 	WorldRec wtree;
 	int sample_group = 64; // slot layout: up to this many samples of a pixel share a wave (rt_core.h; the largest power of two
 						   // <= this that divides every sub-batch of the call is used; 1 = a wave is one 8x8 tile of one sample;
@@ -1044,7 +1050,7 @@ extern "C" int rfwhip_set_mesh(rfwhip_context *c, size_t index, const rfwhip_mes
 		memcpy(&pw, &prim, 4);
 		m.leaf_verts[3 * s + 0] = f4{V[ia].x, V[ia].y, V[ia].z, pw};
 		m.leaf_verts[3 * s + 1] = f4{V[ib].x, V[ib].y, V[ib].z, 1.0f};
-		m.leaf_verts[3 * s + 2] = f4{V[ic].x, V[ic].y, V[ic].z, 1.0f};
+		m.leaf_verts[3 * s + 2] = f4{V[ic].x, V[ic].y, V[ic].z, rt::TRI_EPS}; // (w: the triangle's determinant threshold, rt::tri_test)
 	}
 	RF_TRY(m.d_parents.ensure(m.bvh.parents.size() * sizeof(int)));
 	RF_TRY(dm::h2d(m.d_parents.p, m.bvh.parents.data(), m.bvh.parents.size() * sizeof(int), c->stream));
@@ -1320,9 +1326,16 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 			// (another mesh, or the same one rebuilt: a new object in this slot, not a moving one)
 			const bool same_object = in.has_prev && in.prev_mesh == in.mesh && in.prev_generation == c->meshes[in.mesh].generation;
 			if (!same_object)
-				in.moving = 0u;
+				in.moving = 0u, in.moves = 0u;
 			else if (memcmp(in.prev_transform, in.transform, sizeof(in.transform)) != 0)
-				in.moving = 8u; // (stable for eight updates before it rejoins: one rebuild when an animation starts, one after it ends)
+			{
+				// stable for eight updates before it rejoins: one rebuild when an animation starts, one after it ends — and twice as
+				// long after every further episode (8, 16, 32 ... 8192 updates): an instance that keeps starting and stopping ends up
+				// outside the tree for good instead of paying two synchronous host rebuilds per episode (round 5's advisor)
+				if (!in.moving)
+					in.moves = std::min(in.moves + 1u, 11u);
+				in.moving = 8u << (in.moves - 1u);
+			}
 			else if (in.moving)
 				in.moving--;
 			memcpy(in.prev_transform, in.transform, sizeof(in.transform));
@@ -1374,6 +1387,11 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 		const uint32_t ii = (uint32_t)i;
 		float iw;
 		memcpy(&iw, &ii, 4);
+		// the determinant threshold of the reference's triangle test, stated in object space (rt::tri_test): a = e1 . (d x e2) of the
+		// world-space triangle is det(M) times the object-space one
+		const double det3 = (double)M[0] * ((double)M[5] * M[10] - (double)M[9] * M[6]) - (double)M[4] * ((double)M[1] * M[10] - (double)M[9] * M[2]) +
+							(double)M[8] * ((double)M[1] * M[6] - (double)M[5] * M[2]);
+		const float tri_eps = std::max((float)((double)rt::TRI_EPS * fabs(det3)), 1e-37f); // (a singular matrix: every triangle is rejected)
 		for (size_t s = 0; s < m.triCount; s++, t++)
 		{
 			for (int k = 0; k < 3; k++)
@@ -1383,7 +1401,7 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 				q.x = M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12];
 				q.y = M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13];
 				q.z = M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14];
-				q.w = k == 0 ? p.w : (k == 1 ? iw : 1.0f); // v0.w: primitive id (mesh order), v1.w: instance
+				q.w = k == 0 ? p.w : (k == 1 ? iw : tri_eps); // v0.w: primitive id (mesh order), v1.w: instance, v2.w: determinant threshold
 				verts[3 * t + k] = q;
 			}
 			const f4 &a = verts[3 * t], &b = verts[3 * t + 1], &d = verts[3 * t + 2];
@@ -1412,6 +1430,10 @@ static int prepare_world(rfwhip_context *c, bool &changed)
 	for (int a = 0; a < 3; a++)
 		w.bmin[a] = tree.nodes[0].bmin[a], w.bmax[a] = tree.nodes[0].bmax[a];
 	w.tris = tris, w.member = member, w.mesh_member = mesh_member, w.valid = true;
+	w.mesh_all = mesh_member;
+	for (size_t i = 0; i < c->instances.size(); i++)
+		if (c->instances[i].used && c->instances[i].mesh < w.mesh_all.size() && !member[i])
+			w.mesh_all[c->instances[i].mesh] = 0;
 	return 0;
 }
 
@@ -1741,6 +1763,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	sv.n_area = c->lc.areaLightCount, sv.n_point = c->lc.pointLightCount, sv.n_spot = c->lc.spotLightCount;
 	sv.n_dir = c->lc.directionalLightCount;
 	c->scene_dirty = false;
+	c->depth_stats_valid = false;
 	return RFWHIP_OK;
 }
 
@@ -1898,7 +1921,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 		for (size_t mi = 0; mi < c->meshes.size(); mi++)
 		{
 			const MeshRec &m = c->meshes[mi];
-			const bool in_world = c->wtree.valid && mi < c->wtree.mesh_member.size() && c->wtree.mesh_member[mi];
+			const bool in_world = c->wtree.valid && mi < c->wtree.mesh_all.size() && c->wtree.mesh_all[mi];
 			if (m.used && !in_world && m.n4_count > big_count)
 				big_base = (uint32_t)m.n4_base, big_count = m.n4_count;
 		}
@@ -1974,15 +1997,16 @@ static int ensure_sub_batches(rfwhip_context *c, int subs)
 // device and works through whatever it finds).  The host never reads a counter between bounces, so every launch used to get a grid
 // for the primary count — for the deeper waves of a small call a chip-wide persistent grid whose waves find a few dozen rays each.
 // Paths per primary at depth d: from the counts of the last frame this context waited for (rfwhip_get_stats; same scene, any spp),
-// with a quarter of headroom; before there is one, a half per depth.  extend = false: the traversal launch of depth d — extension
-// rays of depth d and the shadow rays of depth d - 1 beside them; true: the shade launch of depth d.
+// with a quarter of headroom; before there is one — and after every rfwhip_update(), until a frame of the new scene has been
+// waited for — a half per depth.  shade = false: the traversal launch of depth d — extension rays of depth d and the shadow rays
+// of depth d - 1 beside them; true: the shade launch of depth d.
 static uint32_t depth_items(const rfwhip_context *c, uint32_t n, int d, bool shade)
 {
 	if (d <= 0)
 		return n;
 	const rfwhip_render_stats &st = c->stats;
 	double ext = 1.0, prev = 1.0, shadow_per_path = 0.8;
-	if (st.primaryCount > 0)
+	if (st.primaryCount > 0 && c->depth_stats_valid) // (after rfwhip_update the counts of the last frame describe another scene)
 	{
 		const double p = (double)st.primaryCount, r1 = (double)st.secondaryCount / p, rdeep = (double)st.deepCount / p;
 		// (deepCount adds up every depth >= 2: taken as the bound for each of them)
@@ -2317,6 +2341,7 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
 	rfwhip_render_stats &st = c->stats;
+	c->depth_stats_valid = true;
 	const float anim = st.animationTime;
 	memset(&st, 0, sizeof(st));
 	st.animationTime = anim;
@@ -2588,6 +2613,10 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->lds_nodes = std::max(-1, atoi(value));
 	else if (k == "refill")
 		c->refill = atoi(value) & 15;
+	else if (k == "arm")
+	{
+		// (self-arming primary kernels: round 4's switch, removed with the variant in round 5 — accepted and ignored, like refill bit 2)
+	}
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
 	else if (k == "flatten_bytes")
@@ -2666,6 +2695,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->lds_nodes);
 	else if (k == "refill")
 		snprintf(value, cap, "%d", c->refill);
+	else if (k == "arm")
+		snprintf(value, cap, "0"); // (retired: see rfwhip_set_setting)
 	else if (k == "fuse")
 		snprintf(value, cap, "%d", c->fuse);
 	else if (k == "streams")

@@ -585,13 +585,18 @@ RT_FN float ub3(uint32_t x) { return (float)(x >> 24); }
 // different triangle — normal, material — from each of them: with a total order on (t, prim) the hit record is a function of
 // the ray and the scene alone.  (About one primary ray in a million on the terrain; occlusion queries have no such question.)
 template <bool TIE = false>
-RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo, uint32_t prim = 0u, uint32_t cur_prim = 0u)
+RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, float &uo, float &vo, float eps = TRI_EPS, uint32_t prim = 0u,
+					uint32_t cur_prim = 0u, uint32_t inst = 0u, uint32_t cur_inst = 0u)
 {
 	// (fixed-shape arithmetic: see rounded())
 	const f3 e1 = p1 - p0, e2 = p2 - p0;
 	const f3 h = cross_r(d, e2);
 	const float a = dot_r(e1, h);
-	if (a > -1e-6f && a < 1e-6f)
+	// bvh_tree.cpp:174: |a| < 1e-6 rejects the triangle — in the space the reference tests it in, the instance's OBJECT space.  A
+	// triangle of the world tree (written out in world space, M p instead of M^-1 o) has a_world = det(M) a_object, so its threshold
+	// travels with it: eps = w of its third vertex = 1e-6 |det M| (1e-6 for every other triangle).  Round 5's advisor: with the
+	// constant, a finely tessellated mesh instanced at scale 0.002 lost 696 of 697 primary hits to the world tree.
+	if (a > -eps && a < eps)
 		return false;
 	const float f = fast_rcp(a);
 	const f3 s = o - p0;
@@ -604,8 +609,10 @@ RT_FN bool tri_test(f3 o, f3 d, float t_min, float &t, f3 p0, f3 p1, f3 p2, floa
 		return false;
 	const float tt = rounded(f * dot_r(e2, q));
 	bool nearer = t > tt;
+	// total order on (t, instance, primitive): primitive ids are mesh-relative, and the world tree puts the triangles of many
+	// instances (of one mesh, too) into one leaf space
 	if (TIE)
-		nearer = nearer || (t == tt && prim < cur_prim);
+		nearer = nearer || (t == tt && (inst < cur_inst || (inst == cur_inst && prim < cur_prim)));
 	if (tt > t_min && nearer)
 	{
 		t = tt, uo = u, vo = v;
@@ -928,12 +935,14 @@ struct Traverser : TraverserWorld<WORLD>
 			const f4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
 			if (COUNT)
 				st.tris++;
-			if (tri_test<!ANY>(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v, fbits(v0.w), (uint32_t)hit.prim))
+			// (outside every instance: the triangle belongs to an instance that was linked into the top-level tree directly,
+			// and carries its index — rfwhip_update, "flat" instances)
+			const int tri_inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);
+			if (tri_test<!ANY>(o, d, t_min, hit.t, xyz(v0), xyz(v1), xyz(v2), hit.u, hit.v, v2.w, fbits(v0.w), (uint32_t)hit.prim, (uint32_t)tri_inst,
+							   (uint32_t)hit.inst))
 			{
 				hit.prim = (int)fbits(v0.w);
-				// (outside every instance: the triangle belongs to an instance that was linked into the top-level tree directly,
-				// and carries its index — rfwhip_update, "flat" instances)
-				hit.inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1.w);
+				hit.inst = tri_inst;
 				if (ANY)
 				{
 					cur = ENTRY_DONE;

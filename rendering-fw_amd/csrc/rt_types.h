@@ -52,6 +52,9 @@ RT_FN uint32_t strip_of_local(uint32_t local_strip, uint32_t rank, uint32_t worl
 	return local_strip * world + ((local_strip & 1u) ? world - 1u - rank : rank);
 }
 constexpr uint32_t TILE = 8;		  // 8x8 pixel tile = one wave64
+// Determinant threshold of the triangle test (bvh_tree.cpp:174) in the triangle's own space; every leaf-ordered triangle carries
+// its threshold in w of its third vertex: TRI_EPS, or TRI_EPS |det M| for a triangle the world tree holds in world space.
+constexpr float TRI_EPS = 1e-6f;
 constexpr uint32_t ENTRY_LEAF = 0x80000000u;
 constexpr uint32_t ENTRY_TLAS = 0x40000000u;
 constexpr uint32_t ENTRY_SENTINEL = 0xFFFFFFFFu;
