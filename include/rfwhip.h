@@ -192,7 +192,9 @@ RFWHIP_API int rfwhip_group_present_wait(rfwhip_group *group, int slot, const fl
  * calls rfwhip_comm_create with its context (rank / world as given to rfwhip_create) — a collective call, like
  * ncclCommInitRank.  rfwhip_comm_gather is collective too: every rank presents and sends, the root receives and
  * de-interleaves into rgba_device (width * height float4 on its device; ignored on the other ranks; NULL = an internal
- * buffer).  The transport is RCCL; nothing but the id travels outside this library. */
+ * buffer).  The transport is RCCL; nothing but the id travels outside this library.  A world of ONE needs no id (the gather is a
+ * copy); given one all the same, rfwhip_comm_create builds a real one-rank RCCL communicator and the gather sends the strips to
+ * itself through it (ncclSend + ncclRecv on rank 0): the library's RCCL calls exercised on a box with a single device. */
 #define RFWHIP_COMM_ID_BYTES 128
 typedef struct rfwhip_comm rfwhip_comm;
 RFWHIP_API int rfwhip_comm_unique_id(void *id, size_t cap);

@@ -276,6 +276,8 @@ struct rfwhip_group
 {
 	std::vector<Endpoint> ep; // local ranks (all of them for a group, one for a comm)
 	int world = 1, transport = RFWHIP_TRANSPORT_PEER;
+	bool loopback = false; // rfwhip_comm_create with an id and world 1: a REAL one-rank RCCL communicator; the gather sends the strips to
+						   // itself (ncclSend + ncclRecv on rank 0 in one group) — the library's RCCL calls on a box with one device
 	bool owns_contexts = false;
 	uint32_t W = 0, H = 0, local_rows = 0;
 	void *staging = nullptr, *full = nullptr; // on the root's device
@@ -334,7 +336,7 @@ int size_buffers(rfwhip_group *g, uint32_t W, uint32_t H)
 		if (rfwhip_local_rows(e.ctx) != g->local_rows)
 			return rfwhip_internal_set_error(RFWHIP_ERR_STATE, "ranks disagree about the padded strip rows");
 		GR_TRY(dev_use(e.device));
-		if (e.rank != 0)
+		if (e.rank != 0 || g->loopback)
 			GR_TRY(dev_alloc(&e.local_fb, g->chunk_bytes()));
 	}
 	if (g->root_local >= 0)
@@ -390,10 +392,25 @@ int gather(rfwhip_group *g, void *full_out)
 	//    next render waits on the device until the present has read the accumulator)
 	for (auto &e : g->ep)
 	{
-		void *dst = e.rank == 0 ? g->staging : e.local_fb;
+		void *dst = (e.rank == 0 && !g->loopback) ? g->staging : e.local_fb;
 		if (rfwhip_read_local_framebuffer_stream(e.ctx, dst, e.stream))
 			return RFWHIP_ERR_STATE; // (the context's message stands)
 	}
+#if !defined(RFWHIP_HOST_EMULATION)
+	if (g->loopback && root)
+	{
+		// world 1 over RCCL: the one rank sends its strips to itself — same calls, same streams as the root's side of a real gather
+		const size_t count = chunk / sizeof(float);
+		GR_TRY(dev_use(root->device));
+		GR_NCCL(g_rccl.GroupStart());
+		const ncclResult_t r_send = g_rccl.Send(root->local_fb, count, ncclFloat, 0, root->comm, (hipStream_t)root->stream);
+		const ncclResult_t r_recv = r_send == ncclSuccess ? g_rccl.Recv(g->staging, count, ncclFloat, 0, root->comm, (hipStream_t)root->stream) : r_send;
+		const ncclResult_t r_end = g_rccl.GroupEnd();
+		GR_NCCL(r_send);
+		GR_NCCL(r_recv);
+		GR_NCCL(r_end);
+	}
+#endif
 	if (g->world > 1)
 	{
 #if !defined(RFWHIP_HOST_EMULATION)
@@ -809,11 +826,15 @@ extern "C" int rfwhip_comm_create(rfwhip_context *ctx, const void *id, rfwhip_co
 	rfwhip_group *g = &c->g;
 	g->world = world, g->owns_contexts = false, g->root_local = rank == 0 ? 0 : -1;
 	g->transport = world > 1 ? RFWHIP_TRANSPORT_RCCL : RFWHIP_TRANSPORT_PEER;
+#if !defined(RFWHIP_HOST_EMULATION)
+	if (world == 1 && id) // (an id for a world of one: the caller wants the RCCL path, e.g. to see it work before a multi-GPU run)
+		g->transport = RFWHIP_TRANSPORT_RCCL, g->loopback = true;
+#endif
 	g->ep.resize(1);
 	g->ep[0].ctx = ctx, g->ep[0].device = device, g->ep[0].rank = rank;
 	int rc = make_streams(g);
 #if !defined(RFWHIP_HOST_EMULATION)
-	if (!rc && world > 1)
+	if (!rc && (world > 1 || g->loopback))
 	{
 		if (!g_rccl.load())
 			rc = rfwhip_internal_set_error(RFWHIP_ERR_UNSUPPORTED, "librccl.so could not be opened: %s", dlerror());

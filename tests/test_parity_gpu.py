@@ -487,6 +487,43 @@ def test_bench_workload_vs_the_reference_shaped_oracle(pkg, make_hip, make_oracl
         ref.set_setting("arith", "product")  # (process-wide in the oracle)
 
 
+def test_atrium_vs_the_reference_shaped_oracle(pkg, make_hip, make_oracle):
+    """The same meeting on BASELINE config 4's scene: textures, 46 instances, and — what the terrain cannot show — the WORLD TREE's
+    "M p instead of M^-1 o" measured against the reference-shaped TWO-LEVEL walk (plain products, strict `t > tt`, object-space
+    triangle test: `arith=reference`), not only against the product-shaped one.  Bounds of the terrain's test; primary hits: the same
+    triangle of the same instance on >= 99.9 % of the pixels (silhouettes of 45 transformed instances)."""
+    scene = pkg.scenes.atrium(480, 270)
+    hip, ref = make_hip(), make_oracle()
+    try:
+        ref.set_setting("arith", "reference")
+        for ctx in (hip, ref):
+            ctx.init(480, 270)
+            scene.upload(ctx)
+            for k, v in {"integrator": "pt", "spp": 1, "max_depth": 2}.items():
+                ctx.set_setting(k, v)
+            ctx.render_frame(scene.camera, pkg.RESET)
+        ha, hb = hip.primary_hits(), ref.primary_hits()
+        for ctx in (hip, ref):
+            ctx.set_setting("spp", 8)
+            ctx.render_frame(scene.camera, pkg.RESET)
+        a, b = hip.framebuffer(), ref.framebuffer()
+        frac3, rmse, d = image_stats(a, b, 3e-2)
+        assert frac3 <= 2e-2 and rmse <= 8e-2, ((d > 1e-3).mean(), frac3, rmse)
+        assert abs(a[..., :3].mean() - b[..., :3].mean()) <= 5e-3 * b[..., :3].mean()
+        other = (ha["prim"] != hb["prim"]) | (ha["inst"] != hb["inst"])
+        assert other.mean() <= 1e-3, other.mean()
+        same = ~other & (ha["prim"] >= 0)
+        assert (np.abs(ha["t"][same] - hb["t"][same]) <= 1e-4 * hb["t"][same]).all()
+        for k in ("u", "v"):
+            assert np.abs(ha[k][same] - hb[k][same]).max() <= 5e-3
+        sa, sb = hip.get_stats(), ref.get_stats()
+        for name in ("secondaryCount", "deepCount", "shadowCount"):
+            x, y = getattr(sa, name), getattr(sb, name)
+            assert abs(x - y) <= 3e-3 * y, (name, x, y)
+    finally:
+        ref.set_setting("arith", "product")  # (process-wide in the oracle)
+
+
 def test_bench_workload_flips_isolated_gpu_arithmetic_vs_restatement(pkg, make_hip, make_emu, make_oracle):
     """Where do the per-pixel differences of the bench workload come from?  Three renders of the same 480 x 270 x 8 spp frame:
     HIP (the kernels), the host-emulation build of the SAME sources (same code, libm sin/cos/1/x instead of v_sin / v_cos /
