@@ -193,7 +193,7 @@ def test_atrium_eight_strip_ranks_equal_single_rank(pkg, make_hip, atrium):
     single = _ctx(pkg, make_hip, atrium, spp=4)
     single.render_frame(atrium.camera, pkg.RESET)
     st = single.get_stats()
-    assert st.primaryCount == W * H * 4 and st.secondaryCount > 0.9 * st.primaryCount  # (a room: nearly every path goes on)
+    assert st.primaryCount == W * H * 4 and st.secondaryCount > 0.5 * st.primaryCount and st.deepCount > 0.25 * st.primaryCount  # (a room)
     gathered = root = None
     for r in range(world):
         c = _ctx(pkg, make_hip, atrium, rank=r, world=world, spp=4)
@@ -239,6 +239,7 @@ def test_atrium_world_tree_on_and_off(pkg, make_hip, atrium):
     out = []
     for flatten in (1 << 30, 0):
         c = _ctx(pkg, make_hip, atrium, spp=4, flatten_bytes=flatten)
+        c.update()  # (flatten_bytes takes effect with the next update)
         c.render_frame(atrium.camera, pkg.RESET)
         st = c.get_stats()
         out.append((c.framebuffer()[..., :3].astype(np.float64), c.primary_hits(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount)))
@@ -247,7 +248,7 @@ def test_atrium_world_tree_on_and_off(pkg, make_hip, atrium):
     other = (ha["prim"] != hb["prim"]) | (ha["inst"] != hb["inst"])
     assert other.mean() <= 1e-4, other.mean()
     same = ~other & (ha["prim"] >= 0)
-    assert same.mean() > 0.9
+    assert same.mean() > 0.5
     assert (np.abs(ha["t"][same] - hb["t"][same]) <= 5e-6 * hb["t"][same]).mean() >= 0.999
     d = np.sqrt(((ia - ib) ** 2).sum(-1))
     assert (d > 1e-3).mean() <= 3e-2, (d > 1e-3).mean()          # (a path here and there decides differently)
