@@ -1221,14 +1221,26 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) __attribute__((am
 		return;
 	const Params &p = pe; // (the stack declaration reads the LDS node range from `p`)
 	RT_STACK_DECL_N(LDS_STACK, TRACE_BLOCK)
+	// (whose time is it?  every workgroup adds what it spent on either kind of ray to WaveCounters::fused_ticks: two atomics per
+	// workgroup and launch; the host splits the launch's duration by the sums — rfwhip_wait)
+	const unsigned long long t0 = threadIdx.x == 0 ? (unsigned long long)wall_clock64() : 0ull;
 	if (count_e) // (the device clock of the extend stage covers extension rays only: no near-empty span for a launch without any)
 	{
 		clock_in(pe.wv.counters, pe.depth);
 		stream_rays<STREAM_EXT, COUNT>(pe, count_e, ctx);
 		clock_out(pe.wv.counters, pe.depth);
 	}
+	const unsigned long long t1 = threadIdx.x == 0 ? (unsigned long long)wall_clock64() : 0ull;
 	if (count_a)
 		stream_rays<STREAM_ANY, COUNT>(pa, count_a, ctx);
+	if (threadIdx.x == 0)
+	{
+		const unsigned long long t2 = (unsigned long long)wall_clock64();
+		if (t1 > t0)
+			atomicAdd(&pe.wv.counters->fused_ticks[pe.depth][0], t1 - t0);
+		if (t2 > t1)
+			atomicAdd(&pe.wv.counters->fused_ticks[pe.depth][1], t2 - t1);
+	}
 }
 
 // ----------------------------------------------------------------------------------------------------------------

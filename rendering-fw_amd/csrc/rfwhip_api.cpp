@@ -379,6 +379,7 @@ enum KernelFamily
 struct TimedSpan
 {
 	dm::event_t a, b;
+	bool fused = false; // a k_trace_fused launch: extension rays of `depth` + shadow rays of depth - 1 (split by the device's tick sums)
 	int family;
 	int depth; // wave depth for extend spans, -1 otherwise
 };
@@ -438,6 +439,7 @@ struct rfwhip_context
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
 							// static instances that are used several times or transformed are written out in world space (world tree)
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
+	unsigned long long fused_ticks_seen[MAX_SUB][rt::MAX_DEPTH_SLOTS][2] = {}; // WaveCounters::fused_ticks at the last rfwhip_wait, per counter set
 	long long flatten_bytes = 1ll << 28; // ... as long as the world-space copy stays below this many bytes (256 MiB = 2.4 M triangles:
 										 // the tree is built on the host inside rfwhip_update, ~0.2 s per million triangles on 16 cores)
 	WorldRec wtree;
@@ -1870,13 +1872,14 @@ struct StageTimer
 		fam = family, dep = depth;
 	}
 	int fam = 0, dep = 0;
+	bool fused = false;
 	void stop(int launches = 1)
 	{
 		if (!on)
 			return;
 		dm::event_record(c->event_pool[ib], stream);
 		TimedSpan s;
-		s.a = c->event_pool[ia], s.b = c->event_pool[ib], s.family = fam, s.depth = dep;
+		s.a = c->event_pool[ia], s.b = c->event_pool[ib], s.family = fam, s.depth = dep, s.fused = fused;
 		c->spans.push_back(s);
 		c->kernel_launches[fam] += (uint32_t)launches;
 	}
@@ -2240,6 +2243,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				StageTimer te(c, KF_EXTEND, d, s);
 				// (grid sizes of the deeper launches: from the paths EXPECTED there, not from the primary count — depth_items)
 				const uint32_t n_ext = depth_items(c, n, d, false), n_shade = depth_items(c, n, d, true);
+				te.fused = pa_pending;
 				if (pa_pending)
 					rtk::launch_trace_fused(p, pa, count, n_ext, s); // extension rays of depth d + shadow rays of depth d - 1
 				else
@@ -2323,6 +2327,8 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	rt::WaveCounters wc;
 	RF_TRY(dm::d2h(&wc, c->subs_first == 0 ? c->d_counters.p : c->d_counters_sub[c->subs_first].p, sizeof(wc), c->stream));
 	uint32_t stack_overflow = wc.stack_overflow;
+	const rt::WaveCounters wc0 = wc; // (as read: the sums below fold the other sub-batches' counts into wc)
+	std::vector<rt::WaveCounters> more;
 	for (int d = 0; d + 1 < rt::MAX_DEPTH_SLOTS; d++)
 		if (!wc.ext[d + 1])
 			wc.shadow[d] = 0;
@@ -2330,12 +2336,35 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 	{
 		rt::WaveCounters w2;
 		RF_TRY(dm::d2h(&w2, c->d_counters_sub[i].p, sizeof(w2), c->stream));
+		more.push_back(w2);
 		stack_overflow += w2.stack_overflow;
 		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
 		{
 			wc.ext[d] += w2.ext[d];
 			if (d + 1 < rt::MAX_DEPTH_SLOTS && w2.ext[d + 1])
 				wc.shadow[d] += w2.shadow[d];
+		}
+	}
+	// k_trace_fused: the shadow rays' share of each depth's launch, from the workgroups' tick sums since the last wait (over the
+	// counter sets of the last frame's sub-batches: the frames of a pipelined series render the same scene)
+	double shadow_share[rt::MAX_DEPTH_SLOTS];
+	{
+		unsigned long long sums[rt::MAX_DEPTH_SLOTS][2] = {};
+		auto fold = [&](int slot, const rt::WaveCounters &w) {
+			for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+				for (int k = 0; k < 2; k++)
+				{
+					sums[d][k] += w.fused_ticks[d][k] - c->fused_ticks_seen[slot][d][k];
+					c->fused_ticks_seen[slot][d][k] = w.fused_ticks[d][k];
+				}
+		};
+		fold(c->subs_first, wc0);
+		for (size_t k = 0; k < more.size(); k++)
+			fold(c->subs_first + 1 + (int)k, more[k]);
+		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
+		{
+			const double tot = (double)sums[d][0] + (double)sums[d][1];
+			shadow_share[d] = tot > 0.0 ? (double)sums[d][1] / tot : 0.5;
 		}
 	}
 	if (wc.probe_valid)
@@ -2360,7 +2389,14 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		st.shadowCount += wc.shadow[d];
 	for (const TimedSpan &sp : c->spans)
 	{
-		const float ms = dm::event_ms(sp.a, sp.b);
+		float ms = dm::event_ms(sp.a, sp.b);
+		if (sp.fused && sp.depth >= 0 && sp.depth < rt::MAX_DEPTH_SLOTS)
+		{
+			// (one launch, two stages: the shadow rays' share goes where a host of the reference looks for it — shadowTime, context.h:63)
+			const float shadow_ms = ms * (float)shadow_share[sp.depth];
+			st.shadowTime += shadow_ms, c->kernel_ms[KF_CONNECT] += shadow_ms;
+			ms -= shadow_ms;
+		}
 		c->kernel_ms[sp.family] += ms;
 		switch (sp.family)
 		{

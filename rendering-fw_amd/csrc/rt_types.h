@@ -414,6 +414,10 @@ struct WaveCounters
 	// ext_ticks when the counters are re-armed for the next call, or when the host reads them.
 	unsigned long long t_first[MAX_DEPTH_SLOTS], t_last[MAX_DEPTH_SLOTS];
 	unsigned long long ext_ticks;
+	// k_trace_fused: workgroup time (100 MHz ticks, summed over the launch's workgroups, never reset: the host takes differences) spent
+	// on the extension rays of depth d [0] and on the shadow rays of depth d - 1 [1] — the shares the host splits the launch's
+	// duration by, so that RenderStats::shadowTime is the shadow rays' although they share a kernel with the extension rays
+	unsigned long long fused_ticks[MAX_DEPTH_SLOTS][2];
 };
 
 // The wavefront state in HBM.
