@@ -59,7 +59,11 @@ int rfwo_set_probe_index(rfwo_context *ctx, uint32_t x, uint32_t y);
 int rfwo_get_probe_results(rfwo_context *ctx, uint32_t *inst, uint32_t *prim, float *dist);
 int rfwo_get_stats(rfwo_context *ctx, rfwhip_render_stats *stats);
 /* keys as rfwhip_set_setting (integrator, spp, max_depth, jitter, sampler; the launch-shape keys are accepted and
- * ignored); extra keys: bvh = "1" | "0" (0 = brute force over all triangles), threads = N */
+ * ignored); extra keys: bvh = "1" | "0" (0 = brute force over all triangles), threads = N,
+ * arith = "product" (default) | "reference": the triangle test, pt primary ray and sky lookup in the shapes the product fixes
+ * (rounded(), fmaf, total order on (t, instance, prim)) or as the reference's text shapes them (plain products, strict t > tt).
+ * NOTE: `arith` is PROCESS-WIDE although it is set through a context — the arithmetic helpers take no context; contexts
+ * (and threads) of one process share it, so a test that switches it restores "product" in a finally block. */
 int rfwo_set_setting(rfwo_context *ctx, const char *key, const char *value);
 int rfwo_read_primary_hits(rfwo_context *ctx, float *t, int32_t *prim, int32_t *inst, float *u, float *v);
 int rfwo_get_bvh(rfwo_context *ctx, size_t mesh_index, rfwhip_bvh_node *nodes, size_t node_cap, uint32_t *prims,
