@@ -206,6 +206,8 @@ def collect_stage_counters(args, scene_name, timeout_s=240):
     rocprof = shutil.which("rocprofv3")
     if not rocprof:
         return None, "rocprofv3 not on the PATH"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this process is itself being profiled (no counter passes nested under a profiler)"
     out_dir = os.path.join(ROOT, "gpurun_out", "bench_pmc")
     try:
         shutil.rmtree(out_dir, ignore_errors=True)
