@@ -49,9 +49,6 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 uint32_t queue_pad(uint32_t max_items); // extra slots per queue and launch for the void entries of unfinished blocks
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s);
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s);
-// a whole pt frame of `count` path slots in one launch (k_frame_local: a workgroup carries a chunk of slots through every stage);
-// survivors: bit d = the host expects paths at depth d (the connection rule's whole-batch condition for chunks without survivors)
-void launch_frame_local(const Params &p, uint32_t count, uint32_t survivors, stream_t s);
 // the extension rays of pe.depth and the shadow rays of pa.depth (= pe.depth - 1) in one launch (both with persistent lanes)
 void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s);
 void launch_resolve(const Params &p, stream_t s);

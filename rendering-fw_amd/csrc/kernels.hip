@@ -97,25 +97,8 @@ struct Ctx
 	};
 	OutQueue q_ext, q_shadow;
 	uint32_t q_block = QUEUE_BLOCK;
-	// k_frame_local: the two queues are regions of the workgroup's own chunk — lengths in LDS ([0] shadow, [1] extension rays),
-	// slots counted from the chunk's first index (q_block = 0: every call reserves exactly what it emits)
-	uint32_t *local_len = nullptr;
-	uint32_t local_base = 0;
 	__device__ __forceinline__ uint32_t alloc(OutQueue &q, bool flag, uint32_t *queue_len)
 	{
-		if (local_len)
-		{
-			const unsigned long long lm = __ballot(flag);
-			const uint32_t ln = (uint32_t)__popcll(lm);
-			if (ln == 0u)
-				return 0u;
-			uint32_t first = 0;
-			if (__lane_id() == 0u)
-				first = atomicAdd(local_len + (&q == &q_shadow ? 0 : 1), ln);
-			first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-			q.rays += ln;
-			return local_base + first + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-		}
 		const unsigned long long mask = __ballot(flag);
 		const uint32_t n = (uint32_t)__popcll(mask);
 		if (n == 0u)
@@ -439,10 +422,8 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 		{
 			// (the same additions as three fire-and-forget global_atomic_add_f32 — no wait for the slot's old value — measured: the
 			// L2's atomic units are the slower path by far, shade alone 8.55 -> 10.0 ms per sub-batch)
-			// (rounded(): the radiance is a product — throughput x sky, clamped — and must not fuse with this sum in one kernel and not
-			// in another: the item runs in k_shade_pt and in k_frame_local, and the two images are compared bit for bit)
 			f4 r = p.wv.rad[slot];
-			r.x += rounded(out.radiance.x), r.y += rounded(out.radiance.y), r.z += rounded(out.radiance.z);
+			r.x += out.radiance.x, r.y += out.radiance.y, r.z += out.radiance.z;
 			p.wv.rad[slot] = r;
 		}
 	}
@@ -611,7 +592,6 @@ RT_FN void init_counters_item(WaveCounters *c, uint32_t primary_count, uint32_t 
 	for (uint32_t d = t; d < (uint32_t)MAX_DEPTH_SLOTS; d += nt)
 	{
 		c->ext[d] = c->ext_n[d] = d == 0u ? primary_count : 0u, c->shadow[d] = c->shadow_n[d] = 0u;
-		c->local_unconnected[d] = c->local_blind[d] = 0u;
 		if (c->t_last[d] > c->t_first[d]) // fold the previous call's extend-stage clock
 		{
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1053,17 +1033,14 @@ __device__ unsigned long long g_trace_clk[3][8];
 #else
 #define RT_TRACE_TICK(K)
 #endif
-// (local_head / qbase — k_frame_local: the queue is a region of `count` rays that starts at index qbase of the ray buffers, its head a
-// counter in the workgroup's LDS; the waves of the workgroup share it)
-template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(const Params &p, const uint32_t count, Ctx &ctx, uint32_t *local_head = nullptr,
-																			const uint32_t qbase = 0u)
+template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(const Params &p, const uint32_t count, Ctx &ctx)
 {
 	constexpr bool ANY = MODE == STREAM_ANY;
 #if defined(RT_DIAG_TRACE_CLOCK)
 	unsigned long long clk_acc[4] = {0, 0, 0, 0}, clk_n[4] = {0, 0, 0, 0}, clk_last = __builtin_readcyclecounter();
 #endif
 	WaveCounters *const wc = p.wv.counters;
-	uint32_t *const head = local_head ? local_head : &wc->work[p.queue][0];
+	uint32_t *const head = &wc->work[p.queue][0];
 	const uint32_t b = p.depth & 1u;
 	const f4 *const ray_o = ANY ? p.wv.sh_org : p.wv.org[b];
 	const f4 *const ray_d = ANY ? p.wv.sh_dir : p.wv.dir[b];
@@ -1083,8 +1060,6 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 	uint32_t run = count / (gridDim.x * (blockDim.x / 64u) * 4u);
 	constexpr uint32_t RUN_MAX = MODE == STREAM_ANY ? (uint32_t)RT_STREAM_CHUNK_ANY : (uint32_t)RT_STREAM_CHUNK;
 	run = run > RUN_MAX ? RUN_MAX : (run < 64u ? 64u : run);
-	if (local_head)
-		run = 64u;
 #endif
 	uint32_t REFILL = MODE == STREAM_ANY ? RT_REFILL_IDLE_ANY : RT_REFILL_IDLE_EXT;
 	// Waves of near-identical rays — the slot layout's sample groups put >= 8 samples of a pixel side by side (rt_core.h), so a
@@ -1128,9 +1103,8 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 #endif
 			if (!has_ray)
 			{
-				const uint32_t qi = base + wave_prefix(idle_mask);
-				const uint32_t idx = qbase + qi;
-				if (qi < limit)
+				const uint32_t idx = base + wave_prefix(idle_mask);
+				if (idx < limit)
 				{
 					{
 #if RT_REFILL_PIN
@@ -1820,115 +1794,6 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	}
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// A whole small frame in ONE launch (round 6; rfwhip.h: setting `local_frames`).  Below a few million path slots a render call
-// is ten dependent launches of tails (a 1-spp 1080p frame: 2 M paths; every kernel of the chain at half the efficiency of a
-// large batch).  Here a WORKGROUP takes a chunk of RT_LOCAL_CHUNK consecutive path slots and carries it through every stage
-// itself: primary rays (one per lane, traced to completion), then per depth shade -> shadow rays + extension rays, with
-// workgroup barriers between the stages and nothing shared with other workgroups but the chunk counter and the statistics.
-// A chunk's extension / shadow rays live in the chunk's OWN region of the ray buffers (a path emits at most one of either, so
-// the region [first slot, first slot + RT_LOCAL_CHUNK) never overflows): queue lengths and heads are LDS counters, no global
-// queue, no void entries.  The work items are the multi-launch path's (extend_item, shade_pt_item, stream_rays, connect_finish),
-// radiance lands in the same per-slot records, k_resolve follows as its own launch: the image is the multi-launch path's bit for bit.
-// One rule needs the whole batch: the connections of depth d are traced only if SOME path of the batch survives depth d
-// (connection_count).  A chunk knows its own survivors; for a chunk without any, `survivors` carries what the last frame this
-// context waited for knew (bit d + 1: that depth had paths).  rfwhip_wait compares it with this frame's counts and reports a frame
-// for which it was wrong (the host then takes the multi-launch path until the next frame that was waited for agrees).
-// ----------------------------------------------------------------------------------------------------------------
-#ifndef RT_LOCAL_CHUNK
-#define RT_LOCAL_CHUNK 512u
-#endif
-template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVES : RT_SHADE_WAVES_PLAIN) k_frame_local(const Params p0, const uint32_t count, const uint32_t survivors)
-{
-	constexpr uint32_t UNION_WORDS = (uint32_t)(LDS_STACK * BLOCK) > POT_SLOTS * BLOCK ? (uint32_t)(LDS_STACK * BLOCK) : POT_SLOTS * BLOCK;
-	__shared__ f4 s_top[MAX_LDS_NODES * TOP_ROWS];
-	__shared__ uint32_t s_union[UNION_WORDS]; // traversal stack while rays are traced, light-potential cache while paths are shaded
-	__shared__ uint32_t s_cnt[4];			  // [0] shadow rays, [1] extension rays the chunk's shade stage emitted; [2] / [3] heads of the two queues
-	__shared__ uint32_t s_chunk;
-	uint32_t spill_[SPILL_STACK];
-	Params p = p0;
-	Ctx ctx;
-	ctx.stk.lds = s_union + threadIdx.x, ctx.stk.stride = BLOCK, ctx.stk.spill = spill_;
-	stage_top<BLOCK>(p, s_top);
-	ctx.stk.top = s_top, ctx.stk.top_first = p.lds_first, ctx.stk.top_count = p.lds_count;
-	ctx.stk.overflow = &p.wv.counters->stack_overflow;
-	ctx.pot = (float *)s_union + threadIdx.x;
-	ctx.q_block = 0u, ctx.local_len = s_cnt;
-	WaveCounters *const wc = p.wv.counters;
-	const uint32_t nchunks = (count + RT_LOCAL_CHUNK - 1u) / RT_LOCAL_CHUNK;
-	for (;;)
-	{
-		__syncthreads(); // (the previous chunk's last readers of s_chunk / s_cnt are through)
-		if (threadIdx.x == 0)
-			s_chunk = atomicAdd(&wc->work[p0.queue][0], 1u);
-		__syncthreads();
-		const uint32_t chunk = s_chunk;
-		if (chunk >= nchunks)
-			break;
-		const uint32_t base = chunk * RT_LOCAL_CHUNK;
-		ctx.local_base = base;
-		uint32_t n_in = count - base < RT_LOCAL_CHUNK ? count - base : RT_LOCAL_CHUNK;
-		// ---- primary rays: entry i of the primary wave is path slot i
-		p.depth = 0;
-		for (uint32_t j = threadIdx.x; j < RT_LOCAL_CHUNK; j += BLOCK)
-			extend_item<GEN_PT, false>(p, base + j, j < n_in, ctx);
-		for (uint32_t d = 0; d <= p0.max_depth; d++)
-		{
-			__syncthreads(); // hit records of depth d are written; the stack is free for the potentials
-			if (threadIdx.x < 4u)
-				s_cnt[threadIdx.x] = 0u;
-			__syncthreads();
-			// ---- shade the chunk's entries of depth d (every lane of a wave takes part in the queue allocation)
-			p.depth = d;
-			const f4 *const hits = d == 0 ? p.wv.hit0 : p.wv.hit;
-			const int *const insts = d == 0 ? p.wv.hit0_inst : p.wv.hit_inst;
-			for (uint32_t j0 = 0; j0 < n_in; j0 += BLOCK)
-			{
-				const uint32_t j = j0 + threadIdx.x, idx = base + j;
-				bool act = j < n_in;
-				if (d == 0 && act)
-					act = slot_to_pixel(p.fr, idx).valid;
-				f4 h4 = mk4(0, 0, 0, ubits((uint32_t)-1));
-				int hi = -1;
-				if (act)
-					h4 = hits[idx], hi = insts[idx];
-				act = act && (int)fbits(h4.w) >= -1; // (void entries do not exist here; a primary miss was finished by extend_item)
-				shade_pt_item<TEX>(p, idx, act, h4, hi, ctx);
-			}
-			__syncthreads(); // rays of the chunk are stored (workgroup scope), their counts final; the potentials are done with
-			const uint32_t n_sh = s_cnt[0], n_ext = s_cnt[1];
-			if (threadIdx.x == 0)
-			{
-				if (n_ext)
-					atomicAdd(&wc->ext[d + 1], n_ext), atomicAdd(&wc->ext_n[d + 1], n_ext);
-				if (n_sh)
-					atomicAdd(&wc->shadow[d], n_sh), atomicAdd(&wc->shadow_n[d], n_sh);
-			}
-			if (d == p0.max_depth || (n_sh == 0u && n_ext == 0u))
-				break;
-			// ---- connections of depth d (Context.cpp:109-120: only while some path of the BATCH goes on), then extension rays of d + 1
-			const bool connect = n_sh != 0u && (n_ext != 0u || ((survivors >> (d + 1u)) & 1u) != 0u);
-			if (n_sh != 0u && !connect)
-			{
-				if (threadIdx.x == 0)
-					atomicAdd(&wc->local_unconnected[d], n_sh); // (rfwhip_wait: were they rightly left out?)
-				if (d == 0 && p.wv.rad_nee)
-					for (uint32_t j = threadIdx.x; j < n_sh; j += BLOCK)
-						connect_skip_item(p, base + j);
-			}
-			if (connect && n_ext == 0u && threadIdx.x == 0)
-				atomicAdd(&wc->local_blind[d], n_sh);
-			if (connect)
-				stream_rays<STREAM_ANY, false>(p, n_sh, ctx, &s_cnt[2], base);
-			p.depth = d + 1u;
-			if (n_ext)
-				stream_rays<STREAM_EXT, false>(p, n_ext, ctx, &s_cnt[3], base);
-			n_in = n_ext;
-			if (n_ext == 0u)
-				break;
-		}
-	}
-}
 template <bool COUNT>
 __global__ void __launch_bounds__(BLOCK, RT_ANY_WAVES) k_connect(const Params p)
 {
@@ -2244,17 +2109,6 @@ void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(true))), dim3(BLOCK), 0, (hipStream_t)s, p);
 	else
 		hipLaunchKernelGGL(k_shade_pt<false>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(false))), dim3(BLOCK), 0, (hipStream_t)s, p);
-}
-
-void launch_frame_local(const Params &p, uint32_t count, uint32_t survivors, stream_t s)
-{
-	const uint32_t chunks = (count + RT_LOCAL_CHUNK - 1u) / RT_LOCAL_CHUNK;
-	uint32_t blocks = (uint32_t)g_cus * RT_SHADE_BLOCKS_PER_CU(p.textured != 0u);
-	blocks = blocks > chunks ? chunks : blocks;
-	if (p.textured)
-		hipLaunchKernelGGL(k_frame_local<true>, dim3(blocks ? blocks : 1u), dim3(BLOCK), 0, (hipStream_t)s, p, count, survivors);
-	else
-		hipLaunchKernelGGL(k_frame_local<false>, dim3(blocks ? blocks : 1u), dim3(BLOCK), 0, (hipStream_t)s, p, count, survivors);
 }
 
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)

@@ -23,11 +23,6 @@
 #include <string>
 #include <vector>
 
-#if defined(RFWHIP_HOST_EMULATION)
-#define RFWHIP_IS_EMULATION 1
-#else
-#define RFWHIP_IS_EMULATION 0
-#endif
 #if !defined(RFWHIP_HOST_EMULATION)
 #include <hip/hip_runtime.h>
 #endif
@@ -444,10 +439,6 @@ struct rfwhip_context
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
 							// static instances that are used several times or transformed are written out in world space (world tree)
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
-	long long local_frames = 0;		// pt calls of at most this many path slots run as ONE launch (kernels.hip: k_frame_local); 0 = never
-	bool local_hint_bad = false;	// the last local frame's whole-batch hint was wrong: multi-launch until a waited frame says otherwise
-	uint32_t local_mispredicted = 0; // ... how often that happened
-	bool last_call_local = false;
 	unsigned long long fused_ticks_seen[MAX_SUB][rt::MAX_DEPTH_SLOTS][2] = {}; // WaveCounters::fused_ticks at the last rfwhip_wait, per counter set
 	long long flatten_bytes = 1ll << 28; // ... as long as the world-space copy stays below this many bytes (256 MiB = 2.4 M triangles:
 										 // the tree is built on the host inside rfwhip_update, ~0.2 s per million triangles on 16 cores)
@@ -2189,7 +2180,6 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	base.wv.rad_nee = !connect ? nullptr : (alternate ? c->d_rad_nee[0].as<f4>() + paths * par : c->d_rad_nee[par].as<f4>());
 	// ---- sub-batches: each on its own stream; nothing here waits for the previous call's resolve ----
 	const int first_slot = alternate ? (int)par : 0;
-	bool local_call = false;
 	for (int k = 0; k < subs; k++)
 	{
 		const int i = first_slot + k; // which set of streams / counters / buffer slices
@@ -2237,23 +2227,6 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			StageTimer ts(c, KF_SHADE, -1, s);
 			rtk::launch_shade_parity(p, count, n, s);
 			ts.stop();
-		}
-		else if (c->local_frames > 0 && (long long)n <= c->local_frames && subs == 1 && !count && c->depth_stats_valid && !c->local_hint_bad &&
-				 c->stats.primaryCount > 0 && c->max_depth + 2 < 32 && !RFWHIP_IS_EMULATION)
-		{
-			// A small frame as ONE launch (k_frame_local): every workgroup carries a chunk of path slots through all stages.  The
-			// connection rule's whole-batch condition ("some path survives depth d") comes from the last frame this context waited
-			// for — the same scene, as depth_stats_valid says; rfwhip_wait checks it against this frame's own counts.
-			uint32_t survivors = 1u;
-			for (int d = 1; d <= c->max_depth + 1; d++)
-				if (d == 1 ? c->stats.secondaryCount > 0 : c->stats.deepCount > 0)
-					survivors |= 1u << d;
-			p.depth = 0, p.group = row_group, p.queue = queue++;
-			p.wv.sh_org = c->d_sh_org[0].as<f4>() + off, p.wv.sh_dir = c->d_sh_dir[0].as<f4>() + off, p.wv.sh_rad = c->d_sh_rad[0].as<f4>() + off;
-			StageTimer te(c, KF_EXTEND, 0, s); // (one kernel: its time is reported as the primary stage's)
-			rtk::launch_frame_local(p, n, survivors, s);
-			te.stop();
-			local_call = true;
 		}
 		else
 		{
@@ -2332,7 +2305,6 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 	c->call_slot = (par + 1u) % (uint32_t)ring;
 	RF_TRY(dm::last_launch_error());
 	c->subs_last = subs, c->subs_first = first_slot;
-	c->last_call_local = local_call;
 	c->last_wave_off = alternate ? (paths + pad) * par : 0;
 	c->samples_done += (uint32_t)c->spp;
 	c->totals.samples += (uint64_t)c->W * c->H * (uint64_t)c->spp / (uint64_t)c->world;
@@ -2395,17 +2367,6 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 			shadow_share[d] = tot > 0.0 ? (double)sums[d][1] / tot : 0.5;
 		}
 	}
-	if (c->last_call_local)
-	{
-		// k_frame_local: was the whole-batch hint of the connection rule right for the chunks that had to rely on it?
-		bool bad = false;
-		for (int d = 0; d + 1 < rt::MAX_DEPTH_SLOTS; d++)
-			bad = bad || (wc0.local_unconnected[d] && wc0.ext[d + 1]) || (wc0.local_blind[d] && !wc0.ext[d + 1]);
-		if (bad)
-			c->local_hint_bad = true, c->local_mispredicted++;
-	}
-	else
-		c->local_hint_bad = false; // (a multi-launch frame: its counts are exact)
 	if (wc.probe_valid)
 		c->probe_inst = wc.probe_inst, c->probe_prim = wc.probe_prim, c->probe_dist = wc.probe_dist;
 	rfwhip_render_stats &st = c->stats;
@@ -2622,7 +2583,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "local_frames"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2699,8 +2660,6 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->flatten_bytes = std::max(0ll, atoll(value));
 		c->scene_dirty = true;
 	}
-	else if (k == "local_frames")
-		c->local_frames = std::max(0ll, atoll(value));
 	else if (k == "sub_batch_paths")
 	{
 		const long long n = atoll(value);
@@ -2782,10 +2741,6 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%lld", c->flatten_bytes);
 	else if (k == "sub_batch_paths")
 		snprintf(value, cap, "%lld", c->sub_batch_paths);
-	else if (k == "local_frames")
-		snprintf(value, cap, "%lld", c->local_frames);
-	else if (k == "local_mispredicted") // (read-only: frames whose whole-batch connection hint was wrong, see local_frames)
-		snprintf(value, cap, "%u", c->local_mispredicted);
 	else if (k == "ring")
 		snprintf(value, cap, "%d", c->ring);
 	else if (k == "overlap")

@@ -418,10 +418,6 @@ struct WaveCounters
 	// on the extension rays of depth d [0] and on the shadow rays of depth d - 1 [1] — the shares the host splits the launch's
 	// duration by, so that RenderStats::shadowTime is the shadow rays' although they share a kernel with the extension rays
 	unsigned long long fused_ticks[MAX_DEPTH_SLOTS][2];
-	// k_frame_local: shadow rays of depth d that chunks WITHOUT survivors left untraced because the host's hint said no path of the
-	// batch survives depth d (right exactly when ext[d + 1] of the frame is 0: rfwhip_wait checks)
-	uint32_t local_unconnected[MAX_DEPTH_SLOTS];
-	uint32_t local_blind[MAX_DEPTH_SLOTS]; // ... and those such chunks traced because the hint said some path does (right when ext[d + 1] > 0)
 };
 
 // The wavefront state in HBM.
