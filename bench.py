@@ -13,14 +13,16 @@ communicator id, the barriers and the max-over-ranks of the elapsed time).  Inpu
 resident in HBM before the timed region starts.
 
 The JSON line carries, besides the driver contract fields:
-  roofline      the extend stage (closest-hit traversal = k_primary_stream + k_trace_stream<false>, the largest stage):
-                algorithmic bytes per SURVEY §8(d) (ray 32 B in [+32 B out for generated primaries], 64 B per popped inner
-                node, 52 B per triangle test, 16 B hit record out) from an instrumented replay of the same frames, divided
-                by the mean duration of the launches INSIDE the timed region (the kernels' own first-workgroup-in /
-                last-workgroup-out device clock; the hipEvent figure is beside it); peak = 8 TB/s HBM3E.
-                roofline.stages: primary / bounce / shadow / shade each alone on the chip (serialised ms of one sub-batch),
-                with their algorithmic bytes and — from the PMC passes under profiles/, tagged with their source and
-                dropped when the kernels changed since — counter bytes, VALU instructions and lanes per instruction.
+  roofline      the kernel that dominates the default command by time — k_trace_fused: the bounce and shadow waves of a depth in
+                one launch — in the units of what binds it (bound "valu": achieved = VALU wave-instructions per second of the launch,
+                peak = 1024 SIMDs x 2.4 GHz / 2, frac = achieved / peak, lane_weighted_frac beside it; its bytes — algorithmic per
+                SURVEY §8(d) from an instrumented replay, and HBM by the counters — under roofline.bytes; bound "hbm": algorithmic
+                bytes per second against the 8 TB/s peak); launch durations from hipEvents on the launch's own stream, one sub-batch
+                alone on the chip.  roofline.hbm_kernel: the shade kernel, the one stage whose time is bytes.  roofline.stages:
+                primary / bounce / shadow / shade each alone on the chip with algorithmic bytes, counter bytes, VALU instructions and
+                lanes per instruction.  The counters are THIS run's (--pmc auto: four `rocprofv3 --pmc` passes of a 2-step child run
+                before the timed region; roofline.traffic_source says where they came from), else profiles/stage_counters.json when
+                it carries the hash of the running sources.
   cpu_baseline  the CPU oracle's restatement of the same integrator ("port") on the host cores, bounded sample; the GPU
                 image of the same sample indices is compared with the oracle's (parity_vs_cpu_baseline, with a pass rule).
   cpu_baseline_parity  the Embree rendercore's algorithm (EmbreeRT/src/Context.cpp:104-300: 1 primary + one shadow ray per
