@@ -177,6 +177,13 @@ struct Ctx
 #ifndef RT_PRIMARY_MISS
 #define RT_PRIMARY_MISS 1
 #endif
+// Round 6: the primary wave writes NO ray record at all (0) — the shade kernel regenerates a primary ray from its pixel and sample
+// (pt_primary_ray has a fixed arithmetic shape: the same bits in every kernel) instead of reading 16 bytes the primary kernel wrote
+// for it: ~60 instructions in a kernel whose VALUs are busy 0.45 of the time against 32 bytes of HBM traffic per primary hit in the
+// kernel that is bound by it.  1: direction record per hit (+ origin record behind a lens), rounds 1-5.
+#ifndef RT_PRIMARY_RAY_RECORD
+#define RT_PRIMARY_RAY_RECORD 0
+#endif
 RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h)
 {
 	int prim = h.prim;
@@ -189,7 +196,7 @@ RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h
 		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
 		prim = HIT_MISS_SHADED;
 	}
-	else
+	else if (RT_PRIMARY_RAY_RECORD)
 		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
 	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
 	q.wv.hit0_inst[idx] = h.inst;
@@ -262,7 +269,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		{
 			// (pt, pinhole camera: every primary ray starts at the camera position and entry i of the primary wave is path slot
 			// i — the shade kernel needs no origin record: 16 bytes less written here and read there per primary ray)
-			if (GEN != GEN_PT || p.cam.aperture != 0.0f)
+			if (GEN != GEN_PT || (RT_PRIMARY_RAY_RECORD && p.cam.aperture != 0.0f))
 				p.wv.org[0][i] = mk4(O.x, O.y, O.z, ubits((i << 1) | 1u));
 			if (GEN != GEN_PT) // (pt: written with the hit record, or not at all for a miss — primary_finish_item)
 				p.wv.dir[0][i] = mk4(D.x, D.y, D.z, 0.0f);
@@ -386,7 +393,14 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	in.slot = 0, in.flags = 0, in.packedN = 0, in.depth = p.depth;
 	Hit h;
 	h.t = h4.x, h.u = h4.y, h.v = h4.z, h.prim = (int)fbits(h4.w), h.inst = hi;
-	if (active)
+	if (active && p.depth == 0 && !RT_PRIMARY_RAY_RECORD)
+	{
+		// (the primary wave: entry i IS path slot i, and its ray is a function of pixel and sample — regenerated, not read)
+		const PixelRef pr = slot_to_pixel(p.fr, i);
+		pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, in.O, in.D);
+		in.slot = i, in.flags = 1u, in.packedN = 0u;
+	}
+	else if (active)
 	{
 		// (depth 0 behind a pinhole camera: no origin record was written — the origin is the camera, the slot is the entry)
 		const f4 o4 = (p.depth == 0 && p.cam.aperture == 0.0f) ? mk4(p.cam.pos.x, p.cam.pos.y, p.cam.pos.z, ubits((i << 1) | 1u)) : p.wv.org[b][i];
