@@ -565,19 +565,20 @@ def main():
         cnt = instrumented(replay, args.max_depth)
         cnt0 = instrumented(1, 0)  # the primary wave alone (max_depth 0: the same primary rays, nothing behind them)
         primaries = float(W) * H * args.spp / world  # per step
+        prim_hits0 = float(cnt0["shaded"])
         per_step = {k: cnt[k] / replay for k in ("rays_extend", "inner_extend", "tris_extend", "rays_shadow", "inner_shadow",
                                                  "tris_shadow", "shaded", "lds_extend", "lds_shadow")}
         prim = {k: float(cnt0[k]) for k in ("rays_extend", "inner_extend", "tris_extend", "lds_extend")}
         bounce = {k: per_step[k] - prim[k] for k in prim}
         # ---- algorithmic bytes per step, stage by stage ---------------------------------------------------------
-        # primary: 16 B direction (a miss: 16 B radiance instead) + 20 B hit record written per ray (pinhole camera: no origin record), traversal per RAY;
+        # primary: 20 B hit record written per ray (+ 16 B radiance for a miss the kernel finishes itself; no ray record since round 6), traversal per RAY;
         # bounce: 32 B ray in + 20 B hit out; shadow: 32 B ray in (the contribution record and the 32 B read-modify-write of an
         # unoccluded ray's radiance at depths >= 1, the 16 B store of an occluded one at depth 0 are not counted: no count of them
         # is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
-        algo_primary = prim["rays_extend"] * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
+        algo_primary = prim_hits0 * 20 + (prim["rays_extend"] - prim_hits0) * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
         algo_bounce = bounce["rays_extend"] * (32 + 20) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
         algo_shadow = per_step["rays_shadow"] * 32 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
-        # shade: depth-0 hits read direction + hit record (36 B) and write 16 B radiance (+ 16 B for the connection term of a
+        # shade: depth-0 hits read their hit record + instance (20 B; round 6: the primary ray is regenerated from pixel and sample, no direction record) and write 16 B radiance (+ 16 B for the connection term of a
         # path that goes on without a shadow ray: at most the hits minus the shadow rays); deeper entries read origin, direction, throughput, hit record (68 B); a shaded hit gathers
         # its 64 B shading record (round 6; + the 32 B texture-coordinate record on a textured scene) and 48 B of material; 48 B per
         # emitted shadow ray, 48 B per emitted extension ray
@@ -587,7 +588,7 @@ def main():
         prim_miss = max(0.0, prim["rays_extend"] - prim_hits)
         packet_primaries = (args.refill & 8) != 0 and args.integrator == "pt"
         shade_record = 64 + (32 if ctx.get_setting("textured") == "1" else 0)
-        algo_shade = (prim_hits * (36 + 16) + prim_miss * (20 if packet_primaries else 36 + 16) +
+        algo_shade = (prim_hits * (20 + 16) + prim_miss * (20 if packet_primaries else 20 + 16) +
                       max(0.0, prim_hits - per_step["rays_shadow"]) * 16 +
                       bounce["rays_extend"] * 68 + per_step["shaded"] * (shade_record + 48) + per_step["rays_shadow"] * 48 + bounce["rays_extend"] * 48)
 

@@ -49,6 +49,9 @@ void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream
 uint32_t queue_pad(uint32_t max_items); // extra slots per queue and launch for the void entries of unfinished blocks
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s);
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s);
+// the connection wave of depth 0 in packet form: runs of the shadow queue sorted by the chosen light's bin (FrameView::shadow_bins),
+// one wave-uniform occlusion traversal per 64 rays of the sorted order
+void launch_shadow_packets(const Params &p, bool count, uint32_t max_items, stream_t s);
 // the extension rays of pe.depth and the shadow rays of pa.depth (= pe.depth - 1) in one launch (both with persistent lanes)
 void launch_trace_fused(const Params &pe, const Params &pa, bool count, uint32_t max_items, stream_t s);
 void launch_resolve(const Params &p, stream_t s);

@@ -472,11 +472,13 @@ RT_FN void connect_finish(const Params &p, uint32_t i, uint32_t slot, bool visib
 }
 // Depth 0 and no path went on (connection_count() == 0: the reference's host loop traces no connections then): the slots the
 // shade kernel left to the connection wave still have to start at zero.
+// the path slot of a shadow ray's slot word (depth 0 with FrameView::shadow_bins: the light's bin sits above it)
+RT_FN uint32_t shadow_slot(const Params &p, uint32_t word) { return (p.depth == 0 && p.fr.shadow_bins) ? word & SHADOW_SLOT_MASK : word; }
 RT_FN void connect_skip_item(const Params &p, uint32_t i)
 {
 	const f4 o4 = p.wv.sh_org[i];
 	if (fbits(o4.w) != RAY_VOID)
-		p.wv.rad_nee[fbits(o4.w)] = mk4(0, 0, 0, 0);
+		p.wv.rad_nee[shadow_slot(p, fbits(o4.w))] = mk4(0, 0, 0, 0);
 }
 
 template <bool COUNT>
@@ -491,7 +493,7 @@ RT_FN void connect_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		if (fbits(o4.w) == RAY_VOID) // void entry (a real shadow ray may carry tmax < 0: it is traced, hits nothing, and counts)
 			active = false;
 		else
-			connect_finish(p, i, fbits(o4.w), !trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st));
+			connect_finish(p, i, shadow_slot(p, fbits(o4.w)), !trace<true, COUNT>(p.sc, xyz(o4), xyz(d4), 1e-5f, d4.w, h, ctx.stk, st));
 	}
 	if (COUNT)
 	{
@@ -557,7 +559,8 @@ RT_FN void kat_item(const Params &p, int function, const float *in, float *out, 
 	{
 		float pick = 0, pdf = 0;
 		f3 col = mk3(0, 0, 0);
-		const f3 P = random_point_on_light(p.sc, r[6], r[7], mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), pick, pdf, col, pot_cache);
+		uint32_t chosen_light = 0u;
+		const f3 P = random_point_on_light(p.sc, r[6], r[7], mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), pick, pdf, col, chosen_light, pot_cache);
 		o[0] = P.x, o[1] = P.y, o[2] = P.z, o[3] = pick, o[4] = pdf, o[5] = col.x, o[6] = col.y, o[7] = col.z;
 		break;
 	}
@@ -1141,7 +1144,7 @@ template <int MODE, bool COUNT> __device__ __forceinline__ void stream_rays(cons
 						{
 							// shadow rays: (epsilon, dist - 2 epsilon) (Kernels.cu:750, :486); extension rays: (1e-5, 1e34)
 							T.begin(p.sc, xyz(o4), xyz(d4), 1e-5f, ANY ? d4.w : 1e34f);
-							has_ray = true, ray = idx, slot = fbits(o4.w), nrays++;
+							has_ray = true, ray = idx, slot = ANY ? shadow_slot(p, fbits(o4.w)) : fbits(o4.w), nrays++;
 						}
 					}
 				}
@@ -1390,15 +1393,17 @@ __device__ __forceinline__ uint32_t packet_key(float tk_lane, unsigned long long
 }
 
 
-template <bool COUNT>
+// ANY (round 6: the shadow rays of the primary vertices, sorted by light): occlusion query — hit.t holds the ray's length on entry, a
+// lane that finds a triangle inside (t_min, length) has hit.prim >= 0 and leaves the packet; the wave stops when none is left.
+template <bool COUNT, bool ANY = false>
 __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool active, const f3 O, const f3 D, const float t_min, Hit &hit, TStat &st)
 {
-	const unsigned long long act = __ballot(active);
+	unsigned long long act = __ballot(active);
 	// a lane without a ray never enters a box (its bit of every ballot is masked: `act`) and never takes a hit (t > tt fails)
 	hit.t = active ? hit.t : -3.0e38f;
 	if (act == 0ull)
 		return;
-	const int ref_lane = __ffsll((long long)act) - 1;
+	int ref_lane = __ffsll((long long)act) - 1;
 	PacketSpace sp;
 	const char *const nodes = (const char *)sc.nodes4f; // (the table stays below 4 GiB: 32-bit byte offsets)
 	sp.enter(O, D, hit.t, act, nodes);
@@ -1541,15 +1546,25 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			{
 				const pk_v4f v0 = sload4(tb, i * 48u), v1 = sload4(tb, i * 48u + 16u), v2 = sload4(tb, i * 48u + 32u);
 				const int tri_inst = cur_inst >= 0 ? cur_inst : (int)fbits(v1[3]);
-				if (tri_test<true>(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v,
+				if (tri_test<!ANY>(sp.o, sp.d, t_min, hit.t, mk3(v0[0], v0[1], v0[2]), mk3(v1[0], v1[1], v1[2]), mk3(v2[0], v2[1], v2[2]), hit.u, hit.v,
 								   v2[3], fbits(v0[3]), (uint32_t)hit.prim, (uint32_t)tri_inst, (uint32_t)hit.inst))
 				{
 					hit.prim = (int)fbits(v0[3]);
 					hit.inst = tri_inst;
+					if (ANY)
+						hit.t = -3.0e38f; // (occluded: this lane takes no further hit ...)
 				}
 			}
+			if (ANY)
+			{
+				// (... and enters no further box)
+				act &= ~__ballot(hit.prim >= 0);
+				if (act == 0ull)
+					break;
+				ref_lane = __ffsll((long long)act) - 1;
+			}
 #if RT_NORM_T
-			if (hit.t != t_before) // the lane's hit moved: rescale its normalised 1/d and -o/d (Traverser::renormalise)
+			if (!ANY && hit.t != t_before) // the lane's hit moved: rescale its normalised 1/d and -o/d (Traverser::renormalise)
 			{
 				const float r = norm_k(hit.t) * fast_rcp(norm_k(t_before)) * 0.99999952f;
 				sp.id = sp.id * r, sp.noid = sp.noid * r;
@@ -1641,6 +1656,122 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 		ctx.add64(&wc->rays_extend, nrays);
 	}
 	clock_out(p.wv.counters, 0);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The connection wave of the PRIMARY vertices in packet form (round 6; setting `shadow_packets`).  With 64 samples of a pixel side
+// by side, a run of the depth-0 shadow queue holds the connections of four or five neighbouring pixels' first vertices: nearly one
+// origin, and as many directions as those vertices chose lights — three or four that matter.  The shade kernel has written the
+// chosen light's bin into the top bits of every ray's slot word (FrameView::shadow_bins); a wave takes a run of RT_SHADOW_RUN rays,
+// sorts their queue indices by bin (a counting sort in LDS: 17 counters, one LDS atomic per ray), and walks the tree ONCE for
+// every 64 rays of the sorted order — trace_packet<ANY>: scalar node fetches, one stack per wave — instead of once per lane.  Which
+// rays share a packet changes nothing about a ray's answer (is anything inside (1e-5, length)?), so the image is the per-lane
+// kernels' bit for bit.
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef RT_SHADOW_RUN
+#define RT_SHADOW_RUN 256u
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(const Params p)
+{
+	static_assert(RT_SHADOW_RUN % 64u == 0u && RT_SHADOW_RUN <= 1024u, "run = whole packets");
+	__shared__ uint32_t s_order[TRACE_BLOCK / 64][RT_SHADOW_RUN];
+	__shared__ uint32_t s_hist[TRACE_BLOCK / 64][SHADOW_BINS + 2u];
+	const uint32_t count = connection_count(p.wv.counters, p.depth);
+	if (count == 0u)
+	{
+		if (p.depth == 0 && p.wv.rad_nee)
+			for (uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x, n = p.wv.counters->shadow_n[0]; i < n; i += gridDim.x * TRACE_BLOCK)
+				connect_skip_item(p, i);
+		return;
+	}
+	const uint32_t lane = __lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	uint32_t *const order = s_order[wave], *const hist = s_hist[wave];
+	uint32_t *const head = &p.wv.counters->work[p.queue][0];
+	TStat st;
+	st.inner = 0, st.tris = 0, st.lds = 0;
+	uint32_t nrays = 0;
+	for (;;)
+	{
+		uint32_t g = 0;
+		if (lane == 0)
+			g = atomicAdd(head, RT_SHADOW_RUN);
+		g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+		if (g >= count)
+			break;
+		const uint32_t n = count - g < RT_SHADOW_RUN ? count - g : RT_SHADOW_RUN;
+		// ---- counting sort of the run's queue indices by light bin (void entries: a bin of their own, behind the rays)
+		if (lane < SHADOW_BINS + 2u)
+			hist[lane] = 0u;
+		__builtin_amdgcn_wave_barrier();
+		uint32_t bin[RT_SHADOW_RUN / 64u], rank[RT_SHADOW_RUN / 64u];
+#pragma unroll
+		for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
+		{
+			const uint32_t e = j * 64u + lane;
+			bin[j] = SHADOW_BINS + 1u; // (beyond the run)
+			if (e < n)
+			{
+				const uint32_t w = fbits(p.wv.sh_org[g + e].w);
+				bin[j] = w == RAY_VOID ? SHADOW_BINS : w >> SHADOW_SLOT_BITS;
+			}
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
+			rank[j] = atomicAdd(&hist[bin[j]], 1u);
+		__builtin_amdgcn_wave_barrier();
+		// exclusive prefix over the bins (17 values: every lane adds up what lies below its own bins)
+		uint32_t valid = 0;
+		{
+			uint32_t start[RT_SHADOW_RUN / 64u];
+#pragma unroll
+			for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
+				start[j] = 0u;
+			for (uint32_t b = 0; b < SHADOW_BINS; b++)
+			{
+				const uint32_t hb = hist[b];
+				valid += hb;
+#pragma unroll
+				for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
+					start[j] += b < bin[j] ? hb : 0u;
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
+				if (bin[j] < SHADOW_BINS)
+					order[start[j] + rank[j]] = g + j * 64u + lane;
+		}
+		__builtin_amdgcn_wave_barrier();
+		// ---- one packet per 64 rays of the sorted order
+		for (uint32_t k = 0; k < valid; k += 64u)
+		{
+			const bool active = k + lane < valid;
+			uint32_t idx = 0, slot = 0;
+			f3 O = mk3(0, 0, 0), D = mk3(0, 0, 1);
+			Hit h;
+			h.t = 0.0f, h.u = 0.0f, h.v = 0.0f, h.prim = -1, h.inst = -1;
+			if (active)
+			{
+				idx = order[k + lane];
+				const f4 o4 = p.wv.sh_org[idx], d4 = p.wv.sh_dir[idx];
+				O = xyz(o4), D = xyz(d4), h.t = d4.w, slot = shadow_slot(p, fbits(o4.w));
+			}
+			// (a ray of negative length is traced, hits nothing and counts: Kernels.cu:750 — the packet walks nothing for it)
+			trace_packet<COUNT, true>(fresh_params().sc, active && h.t > 1e-5f, O, D, 1e-5f, h, st);
+			if (active)
+			{
+				connect_finish(p, idx, slot, h.prim < 0);
+				nrays++;
+			}
+		}
+	}
+	if (COUNT)
+	{
+		WaveCounters *const wc = p.wv.counters;
+		Ctx ctx;
+		ctx.add64(&wc->inner_shadow, st.inner);
+		ctx.add64(&wc->tris_shadow, st.tris);
+		ctx.add64(&wc->rays_shadow, nrays);
+	}
 }
 
 template <bool COUNT>
@@ -2123,6 +2254,16 @@ void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s)
 		hipLaunchKernelGGL(k_shade_pt<true>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(true))), dim3(BLOCK), 0, (hipStream_t)s, p);
 	else
 		hipLaunchKernelGGL(k_shade_pt<false>, dim3(persistent_grid(max_items, RT_SHADE_BLOCKS_PER_CU(false))), dim3(BLOCK), 0, (hipStream_t)s, p);
+}
+
+void launch_shadow_packets(const Params &p, bool count, uint32_t max_items, stream_t s)
+{
+	const dim3 g(persistent_grid(max_items));
+	const dim3 gt(std::max(8u, g.x * BLOCK / TRACE_BLOCK)), bt(TRACE_BLOCK);
+	if (count)
+		hipLaunchKernelGGL((k_shadow_packet<true>), gt, bt, 0, (hipStream_t)s, p);
+	else
+		hipLaunchKernelGGL((k_shadow_packet<false>), gt, bt, 0, (hipStream_t)s, p);
 }
 
 void launch_connect(const Params &p, bool count, uint32_t max_items, stream_t s)

@@ -439,6 +439,7 @@ struct rfwhip_context
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
 							// static instances that are used several times or transformed are written out in world space (world tree)
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
+	int shadow_packets = 1;			// the connection wave of the primary vertices in packet form (kernels.hip: k_shadow_packet) where it applies
 	unsigned long long fused_ticks_seen[MAX_SUB][rt::MAX_DEPTH_SLOTS][2] = {}; // WaveCounters::fused_ticks at the last rfwhip_wait, per counter set
 	long long flatten_bytes = 1ll << 28; // ... as long as the world-space copy stays below this many bytes (256 MiB = 2.4 M triangles:
 										 // the tree is built on the host inside rfwhip_update, ~0.2 s per million triangles on 16 cores)
@@ -2214,6 +2215,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		p.fr.spp = spp_i;
 		p.fr.sample_base = c->samples_done + s_begin;
 		const uint32_t n = c->fr.slots * spp_i;
+		// packet form of the depth-0 connection wave: where the packet traversal can run (float node table, trees within its stack),
+		// a wave's shadow rays are neighbours (sample groups of >= 8) and the batch's slots leave room for the light's bin
+		p.fr.shadow_bins = (c->integrator == 1 && connect && c->shadow_packets && (p.refill & 8u) && sgroup_log2 >= 3u &&
+							(unsigned long long)n <= (unsigned long long)rt::SHADOW_SLOT_MASK && !side)
+							   ? 1u
+							   : 0u;
 		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
@@ -2260,6 +2267,16 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				// (CUDART/src/Context.cpp:109-120): the shade kernel does not emit them, and no wave is launched for them.
 				if (connect && d < c->max_depth)
 				{
+					if (d == 0 && p.fr.shadow_bins)
+					{
+						// the connections of the primary vertices, sorted by light, as packets (their own launch: the extension wave of
+						// depth 1 then runs without them)
+						p.group = 16u, p.queue = queue++;
+						StageTimer tc(c, KF_CONNECT, -1, s);
+						rtk::launch_shadow_packets(p, count, depth_items(c, n, 1, false), s);
+						tc.stop();
+						continue;
+					}
 					if (fused)
 					{
 						pa = p, pa.group = 16u, pa.queue = queue++;
@@ -2583,7 +2600,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "shadow_packets"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2655,6 +2672,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	}
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
+	else if (k == "shadow_packets")
+		c->shadow_packets = atoi(value) != 0;
 	else if (k == "flatten_bytes")
 	{
 		c->flatten_bytes = std::max(0ll, atoll(value));
@@ -2735,6 +2754,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "0"); // (retired: see rfwhip_set_setting)
 	else if (k == "fuse")
 		snprintf(value, cap, "%d", c->fuse);
+	else if (k == "shadow_packets")
+		snprintf(value, cap, "%d", c->shadow_packets);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "flatten_bytes")

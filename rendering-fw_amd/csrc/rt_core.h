@@ -1631,8 +1631,9 @@ constexpr int POT_STRIDE = 256;
 constexpr int POT_STRIDE = 1;
 #endif
 RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3 N, float &pickProb, float &lightPdf,
-							   f3 &lightColor, float *pot_cache RT_CLK_PARAM)
+							   f3 &lightColor, uint32_t &light, float *pot_cache RT_CLK_PARAM)
 {
+	light = 0u;
 	const uint32_t lights = total_lights(sc);
 	const f3 bary = random_barycentrics(r0);
 	RT_TICK(9);
@@ -1676,6 +1677,7 @@ RT_FN f3 random_point_on_light(const SceneView &sc, float r0, float r1, f3 I, f3
 			li = 0, chosen = first;
 	}
 	pickProb = m_div(chosen, sum);
+	light = li;
 	RT_TICK(11);
 	if (li < sc.n_area)
 	{
@@ -1965,7 +1967,8 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, const FrameView &fr
 				}
 				else
 					q0 = random_float(seed), q1 = random_float(seed);
-				f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, pot_cache RT_CLK_ARG) - I;
+				uint32_t light = 0u;
+				f3 L = random_point_on_light(sc, q0, q1, I, iN, pickProb, lightPdf, lightColor, light, pot_cache RT_CLK_ARG) - I;
 				RT_TICK(12);
 				const float dist = length(L);
 				L = L * m_rcp(dist);
@@ -1982,7 +1985,10 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, const FrameView &fr
 						{
 							const f3 o = I + N * 1e-5f; // SafeOrigin, tools.h:119-123
 							emit_shadow = true;
-							so = mk4(o.x, o.y, o.z, ubits(in.slot));
+							// (depth 0, fr.shadow_bins: the light's bin rides in the top bits of the slot word — what the packet form of the
+							// connection wave sorts a run's rays by)
+							const uint32_t bin = (fr.shadow_bins && in.depth == 0u) ? (light < SHADOW_BINS - 1u ? light : SHADOW_BINS - 1u) << SHADOW_SLOT_BITS : 0u;
+							so = mk4(o.x, o.y, o.z, ubits(in.slot | bin));
 							sdir = mk4(L.x, L.y, L.z, dist - 2.0f * 1e-5f);
 							se = mk4(contribution.x, contribution.y, contribution.z, 0.0f);
 						}
