@@ -1663,7 +1663,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 // by side, a run of the depth-0 shadow queue holds the connections of four or five neighbouring pixels' first vertices: nearly one
 // origin, and as many directions as those vertices chose lights — three or four that matter.  The shade kernel has written the
 // chosen light's bin into the top bits of every ray's slot word (FrameView::shadow_bins); a wave takes a run of RT_SHADOW_RUN rays,
-// sorts their queue indices by bin (a counting sort in LDS: 17 counters, one LDS atomic per ray), and walks the tree ONCE for
+// sorts their queue indices by bin (stable: ballots and prefixes, the order in LDS), and walks the tree ONCE for
 // every 64 rays of the sorted order — trace_packet<ANY>: scalar node fetches, one stack per wave — instead of once per lane.  Which
 // rays share a packet changes nothing about a ray's answer (is anything inside (1e-5, length)?), so the image is the per-lane
 // kernels' bit for bit.
@@ -1676,7 +1676,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 {
 	static_assert(RT_SHADOW_RUN % 64u == 0u && RT_SHADOW_RUN <= 1024u, "run = whole packets");
 	__shared__ uint32_t s_order[TRACE_BLOCK / 64][RT_SHADOW_RUN];
-	__shared__ uint32_t s_hist[TRACE_BLOCK / 64][SHADOW_BINS + 2u];
 	const uint32_t count = connection_count(p.wv.counters, p.depth);
 	if (count == 0u)
 	{
@@ -1686,11 +1685,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 		return;
 	}
 	const uint32_t lane = __lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	uint32_t *const order = s_order[wave], *const hist = s_hist[wave];
+	uint32_t *const order = s_order[wave];
 	uint32_t *const head = &p.wv.counters->work[p.queue][0];
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
-	uint32_t nrays = 0;
+	uint32_t nrays = 0, nruns = 0, nbins = 0;
 	for (;;)
 	{
 		uint32_t g = 0;
@@ -1700,46 +1699,37 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 		if (g >= count)
 			break;
 		const uint32_t n = count - g < RT_SHADOW_RUN ? count - g : RT_SHADOW_RUN;
-		// ---- counting sort of the run's queue indices by light bin (void entries: a bin of their own, behind the rays)
-		if (lane < SHADOW_BINS + 2u)
-			hist[lane] = 0u;
-		__builtin_amdgcn_wave_barrier();
-		uint32_t bin[RT_SHADOW_RUN / 64u], rank[RT_SHADOW_RUN / 64u];
+		// ---- the run's queue indices sorted by light bin (void entries left out), STABLE: within a bin the rays keep the order of
+		// the queue — the order of the image — so that a packet is the rays of one or two neighbouring pixels towards one light,
+		// not a sample of all the run's pixels.  One ballot + prefix per bin and 64 entries (64 of them per run: a few hundred
+		// instructions against the thousands of a packet's traversal)
+		uint32_t bin[RT_SHADOW_RUN / 64u];
 #pragma unroll
 		for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
 		{
 			const uint32_t e = j * 64u + lane;
-			bin[j] = SHADOW_BINS + 1u; // (beyond the run)
+			bin[j] = SHADOW_BINS; // (beyond the run, or void)
 			if (e < n)
 			{
 				const uint32_t w = fbits(p.wv.sh_org[g + e].w);
 				bin[j] = w == RAY_VOID ? SHADOW_BINS : w >> SHADOW_SLOT_BITS;
 			}
 		}
-#pragma unroll
-		for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
-			rank[j] = atomicAdd(&hist[bin[j]], 1u);
-		__builtin_amdgcn_wave_barrier();
-		// exclusive prefix over the bins (17 values: every lane adds up what lies below its own bins)
 		uint32_t valid = 0;
+		for (uint32_t b = 0; b < SHADOW_BINS; b++)
 		{
-			uint32_t start[RT_SHADOW_RUN / 64u];
+			const uint32_t before = valid;
 #pragma unroll
 			for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
-				start[j] = 0u;
-			for (uint32_t b = 0; b < SHADOW_BINS; b++)
 			{
-				const uint32_t hb = hist[b];
-				valid += hb;
-#pragma unroll
-				for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
-					start[j] += b < bin[j] ? hb : 0u;
+				const unsigned long long m = __ballot(bin[j] == b);
+				if (bin[j] == b)
+					order[valid + wave_prefix(m)] = g + j * 64u + lane;
+				valid += (uint32_t)__popcll(m);
 			}
-#pragma unroll
-			for (uint32_t j = 0; j < RT_SHADOW_RUN / 64u; j++)
-				if (bin[j] < SHADOW_BINS)
-					order[start[j] + rank[j]] = g + j * 64u + lane;
+			nbins += valid != before ? 1u : 0u;
 		}
+		nruns++;
 		__builtin_amdgcn_wave_barrier();
 		// ---- one packet per 64 rays of the sorted order
 		for (uint32_t k = 0; k < valid; k += 64u)
@@ -1764,6 +1754,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 			}
 		}
 	}
+	if (lane == 0u && nruns)
+		atomicAdd(&p.wv.counters->sp_runs, (unsigned long long)nruns), atomicAdd(&p.wv.counters->sp_bins, (unsigned long long)nbins);
 	if (COUNT)
 	{
 		WaveCounters *const wc = p.wv.counters;

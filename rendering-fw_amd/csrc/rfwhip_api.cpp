@@ -439,7 +439,11 @@ struct rfwhip_context
 	int flat_instances = 1; // identity-transform instances of singly used meshes are linked into the top-level tree directly, and
 							// static instances that are used several times or transformed are written out in world space (world tree)
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
-	int shadow_packets = 1;			// the connection wave of the primary vertices in packet form (kernels.hip: k_shadow_packet) where it applies
+	int shadow_packets = -1;		// the connection wave of the primary vertices in packet form (kernels.hip: k_shadow_packet) where it applies:
+									// 1 always, 0 never, -1 (default) while the runs it sorts hold few light bins (shadow_bins_per_run)
+	bool shadow_packets_auto_on = true; // -1: what the last waited frame's bins per run said (reset to true by rfwhip_update)
+	double shadow_bins_per_run = 0.0;
+	unsigned long long sp_seen[MAX_SUB][2] = {};
 	unsigned long long fused_ticks_seen[MAX_SUB][rt::MAX_DEPTH_SLOTS][2] = {}; // WaveCounters::fused_ticks at the last rfwhip_wait, per counter set
 	long long flatten_bytes = 1ll << 28; // ... as long as the world-space copy stays below this many bytes (256 MiB = 2.4 M triangles:
 										 // the tree is built on the host inside rfwhip_update, ~0.2 s per million triangles on 16 cores)
@@ -1767,6 +1771,7 @@ extern "C" int rfwhip_update(rfwhip_context *c)
 	sv.n_dir = c->lc.directionalLightCount;
 	c->scene_dirty = false;
 	c->depth_stats_valid = false;
+	c->shadow_packets_auto_on = true; // (another scene: the packet form of the depth-0 connection wave gets its chance again)
 	return RFWHIP_OK;
 }
 
@@ -1810,6 +1815,7 @@ static int sync_all(rfwhip_context *c);
 // sub-batches double-buffers sets 0 / 1).
 constexpr size_t WAVE_SLOT_BYTES = 2 * 3 * sizeof(f4) + 2 * (sizeof(f4) + 4) + 2 * 3 * sizeof(f4);
 constexpr size_t RAD_SLOT_BYTES = 2 * sizeof(f4);
+constexpr double SHADOW_PACKET_MAX_BINS_PER_RUN = 4.5; // (shadow_packets = -1; measured: DESIGN.md §4 "Round 6")
 static size_t wave_bytes_held(const rfwhip_context *c);
 static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots0, size_t rad_slots1)
 {
@@ -2217,7 +2223,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		const uint32_t n = c->fr.slots * spp_i;
 		// packet form of the depth-0 connection wave: where the packet traversal can run (float node table, trees within its stack),
 		// a wave's shadow rays are neighbours (sample groups of >= 8) and the batch's slots leave room for the light's bin
-		p.fr.shadow_bins = (c->integrator == 1 && connect && c->shadow_packets && (p.refill & 8u) && sgroup_log2 >= 3u &&
+		p.fr.shadow_bins = (c->integrator == 1 && connect && (c->shadow_packets > 0 || (c->shadow_packets < 0 && c->shadow_packets_auto_on)) && (p.refill & 8u) && sgroup_log2 >= 3u &&
 							(unsigned long long)n <= (unsigned long long)rt::SHADOW_SLOT_MASK && !side)
 							   ? 1u
 							   : 0u;
@@ -2378,6 +2384,22 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		fold(c->subs_first, wc0);
 		for (size_t k = 0; k < more.size(); k++)
 			fold(c->subs_first + 1 + (int)k, more[k]);
+		// k_shadow_packet: light bins per sorted run of the frames since the last wait.  Many bins per run = the first vertices of
+		// neighbouring pixels do not agree about their lights (an interior lit from all sides): packets of 64 then mix directions and
+		// the per-lane connection wave is as fast or faster (atrium: 7.5 against 7.9 ms per sub-batch; terrain: 6.7 against 5.8)
+		unsigned long long runs = 0, bins = 0;
+		auto fold_sp = [&](int slot, const rt::WaveCounters &w) {
+			runs += w.sp_runs - c->sp_seen[slot][0], bins += w.sp_bins - c->sp_seen[slot][1];
+			c->sp_seen[slot][0] = w.sp_runs, c->sp_seen[slot][1] = w.sp_bins;
+		};
+		fold_sp(c->subs_first, wc0);
+		for (size_t k = 0; k < more.size(); k++)
+			fold_sp(c->subs_first + 1 + (int)k, more[k]);
+		if (runs)
+		{
+			c->shadow_bins_per_run = (double)bins / (double)runs;
+			c->shadow_packets_auto_on = c->shadow_bins_per_run <= SHADOW_PACKET_MAX_BINS_PER_RUN;
+		}
 		for (int d = 0; d < rt::MAX_DEPTH_SLOTS; d++)
 		{
 			const double tot = (double)sums[d][0] + (double)sums[d][1];
@@ -2673,7 +2695,11 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
 	else if (k == "shadow_packets")
-		c->shadow_packets = atoi(value) != 0;
+	{
+		const int v = atoi(value);
+		c->shadow_packets = v < 0 ? -1 : (v != 0);
+		c->shadow_packets_auto_on = true;
+	}
 	else if (k == "flatten_bytes")
 	{
 		c->flatten_bytes = std::max(0ll, atoll(value));
@@ -2756,6 +2782,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->fuse);
 	else if (k == "shadow_packets")
 		snprintf(value, cap, "%d", c->shadow_packets);
+	else if (k == "shadow_bins_per_run") // (read-only: light bins per sorted run of the last waited frames, see shadow_packets)
+		snprintf(value, cap, "%.3f", c->shadow_bins_per_run);
 	else if (k == "streams")
 		snprintf(value, cap, "%d", c->streams);
 	else if (k == "flatten_bytes")

@@ -422,6 +422,9 @@ struct WaveCounters
 	// on the extension rays of depth d [0] and on the shadow rays of depth d - 1 [1] — the shares the host splits the launch's
 	// duration by, so that RenderStats::shadowTime is the shadow rays' although they share a kernel with the extension rays
 	unsigned long long fused_ticks[MAX_DEPTH_SLOTS][2];
+	// k_shadow_packet: runs sorted and light bins that occurred in them, summed over the launch (never reset: the host takes
+	// differences) — bins per run is what tells a scene whose first vertices agree about their lights from one where they do not
+	unsigned long long sp_runs, sp_bins;
 };
 
 // The wavefront state in HBM.
