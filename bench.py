@@ -58,8 +58,10 @@ def stage_kernels(ctx, sample_group):
     (fuse=0: the per-stage table and the counter passes); the default launches both bodies as ONE kernel per depth, `fused`."""
     textured = ctx.get_setting("textured") == "1"
     packet = ctx.get_setting("packet") == "1" and sample_group >= 2
+    # round 6: the connection wave of the primary vertices in packet form (k_shadow_packet) where the library chose it
+    shadow0 = "k_shadow_packet<false>" if (ctx.get_setting("shadow_packets_on") == "1" and sample_group >= 8) else None
     return {"primary": "k_primary_packet<false>" if packet else "k_extend<1, false>", "bounce": "k_trace_stream<false, false>",
-            "shadow": "k_trace_stream<true, false>", "shade": "k_shade_pt<true>" if textured else "k_shade_pt<false>",
+            "shadow": "k_trace_stream<true, false>", "shadow0": shadow0, "shade": "k_shade_pt<true>" if textured else "k_shade_pt<false>",
             "fused": "k_trace_fused<false>"}
 
 
@@ -599,6 +601,7 @@ def main():
         ctx.set_setting("stage_timing", 1)
         ctx.set_setting("overlap", 0)
         ctx.set_setting("fuse", 0)
+        ctx.set_setting("shadow_side", 0)  # (the packet form of the depth-0 connection wave on the sub-batch's own stream: alone on the chip like the others)
         ctx.render_frame(scene.camera, pkg.RESET)
         ser_frames, acc = 3, {}
         for k in range(ser_frames):
@@ -610,6 +613,8 @@ def main():
         ctx.set_setting("spp", args.spp)
         ctx.set_setting("overlap", args.overlap)
         ctx.set_setting("fuse", int(extra.get("fuse", 1)))
+        if not (int(extra.get("fuse", 1)) and (args.refill & 3) == 3 and args.max_depth >= 1):
+            ctx.set_setting("shadow_side", int(extra.get("shadow_side", 1)))
         ser = {"primary": acc["primaryTime"], "bounce": acc["secondaryTime"] + acc["deepTime"], "shadow": acc["shadowTime"],
                "shade": acc["shadeTime"], "resolve": acc["finalizeTime"]}
         # ... and once more as the product launches them: extension rays of depth d + 1 and shadow rays of depth d in ONE kernel per
@@ -631,6 +636,7 @@ def main():
             ctx.set_setting("streams", args.streams)
             ctx.set_setting("spp", args.spp)
             ctx.set_setting("overlap", args.overlap)
+            ctx.set_setting("shadow_side", int(extra.get("shadow_side", 1)))
             fused_ms = {"primary": facc["primaryTime"], "fused": facc["secondaryTime"] + facc["deepTime"] + facc["shadowTime"],
                         "shade": facc["shadeTime"], "resolve": facc["finalizeTime"]}
         frac_of_step = 1.0 / subs  # one sub-batch = 1 / subs of a step's samples
@@ -664,6 +670,28 @@ def main():
                    # above 1: the bytes the algorithm asks for are served by the caches, not by HBM (see counter_hbm_* for HBM)
                    "cache_served": bool(a_gbs and a_gbs > HBM_PEAK_GBS)}
             k = pm["kernels"].get(STAGE_KERNELS[name]) if (pm and fresh) else None
+            if name == "shadow" and STAGE_KERNELS.get("shadow0") and pm and fresh:
+                # the shadow stage as TWO kernels: the packet form for the connections of depth 0 (one launch per sub-batch) and the
+                # per-lane kernel for the deeper ones — the stage's entry is their sum per sub-batch, rates weighted by instructions
+                k0 = pm["kernels"].get(STAGE_KERNELS["shadow0"])
+                if k0:
+                    n1 = max(0, launches[name] - 1)
+                    parts = [(k0, 1)] + ([(k, n1)] if (k and n1) else [])
+                    def tot(key):
+                        vals = [(q.get(key) or 0.0) * m for q, m in parts]
+                        return sum(vals) if all(q.get(key) is not None for q, _ in parts) else None
+                    insts_t = tot("sq_insts_valu_per_dispatch")
+                    def wavg(key):
+                        if not insts_t or any(q.get(key) is None for q, _ in parts):
+                            return None
+                        return round(sum(q[key] * (q.get("sq_insts_valu_per_dispatch") or 0.0) * m for q, m in parts) / insts_t, 4)
+                    k = {"hbm_bytes_per_dispatch": tot("hbm_bytes_per_dispatch") / launches[name] if tot("hbm_bytes_per_dispatch") is not None else None,
+                         "sq_insts_valu_per_dispatch": insts_t / launches[name] if insts_t else None,
+                         "avg_dispatch_us": tot("avg_dispatch_us") / launches[name],
+                         "valu_lanes_per_instruction": wavg("valu_lanes_per_instruction"), "valu_busy_frac": wavg("valu_busy_frac"),
+                         "valu_2_cycle_share": wavg("valu_2_cycle_share"), "valu_slow_pipe_frac": wavg("valu_slow_pipe_frac"),
+                         "valu_issue_frac": wavg("valu_issue_frac"), "valu_transcendental_share": wavg("valu_transcendental_share")}
+                    ent["kernel"] = "%s (depth 0) + %s" % (STAGE_KERNELS["shadow0"], STAGE_KERNELS["shadow"])
             if k:
                 n = launches[name]
                 hbm, insts = k.get("hbm_bytes_per_dispatch"), k.get("sq_insts_valu_per_dispatch")
@@ -744,9 +772,12 @@ def main():
         cand = dict(fused_ms) if fused_ms else {"primary": ser["primary"], "bounce": ser["bounce"], "shadow": ser["shadow"],
                                                 "shade": ser["shade"], "resolve": ser["resolve"]}
         dom = max(cand, key=lambda k: cand[k])
-        dom_kernel = {"primary": STAGE_KERNELS["primary"], "fused": STAGE_KERNELS["fused"], "bounce": STAGE_KERNELS["bounce"],
+        fused_name = STAGE_KERNELS["fused"] if not STAGE_KERNELS.get("shadow0") else (
+            "the traversal of the bounce and shadow waves (%s for the extension rays of depth 1, %s for the connections of depth 0 beside it, %s deeper)" % (
+                STAGE_KERNELS["bounce"], STAGE_KERNELS["shadow0"], STAGE_KERNELS["fused"]))
+        dom_kernel = {"primary": STAGE_KERNELS["primary"], "fused": fused_name, "bounce": STAGE_KERNELS["bounce"],
                       "shadow": STAGE_KERNELS["shadow"], "shade": STAGE_KERNELS["shade"], "resolve": "k_resolve"}[dom]
-        dom_launches = {"primary": 1, "fused": args.max_depth, "bounce": args.max_depth, "shadow": args.max_depth,
+        dom_launches = {"primary": 1, "fused": args.max_depth + (1 if STAGE_KERNELS.get("shadow0") else 0), "bounce": args.max_depth, "shadow": args.max_depth,
                         "shade": args.max_depth + 1, "resolve": 1}[dom]
         dom_parts = {"fused": ("bounce", "shadow")}.get(dom, (dom,))  # the stage entries whose bodies the kernel runs
         dom_algo = sum(algo.get(q, 0.0) for q in dom_parts)          # algorithmic bytes per sub-batch

@@ -441,6 +441,8 @@ struct rfwhip_context
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
 	int shadow_packets = -1;		// the connection wave of the primary vertices in packet form (kernels.hip: k_shadow_packet) where it applies:
 									// 1 always, 0 never, -1 (default) while the runs it sorts hold few light bins (shadow_bins_per_run)
+	int shadow_side = 1;				// ... on the sub-batch's connection stream, beside the extension wave of depth 1 (0: on the sub-batch's own
+									// stream, in front of it — what a per-stage timing wants)
 	bool shadow_packets_auto_on = true; // -1: what the last waited frame's bins per run said (reset to true by rfwhip_update)
 	double shadow_bins_per_run = 0.0;
 	unsigned long long sp_seen[MAX_SUB][2] = {};
@@ -2230,6 +2232,7 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
+		bool sp_side_pending = false; // k_shadow_packet of this sub-batch runs on its connection stream and nobody has waited for it yet
 		if (c->integrator == 0)
 		{
 			p.depth = 0, p.group = row_group, p.queue = queue++;
@@ -2257,6 +2260,11 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				// (grid sizes of the deeper launches: from the paths EXPECTED there, not from the primary count — depth_items)
 				const uint32_t n_ext = depth_items(c, n, d, false), n_shade = depth_items(c, n, d, true);
 				te.fused = pa_pending;
+				if (pa_pending && sp_side_pending) // (the depth-0 connection wave on the side stream zeroes slots this launch's shadow rays add into)
+				{
+					RF_TRY(dm::stream_wait_event(s, c->ev_conn[i][0]));
+					sp_side_pending = false;
+				}
 				if (pa_pending)
 					rtk::launch_trace_fused(p, pa, count, n_ext, s); // extension rays of depth d + shadow rays of depth d - 1
 				else
@@ -2278,9 +2286,22 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 						// the connections of the primary vertices, sorted by light, as packets (their own launch: the extension wave of
 						// depth 1 then runs without them)
 						p.group = 16u, p.queue = queue++;
-						StageTimer tc(c, KF_CONNECT, -1, s);
-						rtk::launch_shadow_packets(p, count, depth_items(c, n, 1, false), s);
+						void *const sp_stream = c->shadow_side ? c->conn_stream[i] : s;
+						if (c->shadow_side)
+						{
+							// beside the extension wave of depth 1, on the sub-batch's connection stream; the connection wave of depth 1
+							// (which adds into the slots this one zeroes) waits for it below
+							RF_TRY(dm::event_record(c->ev_shade[i][0], s));
+							RF_TRY(dm::stream_wait_event(sp_stream, c->ev_shade[i][0]));
+						}
+						StageTimer tc(c, KF_CONNECT, -1, sp_stream);
+						rtk::launch_shadow_packets(p, count, depth_items(c, n, 1, false), sp_stream);
 						tc.stop();
+						if (c->shadow_side)
+						{
+							RF_TRY(dm::event_record(c->ev_conn[i][0], sp_stream));
+							sp_side_pending = true;
+						}
 						continue;
 					}
 					if (fused)
@@ -2306,6 +2327,8 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 				}
 			}
 		}
+		if (sp_side_pending) // (nothing deeper waited for it: the sub-batch is done when it is)
+			RF_TRY(dm::stream_wait_event(s, c->ev_conn[i][0]));
 		RF_TRY(dm::event_record(c->ev_sub_done[i], s));
 		if (conn_now)
 			RF_TRY(dm::event_record(c->ev_conn_last[i], sc));
@@ -2622,7 +2645,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "shadow_packets"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "shadow_packets", "shadow_side"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2694,6 +2717,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 	}
 	else if (k == "fuse")
 		c->fuse = atoi(value) != 0;
+	else if (k == "shadow_side")
+		c->shadow_side = atoi(value) != 0;
 	else if (k == "shadow_packets")
 	{
 		const int v = atoi(value);
@@ -2782,6 +2807,10 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->fuse);
 	else if (k == "shadow_packets")
 		snprintf(value, cap, "%d", c->shadow_packets);
+	else if (k == "shadow_side")
+		snprintf(value, cap, "%d", c->shadow_side);
+	else if (k == "shadow_packets_on") // (read-only: would the next large pt call take the packet form of the depth-0 connection wave?)
+		snprintf(value, cap, "%d", (c->shadow_packets > 0 || (c->shadow_packets < 0 && c->shadow_packets_auto_on)) && c->packet_ok && c->nodes4f_current && (c->refill & 8) ? 1 : 0);
 	else if (k == "shadow_bins_per_run") // (read-only: light bins per sorted run of the last waited frames, see shadow_packets)
 		snprintf(value, cap, "%.3f", c->shadow_bins_per_run);
 	else if (k == "streams")
