@@ -268,8 +268,18 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *   fuse         = "1" (default): the extension rays of depth d + 1 and the shadow rays of depth d share ONE launch (both
  *                  queues are complete when the shade stage of depth d has finished; one kernel tail per depth instead of
  *                  two: 1-spp frames 1.34 -> 1.21 ms); "0": a launch each.  Never changes the image
- *   rfwhip_get_setting also answers three read-only keys: "textured" (the textured shade kernel variant is in use), "packet" (the
- *   pt primary wave can run in packet form) and "world_tree" (triangles in the world tree of the last update; 0: none).
+ *   shadow_packets = "-1" (default) | "1" | "0": the connection wave of the PRIMARY vertices in packet form — their shadow rays
+ *                  carry the chosen light's bin in the top bits of their slot word, a wave sorts runs of 256 rays by it and walks
+ *                  the tree once per 64 rays (wave-uniform occlusion traversal) instead of once per lane; applies where the pt
+ *                  primary wave can run in packet form, the samples of a pixel sit side by side (sample_group >= 8) and a
+ *                  sub-batch has fewer than 2^27 path slots.  "-1": while the sorted runs of the last waited frame hold at most
+ *                  4.5 light bins on average (read-only key "shadow_bins_per_run"; "shadow_packets_on" says what the next call
+ *                  will do) — an interior lit from all sides gains nothing from it.  Never changes the image
+ *   shadow_side  = "1" (default): that wave runs on the sub-batch's connection stream, beside the extension wave of depth 1;
+ *                  "0": on the sub-batch's own stream, in front of it (per-stage timings)
+ *   rfwhip_get_setting also answers read-only keys: "textured" (the textured shade kernel variant is in use), "packet" (the
+ *   pt primary wave can run in packet form), "world_tree" (triangles in the world tree of the last update; 0: none),
+ *   "shadow_bins_per_run", "shadow_packets_on".
  * Returns the number of keys; fills up to cap pointers with static strings. */
 RFWHIP_API int rfwhip_set_setting(rfwhip_context *ctx, const char *key, const char *value);
 RFWHIP_API int rfwhip_get_setting(rfwhip_context *ctx, const char *key, char *value, size_t cap);

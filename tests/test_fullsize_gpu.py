@@ -255,3 +255,27 @@ def test_atrium_world_tree_on_and_off(pkg, make_hip, atrium):
     assert abs(ia.mean() - ib.mean()) <= 2e-3 * ib.mean()
     for x, y in zip(ca, cb):
         assert abs(x - y) <= 3e-3 * max(y, 1), (ca, cb)
+
+
+def test_connection_packets_do_not_change_the_image(pkg, make_hip, terrain, atrium):
+    """Round 6: the connection wave of the primary vertices in packet form (k_shadow_packet: shadow rays carry their light's bin in the
+    top bits of their slot word, a wave sorts runs of 256 by it and walks the tree once per 64 rays; setting shadow_packets, on the
+    sub-batch's connection stream with shadow_side).  Which rays share a packet changes no ray's answer: image, primary hits and
+    per-depth ray counts are those of the per-lane connection wave, bit for bit, on the bench scene and on the atrium at full size;
+    the default (-1) measures the light bins per sorted run and keeps the packets where the first vertices agree about their lights."""
+    for scene, name in ((terrain, "terrain"), (atrium, "atrium")):
+        out = []
+        for settings in (dict(shadow_packets=0), dict(shadow_packets=1, shadow_side=0), dict(shadow_packets=1, shadow_side=1), dict()):
+            c = _ctx(pkg, make_hip, scene, spp=16, **settings)
+            c.render_frame(scene.camera, pkg.RESET)
+            c.render_frame(scene.camera, pkg.CONVERGE)
+            st = c.get_stats()
+            out.append((c.framebuffer(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount), float(c.get_setting("shadow_bins_per_run")),
+                        c.get_setting("shadow_packets_on")))
+            c.destroy()
+        for img, counts, _, _ in out[1:]:
+            assert np.array_equal(img, out[0][0]), name
+            assert counts == out[0][1], name
+        assert out[0][2] == 0.0 and out[1][2] > 1.0          # (no packets, no runs sorted; with them: a few bins per run)
+        # the default decides by the measured bins per run (4.5): the terrain's first vertices agree about their lights, the atrium's do not
+        assert out[3][3] == ("1" if name == "terrain" else "0"), (name, out[3][2], out[3][3])
