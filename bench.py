@@ -769,15 +769,23 @@ def main():
                              "algorithmic_gbs_over_the_step": round(algo_shade / (step_ms * 1e-3) / 1e9, 1),
                              "algorithmic_rate_below_peak": bool(algo_shade / (step_ms * 1e-3) / 1e9 <= HBM_PEAK_GBS)}}
         # the candidates' times per sub-batch, alone on the chip, as the product launches them
-        cand = dict(fused_ms) if fused_ms else {"primary": ser["primary"], "bounce": ser["bounce"], "shadow": ser["shadow"],
-                                                "shade": ser["shade"], "resolve": ser["resolve"]}
+        # (round 6, connections of depth 0 in packet form: the bounce and shadow waves are no longer ONE kernel per depth — the extension
+        # rays of depth 1 run in k_trace_stream<false>, the connections of depth 0 beside them in k_shadow_packet, only the deeper waves
+        # share k_trace_fused — so they are candidates of their own: bounce = the extension rays' launches and halves, shadow = the
+        # connections'; hipEvents and, inside k_trace_fused, the device's tick sums, as the product launches them)
+        if fused_ms and STAGE_KERNELS.get("shadow0"):
+            cand = {"primary": facc["primaryTime"], "bounce": facc["secondaryTime"] + facc["deepTime"], "shadow": facc["shadowTime"],
+                    "shade": facc["shadeTime"], "resolve": facc["finalizeTime"]}
+        elif fused_ms:
+            cand = dict(fused_ms)
+        else:
+            cand = {"primary": ser["primary"], "bounce": ser["bounce"], "shadow": ser["shadow"], "shade": ser["shade"], "resolve": ser["resolve"]}
         dom = max(cand, key=lambda k: cand[k])
-        fused_name = STAGE_KERNELS["fused"] if not STAGE_KERNELS.get("shadow0") else (
-            "the traversal of the bounce and shadow waves (%s for the extension rays of depth 1, %s for the connections of depth 0 beside it, %s deeper)" % (
-                STAGE_KERNELS["bounce"], STAGE_KERNELS["shadow0"], STAGE_KERNELS["fused"]))
-        dom_kernel = {"primary": STAGE_KERNELS["primary"], "fused": fused_name, "bounce": STAGE_KERNELS["bounce"],
-                      "shadow": STAGE_KERNELS["shadow"], "shade": STAGE_KERNELS["shade"], "resolve": "k_resolve"}[dom]
-        dom_launches = {"primary": 1, "fused": args.max_depth + (1 if STAGE_KERNELS.get("shadow0") else 0), "bounce": args.max_depth, "shadow": args.max_depth,
+        dom_kernel = {"primary": STAGE_KERNELS["primary"], "fused": STAGE_KERNELS["fused"],
+                      "bounce": STAGE_KERNELS["bounce"] + (" (+ the extension rays' half of %s at depth >= 2)" % STAGE_KERNELS["fused"] if fused_ms else ""),
+                      "shadow": ("%s (depth 0) + the connections' half of %s" % (STAGE_KERNELS["shadow0"], STAGE_KERNELS["fused"])) if STAGE_KERNELS.get("shadow0") else STAGE_KERNELS["shadow"],
+                      "shade": STAGE_KERNELS["shade"], "resolve": "k_resolve"}[dom]
+        dom_launches = {"primary": 1, "fused": args.max_depth, "bounce": args.max_depth, "shadow": args.max_depth,
                         "shade": args.max_depth + 1, "resolve": 1}[dom]
         dom_parts = {"fused": ("bounce", "shadow")}.get(dom, (dom,))  # the stage entries whose bodies the kernel runs
         dom_algo = sum(algo.get(q, 0.0) for q in dom_parts)          # algorithmic bytes per sub-batch
