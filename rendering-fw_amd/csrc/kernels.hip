@@ -1488,8 +1488,12 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 					}
 			}
 			// the nearest child some lane enters comes next, the other entered children go on the stack (scalar unit)
-			uint32_t k0 = packet_key(tk[0], m[0], ref_lane), k1 = packet_key(tk[1], m[1], ref_lane);
-			uint32_t k2 = packet_key(tk[2], m[2], ref_lane), k3 = packet_key(tk[3], m[3], ref_lane);
+			// (ANY: an occlusion ray that reaches its light walks every node along it whatever the order, and most do — the children
+			// are taken as they come: no entry distances fetched from the reference lane, no comparators)
+#define RT_ANY_KEY(M) ((uint32_t)__builtin_amdgcn_readfirstlane((int)((M) ? 0u : 0xFFFFFFFFu)))
+			uint32_t k0 = ANY ? RT_ANY_KEY(m[0]) : packet_key(tk[0], m[0], ref_lane), k1 = ANY ? RT_ANY_KEY(m[1]) : packet_key(tk[1], m[1], ref_lane);
+			uint32_t k2 = ANY ? RT_ANY_KEY(m[2]) : packet_key(tk[2], m[2], ref_lane), k3 = ANY ? RT_ANY_KEY(m[3]) : packet_key(tk[3], m[3], ref_lane);
+#undef RT_ANY_KEY
 			uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3];
 #define RT_PSWAP(KA, EA, KB, EB)                          \
 	{                                                     \
@@ -1498,9 +1502,12 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 		KB = sw ? KA : KB, EB = sw ? EA : EB;             \
 		KA = kl, EA = el;                                 \
 	}
-			RT_PSWAP(k0, e0, k1, e1)
-			RT_PSWAP(k2, e2, k3, e3)
-			RT_PSWAP(k0, e0, k2, e2)
+			if (!ANY)
+			{
+				RT_PSWAP(k0, e0, k1, e1)
+				RT_PSWAP(k2, e2, k3, e3)
+				RT_PSWAP(k0, e0, k2, e2)
+			}
 #undef RT_PSWAP
 			// (three of the five comparators: the nearest entered child first, the others in no particular order — all five measure
 			// the same, 5.18 against 4.93 ms per primary wave.)  The pop below reads what was just written
