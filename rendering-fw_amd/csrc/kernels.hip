@@ -1718,7 +1718,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 			bin[j] = SHADOW_BINS; // (beyond the run, or void)
 			if (e < n)
 			{
-				const uint32_t w = fbits(p.wv.sh_org[g + e].w);
+				const uint32_t w = fbits(fresh_params().wv.sh_org[g + e].w);
 				bin[j] = w == RAY_VOID ? SHADOW_BINS : w >> SHADOW_SLOT_BITS;
 			}
 		}
@@ -1749,14 +1749,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 			if (active)
 			{
 				idx = order[k + lane];
-				const f4 o4 = p.wv.sh_org[idx], d4 = p.wv.sh_dir[idx];
-				O = xyz(o4), D = xyz(d4), h.t = d4.w, slot = shadow_slot(p, fbits(o4.w));
+				const Params &q = fresh_params(); // (the arguments from the kernarg segment again: nothing of them stays live across the walk)
+				const f4 o4 = q.wv.sh_org[idx], d4 = q.wv.sh_dir[idx];
+				O = xyz(o4), D = xyz(d4), h.t = d4.w, slot = shadow_slot(q, fbits(o4.w));
 			}
 			// (a ray of negative length is traced, hits nothing and counts: Kernels.cu:750 — the packet walks nothing for it)
 			trace_packet<COUNT, true>(fresh_params().sc, active && h.t > 1e-5f, O, D, 1e-5f, h, st);
 			if (active)
 			{
-				connect_finish(p, idx, slot, h.prim < 0);
+				connect_finish(fresh_params(), idx, slot, h.prim < 0);
 				nrays++;
 			}
 		}
@@ -1842,6 +1843,9 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 #ifndef RT_SHADE_RUN
 #define RT_SHADE_RUN 32u
 #endif
+#ifndef RT_SHADE_FRESH_PARAMS
+#define RT_SHADE_FRESH_PARAMS 1
+#endif
 	// a wave walks RUNS of consecutive chunks (fewer when the launch has less than four runs per wave)
 	uint32_t srun = nchunks / (nwaves * 4u);
 	srun = srun > RT_SHADE_RUN ? RT_SHADE_RUN : (srun ? srun : 1u);
@@ -1913,7 +1917,13 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 #if defined(RT_DIAG_SHADE_CLOCK)
 		shade_pt_item<TEX>(p, idx, act, h4, hi, ctx, &clk);
 #else
+#if RT_SHADE_FRESH_PARAMS
+		// (the kernel's arguments read again from the kernarg segment — scalar loads — instead of staying live across the loop: with
+		// ~150 wave-uniform words of scene, wave buffers, camera and frame the compiler parks them in VGPR lanes, a v_readlane per use)
+		shade_pt_item<TEX>(fresh_params(), idx, act, h4, hi, ctx);
+#else
 		shade_pt_item<TEX>(p, idx, act, h4, hi, ctx);
+#endif
 #endif
 	}
 #if defined(RT_DIAG_SHADE_CLOCK)
