@@ -473,7 +473,10 @@ RT_FN void connect_finish(const Params &p, uint32_t i, uint32_t slot, bool visib
 // Depth 0 and no path went on (connection_count() == 0: the reference's host loop traces no connections then): the slots the
 // shade kernel left to the connection wave still have to start at zero.
 // the path slot of a shadow ray's slot word (depth 0 with FrameView::shadow_bins: the light's bin sits above it)
-RT_FN uint32_t shadow_slot(const Params &p, uint32_t word) { return (p.depth == 0 && p.fr.shadow_bins) ? word & SHADOW_SLOT_MASK : word; }
+RT_FN uint32_t shadow_slot(const Params &p, uint32_t word)
+{
+	return (p.depth == 0 && p.fr.shadow_bins) ? word & ((1u << shadow_slot_bits(p.fr.shadow_bins)) - 1u) : word;
+}
 RT_FN void connect_skip_item(const Params &p, uint32_t i)
 {
 	const f4 o4 = p.wv.sh_org[i];
@@ -1693,6 +1696,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 	}
 	const uint32_t lane = __lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint32_t *const order = s_order[wave];
+	const uint32_t slot_bits = shadow_slot_bits(p.fr.shadow_bins);
 	uint32_t *const head = &p.wv.counters->work[p.queue][0];
 	TStat st;
 	st.inner = 0, st.tris = 0, st.lds = 0;
@@ -1719,7 +1723,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_shadow_packet(
 			if (e < n)
 			{
 				const uint32_t w = fbits(fresh_params().wv.sh_org[g + e].w);
-				bin[j] = w == RAY_VOID ? SHADOW_BINS : w >> SHADOW_SLOT_BITS;
+				bin[j] = w == RAY_VOID ? SHADOW_BINS : w >> slot_bits;
 			}
 		}
 		uint32_t valid = 0;

@@ -2225,10 +2225,12 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 		const uint32_t n = c->fr.slots * spp_i;
 		// packet form of the depth-0 connection wave: where the packet traversal can run (float node table, trees within its stack),
 		// a wave's shadow rays are neighbours (sample groups of >= 8) and the batch's slots leave room for the light's bin
-		p.fr.shadow_bins = (c->integrator == 1 && connect && (c->shadow_packets > 0 || (c->shadow_packets < 0 && c->shadow_packets_auto_on)) && (p.refill & 8u) && sgroup_log2 >= 3u &&
-							(unsigned long long)n <= (unsigned long long)rt::SHADOW_SLOT_MASK && !side)
-							   ? 1u
-							   : 0u;
+		p.fr.shadow_bins = 0u;
+		if (c->integrator == 1 && connect && (c->shadow_packets > 0 || (c->shadow_packets < 0 && c->shadow_packets_auto_on)) && (p.refill & 8u) &&
+			sgroup_log2 >= 3u && !side)
+			for (uint32_t b = rt::SHADOW_BIN_BITS; b >= 1u && !p.fr.shadow_bins; b--) // (as many bin bits as the batch's slots leave room for)
+				if ((unsigned long long)n <= (1ull << rt::shadow_slot_bits(b)))
+					p.fr.shadow_bins = b;
 		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;

@@ -1987,7 +1987,8 @@ RT_FN void pt_shade(const SceneView &sc, const CamView &cam, const FrameView &fr
 							emit_shadow = true;
 							// (depth 0, fr.shadow_bins: the light's bin rides in the top bits of the slot word — what the packet form of the
 							// connection wave sorts a run's rays by)
-							const uint32_t bin = (fr.shadow_bins && in.depth == 0u) ? (light < SHADOW_BINS - 1u ? light : SHADOW_BINS - 1u) << SHADOW_SLOT_BITS : 0u;
+							const uint32_t last_bin = (1u << fr.shadow_bins) - 1u;
+							const uint32_t bin = (fr.shadow_bins && in.depth == 0u) ? (light < last_bin ? light : last_bin) << shadow_slot_bits(fr.shadow_bins) : 0u;
 							so = mk4(o.x, o.y, o.z, ubits(in.slot | bin));
 							sdir = mk4(L.x, L.y, L.z, dist - 2.0f * 1e-5f);
 							se = mk4(contribution.x, contribution.y, contribution.z, 0.0f);

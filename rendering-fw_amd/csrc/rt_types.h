@@ -354,8 +354,9 @@ struct FrameView
 	uint32_t sample_base;  // index of the first sample of the batch
 	uint32_t probe_pixel;  // y*W + x
 	uint32_t sgroup_log2;  // log2 of the sample group g (rt_core.h: slot layout): a wave's 64 slots = 64/g pixels x g samples
-	uint32_t shadow_bins;  // the shadow rays of the primary vertices carry the chosen light's bin in the top bits of their slot word
-						   // (SHADOW_SLOT_BITS: the call's path slots fit below): k_shadow_packet sorts a run's rays by it
+	uint32_t shadow_bins;  // b > 0: the shadow rays of the primary vertices carry the chosen light's bin in b bits above their path slot
+						   // (bits 31 - b .. 30 of the slot word; the sub-batch's slots fit below; b = SHADOW_BIN_BITS = 4 up to 2^27
+						   // slots, 3 / 2 / 1 for larger ones): k_shadow_packet sorts a run's rays by it
 	FastDiv div_tiles_x;   // n / tiles_x
 	FastDiv div_group;	   // n / (slots << sgroup_log2): which sample group a slot belongs to
 };
@@ -393,8 +394,8 @@ constexpr int WORK_QUEUES = 3 * MAX_DEPTH_SLOTS + 4; // one per traversal launch
 #define RT_QUEUE_BLOCK 256u
 #endif
 constexpr uint32_t QUEUE_BLOCK = RT_QUEUE_BLOCK;
-constexpr uint32_t SHADOW_SLOT_BITS = 27u, SHADOW_SLOT_MASK = (1u << SHADOW_SLOT_BITS) - 1u; // FrameView::shadow_bins
-constexpr uint32_t SHADOW_BINS = 16u;		   // lights 0..14 have bins of their own, the others share the last
+constexpr uint32_t SHADOW_BIN_BITS = 4u, SHADOW_BINS = 1u << SHADOW_BIN_BITS; // at most: lights 0..14 have bins of their own, the others share the last
+RT_FN uint32_t shadow_slot_bits(uint32_t bin_bits) { return 31u - bin_bits; }		 // (bit 31 stays clear: a slot word is never RAY_VOID)
 constexpr uint32_t RAY_VOID = 0xFFFFFFFFu; // org.w / sh_org.w of a void queue entry (slots are < 2^31)
 constexpr int HIT_VOID = -2;			   // hit.prim of a void entry (-1: miss)
 constexpr int HIT_MISS_SHADED = -3;	   // primary wave, packet form: a miss whose sky term is already in its slot (read back as -1)

@@ -279,3 +279,12 @@ def test_connection_packets_do_not_change_the_image(pkg, make_hip, terrain, atri
         assert out[0][2] == 0.0 and out[1][2] > 1.0          # (no packets, no runs sorted; with them: a few bins per run)
         # the default decides by the measured bins per run (4.5): the terrain's first vertices agree about their lights, the atrium's do not
         assert out[3][3] == ("1" if name == "terrain" else "0"), (name, out[3][2], out[3][3])
+    # a sub-batch of more than 2^27 path slots (128 spp in ONE sub-batch: 265 M) leaves 3 bits for the bin instead of 4: 8 bins
+    big = []
+    for sp in (0, 1):
+        c = _ctx(pkg, make_hip, terrain, spp=128, streams=1, shadow_packets=sp)
+        c.render_frame(terrain.camera, pkg.RESET)
+        st = c.get_stats()
+        big.append((c.framebuffer(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount), float(c.get_setting("shadow_bins_per_run"))))
+        c.destroy()
+    assert np.array_equal(big[0][0], big[1][0]) and big[0][1] == big[1][1] and big[1][2] > 1.0
