@@ -1817,7 +1817,7 @@ static int sync_all(rfwhip_context *c);
 // sub-batches double-buffers sets 0 / 1).
 constexpr size_t WAVE_SLOT_BYTES = 2 * 3 * sizeof(f4) + 2 * (sizeof(f4) + 4) + 2 * 3 * sizeof(f4);
 constexpr size_t RAD_SLOT_BYTES = 2 * sizeof(f4);
-constexpr double SHADOW_PACKET_MAX_BINS_PER_RUN = 4.5; // (shadow_packets = -1; measured: DESIGN.md §4 "Round 6")
+constexpr double SHADOW_PACKET_MAX_BINS_PER_RUN = 8.0; // (shadow_packets = -1; measured: DESIGN.md §4 "Round 6")
 static size_t wave_bytes_held(const rfwhip_context *c);
 static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots0, size_t rad_slots1)
 {
@@ -2410,8 +2410,8 @@ extern "C" int rfwhip_wait(rfwhip_context *c)
 		for (size_t k = 0; k < more.size(); k++)
 			fold(c->subs_first + 1 + (int)k, more[k]);
 		// k_shadow_packet: light bins per sorted run of the frames since the last wait.  Many bins per run = the first vertices of
-		// neighbouring pixels do not agree about their lights (an interior lit from all sides): packets of 64 then mix directions and
-		// the per-lane connection wave is as fast or faster (atrium: 7.5 against 7.9 ms per sub-batch; terrain: 6.7 against 5.8)
+		// neighbouring pixels do not agree about their lights: packets of 64 then mix many directions.  Measured: terrain 3.6 bins per
+		// run, + 8 %; atrium (an interior lit from all sides) 5.5, + 0.6 %; the threshold, half of the 16 bins, is beyond what was measured
 		unsigned long long runs = 0, bins = 0;
 		auto fold_sp = [&](int slot, const rt::WaveCounters &w) {
 			runs += w.sp_runs - c->sp_seen[slot][0], bins += w.sp_bins - c->sp_seen[slot][1];

@@ -262,7 +262,7 @@ def test_connection_packets_do_not_change_the_image(pkg, make_hip, terrain, atri
     top bits of their slot word, a wave sorts runs of 256 by it and walks the tree once per 64 rays; setting shadow_packets, on the
     sub-batch's connection stream with shadow_side).  Which rays share a packet changes no ray's answer: image, primary hits and
     per-depth ray counts are those of the per-lane connection wave, bit for bit, on the bench scene and on the atrium at full size;
-    the default (-1) measures the light bins per sorted run and keeps the packets where the first vertices agree about their lights."""
+    the default (-1) measures the light bins per sorted run and keeps the packets while they average at most 8."""
     for scene, name in ((terrain, "terrain"), (atrium, "atrium")):
         out = []
         for settings in (dict(shadow_packets=0), dict(shadow_packets=1, shadow_side=0), dict(shadow_packets=1, shadow_side=1), dict()):
@@ -277,8 +277,8 @@ def test_connection_packets_do_not_change_the_image(pkg, make_hip, terrain, atri
             assert np.array_equal(img, out[0][0]), name
             assert counts == out[0][1], name
         assert out[0][2] == 0.0 and out[1][2] > 1.0          # (no packets, no runs sorted; with them: a few bins per run)
-        # the default decides by the measured bins per run (4.5): the terrain's first vertices agree about their lights, the atrium's do not
-        assert out[3][3] == ("1" if name == "terrain" else "0"), (name, out[3][2], out[3][3])
+        # the default decides by the measured bins per run (<= 8 of the 16): on for both (terrain ~3.6, atrium ~5.5)
+        assert out[3][3] == "1" and 1.0 < out[3][2] <= 8.0, (name, out[3][2], out[3][3])
     # a sub-batch of more than 2^27 path slots (128 spp in ONE sub-batch: 265 M) leaves 3 bits for the bin instead of 4: 8 bins
     big = []
     for sp in (0, 1):
