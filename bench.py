@@ -577,7 +577,8 @@ def main():
         # bounce: 32 B ray in + 20 B hit out; shadow: 32 B ray in (the contribution record and the 32 B read-modify-write of an
         # unoccluded ray's radiance at depths >= 1, the 16 B store of an occluded one at depth 0 are not counted: no count of them
         # is kept — a lower bound); traversal: 64 B per popped 4-wide node, 52 B per triangle test
-        algo_primary = prim_hits0 * 20 + (prim["rays_extend"] - prim_hits0) * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
+        # (round 6, late: a hit's slot of radiance starts in the primary kernel too — 16 B more written here, 16 B less in the shade kernel)
+        algo_primary = prim_hits0 * (20 + 16) + (prim["rays_extend"] - prim_hits0) * (16 + 20) + NODE_BYTES * prim["inner_extend"] + 52.0 * prim["tris_extend"]
         algo_bounce = bounce["rays_extend"] * (32 + 20) + NODE_BYTES * bounce["inner_extend"] + 52.0 * bounce["tris_extend"]
         algo_shadow = per_step["rays_shadow"] * 32 + NODE_BYTES * per_step["inner_shadow"] + 52.0 * per_step["tris_shadow"]
         # shade: depth-0 hits read their hit record + instance (20 B; round 6: the primary ray is regenerated from pixel and sample, no direction record) and write 16 B radiance (+ 16 B for the connection term of a
@@ -590,7 +591,12 @@ def main():
         prim_miss = max(0.0, prim["rays_extend"] - prim_hits)
         packet_primaries = (args.refill & 8) != 0 and args.integrator == "pt"
         shade_record = 64 + (32 if ctx.get_setting("textured") == "1" else 0)
-        algo_shade = (prim_hits * (20 + 16) + prim_miss * (20 if packet_primaries else 20 + 16) +
+        # Round 6, late: (a) the packet form flags the 64-slot groups it has finished and the scan passes them by — the misses' 20 B are
+        # read only in groups that also hold a hit (no count of those is kept: counted as 0, a lower bound); (b) the radiance slot of
+        # a hit is initialised by the primary kernel, the shade kernel writes it only for a path that adds light or ends at depth 0
+        # (no count kept: 0, a lower bound)
+        group_flags = packet_primaries and ctx.get_setting("group_flags") == "1"
+        algo_shade = (prim_hits * 20 + prim_miss * (0 if group_flags else 20 if packet_primaries else 20 + 16) +
                       max(0.0, prim_hits - per_step["rays_shadow"]) * 16 +
                       bounce["rays_extend"] * 68 + per_step["shaded"] * (shade_record + 48) + per_step["rays_shadow"] * 48 + bounce["rays_extend"] * 48)
 

@@ -275,6 +275,9 @@ RFWHIP_API int rfwhip_get_stats(rfwhip_context *ctx, rfwhip_render_stats *stats)
  *                  to 2^27 path slots per sub-batch, 8 / 4 / 2 for larger ones.  "-1": while the sorted runs of the last waited frame hold at most
  *                  8 light bins on average (read-only key "shadow_bins_per_run"; "shadow_packets_on" says what the next call
  *                  will do; measured: 3.6 bins per run + 8 %, 5.5 bins + 0.6 %).  Never changes the image
+ *   group_flags  = "1" (default): the packet form of the pt primary wave flags the 64-slot groups it has finished itself (no hit:
+ *                  sky terms written) in a byte each, and the shade kernel's scan passes them by without reading their records
+ *                  (a quarter of the terrain's groups).  "0": every record is read.  Never changes the image
  *   shadow_side  = "1" (default): that wave runs on the sub-batch's connection stream, beside the extension wave of depth 1;
  *                  "0": on the sub-batch's own stream, in front of it (per-stage timings)
  *   rfwhip_get_setting also answers read-only keys: "textured" (the textured shade kernel variant is in use), "packet" (the

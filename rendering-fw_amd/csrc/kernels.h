@@ -45,6 +45,7 @@ void launch_set_ext_count(rt::WaveCounters *c, uint32_t depth, uint32_t count, s
 void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uint32_t *jump_table,
 					   uint32_t packets_per_sample, uint32_t spp, stream_t s);
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t s);
+bool primary_packet_form(const Params &p, uint32_t max_items); // the pt primary wave of such a launch fills WaveView::hit0_done
 void launch_shade_parity(const Params &p, bool count, uint32_t max_items, stream_t s);
 uint32_t queue_pad(uint32_t max_items); // extra slots per queue and launch for the void entries of unfinished blocks
 void launch_shade_pt(const Params &p, uint32_t max_items, stream_t s);

@@ -174,6 +174,9 @@ struct Ctx
 // (pt_shade, h.prim < 0 at depth 0: throughput 1, pdf 1; shade_pt_item: alpha -1 = the path ends, no connection record) — needs
 // nothing the kernel does not hold.  The shade kernel then neither queues the path nor reads its direction (27 % of the bench
 // scene's primaries), and no direction record is written for it; its hit record says HIT_MISS_SHADED (read back as a miss).
+#ifndef RT_PRIMARY_INITS_RAD
+#define RT_PRIMARY_INITS_RAD 1
+#endif
 #ifndef RT_PRIMARY_MISS
 #define RT_PRIMARY_MISS 1
 #endif
@@ -196,8 +199,15 @@ RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h
 		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
 		prim = HIT_MISS_SHADED;
 	}
-	else if (RT_PRIMARY_RAY_RECORD)
-		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+	else
+	{
+		if (RT_PRIMARY_RAY_RECORD)
+			q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
+		// a hit's slot starts as what most hits leave there — no radiance, a path that goes on — from here, where the stores of a
+		// wave are neighbours and the memory pipes idle; the shade kernel writes the slot of a path that adds light or ends only
+		if (RT_PRIMARY_INITS_RAD)
+			q.wv.rad[idx] = mk4(0.0f, 0.0f, 0.0f, 1.0f);
+	}
 	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
 	q.wv.hit0_inst[idx] = h.inst;
 }
@@ -426,7 +436,9 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 			// rad_nee is neither initialised nor read; alpha -1 tells the resolve (|alpha| is the alpha: the pt integrator's is 1).
 			// 16 bytes less written here and 16 less read there for every such path (two in five on the terrain).
 			const bool ends = p.wv.rad_nee && !out.emit_shadow && !out.emit_ext;
-			p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, ends ? -1.0f : 1.0f);
+			// (a hit without light of its own that goes on: primary_finish_item has written exactly that)
+			if (!RT_PRIMARY_INITS_RAD || h.prim < 0 || ends || out.radiance.x != 0.0f || out.radiance.y != 0.0f || out.radiance.z != 0.0f)
+				p.wv.rad[slot] = mk4(out.radiance.x, out.radiance.y, out.radiance.z, ends ? -1.0f : 1.0f);
 			// (a path with a shadow ray: ShadeSink::shadow has stored its connection term)  Paths that emit no shadow ray but go on
 			// start theirs at zero.
 			if (p.wv.rad_nee && out.emit_ext && !out.emit_shadow)
@@ -1655,6 +1667,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 				primary_finish_item(fresh_params(), idx, D, h); // (direction + hit record, or the sky term of a miss)
 				nrays++;
 			}
+			// a group without a hit is finished here (27 % of the terrain's): the shade kernel's scan passes it by
+			if (RT_PRIMARY_MISS)
+			{
+				unsigned char *const done = fresh_params().wv.hit0_done;
+				const bool none = __ballot(active && h.prim >= 0) == 0ull;
+				if (done && lane == 0u)
+					done[base >> 6] = none ? 1 : 0;
+			}
 		}
 	}
 	if (COUNT)
@@ -1858,6 +1878,11 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 	uint32_t hq = 0, nq = 0;						// hit queue: first entry, entries (wave-uniform)
 	uint32_t mq = 0, nm = 0;						// miss queue
 	uint32_t nshaded = 0;							// hits shaded by this wave (statistics: the gathers of the roofline's byte count)
+	// depth 0 behind the packet form of the primary wave: which 64-slot groups of the wave's run are finished already
+	// (WaveView::hit0_done; one coalesced byte load and a ballot per run)
+	static_assert(RT_SHADE_RUN <= 32u, "run_done is a 32-bit mask");
+	const unsigned char *const done = p.depth == 0 ? p.wv.hit0_done : nullptr;
+	uint32_t run_done = 0;
 #pragma nounroll
 	for (;;)
 	{
@@ -1884,11 +1909,16 @@ template <bool TEX> __global__ void __launch_bounds__(BLOCK, TEX ? RT_SHADE_WAVE
 		}
 		else if (!drain)
 		{
+			if (done && c_left == srun) // a run begins
+				run_done = (uint32_t)__ballot(lane < srun && c + lane < nchunks && done[c + lane] != 0);
+			const bool skip = (run_done >> (srun - c_left)) & 1u;
 			idx = c * 64u + lane;
 			if (--c_left)
 				c++;
 			else
 				c += (nwaves - 1u) * srun + 1u, c_left = srun;
+			if (skip)
+				continue;
 			bool valid = idx < count;
 			if (p.depth == 0 && valid)
 				valid = slot_to_pixel(p.fr, idx).valid;
@@ -2174,6 +2204,12 @@ void launch_rng_states(uint32_t *states, const uint32_t base_state[4], const uin
 					   jump_table, total);
 }
 
+// does the pt primary wave of this launch run in packet form?  (the host asks too: only that form fills WaveView::hit0_done)
+bool primary_packet_form(const Params &p, uint32_t max_items)
+{
+	return (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= RT_PRIMARY_PACKET_MIN);
+}
+
 void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, stream_t s)
 {
 	const dim3 g(persistent_grid(max_items)), b(BLOCK);
@@ -2201,7 +2237,7 @@ void launch_extend(const Params &p, int gen, bool count, uint32_t max_items, str
 		else
 			RT_EXT(GEN_RANGED, false);
 	}
-	else if (gen == GEN_PT && (p.refill & 8u) && (p.fr.sgroup_log2 >= 1u || max_items >= RT_PRIMARY_PACKET_MIN))
+	else if (gen == GEN_PT && primary_packet_form(p, max_items))
 	{
 		// packet form of the primary wave: no LDS, one wave = one 64-slot group at a time.  MI355X, 1080p terrain, 64 spp per
 		// launch, primary wave per-lane / packet by sample-group size: 1: 9.33 / 9.07 ms, 4: 9.08 / 6.60, 8: 8.87 / 6.39, 16: 8.79 /

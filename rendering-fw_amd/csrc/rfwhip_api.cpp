@@ -441,6 +441,7 @@ struct rfwhip_context
 	bool depth_stats_valid = false; // c->stats counts paths of the CURRENT scene (depth_items)
 	int shadow_packets = -1;		// the connection wave of the primary vertices in packet form (kernels.hip: k_shadow_packet) where it applies:
 									// 1 always, 0 never, -1 (default) while the runs it sorts hold few light bins (shadow_bins_per_run)
+	int group_flags = 1;				// the packet form of the pt primary wave flags the 64-slot groups it finishes; the shade scan passes them by
 	int shadow_side = 1;				// ... on the sub-batch's connection stream, beside the extension wave of depth 1 (0: on the sub-batch's own
 									// stream, in front of it — what a per-stage timing wants)
 	bool shadow_packets_auto_on = true; // -1: what the last waited frame's bins per run said (reset to true by rfwhip_update)
@@ -478,7 +479,7 @@ struct rfwhip_context
 	// wave state
 	// shadow-ray buffers: two sets (by depth parity) so that shade(d + 1) can write while connect(d) still reads;
 	// radiance: two sets (by call parity) x {shade, connections}, so that a call can start while the previous one resolves
-	DevBuf d_org[2], d_dir2[2], d_thr[2], d_hit, d_hit_inst, d_hit0, d_hit0_inst, d_sh_org[2], d_sh_dir[2], d_sh_rad[2],
+	DevBuf d_org[2], d_dir2[2], d_thr[2], d_hit, d_hit_inst, d_hit0, d_hit0_inst, d_hit0_done, d_sh_org[2], d_sh_dir[2], d_sh_rad[2],
 		d_rad[2], d_rad_nee[2], d_acc, d_counters, d_packet_rng, d_jump_table, d_present;
 	uint32_t samples_done = 0;
 	size_t wave_capacity = 0; // path slots the wave buffers can hold
@@ -644,7 +645,7 @@ static void free_all(rfwhip_context *c)
 	DevBuf *bufs[] = {&c->d_nodes4, &c->d_nodes4f, &c->d_nodes4_src, &c->d_nodes, &c->d_tri_verts, &c->d_tri_shade, &c->d_tri_uv, &c->d_tlas_prims, &c->d_instances,
 					  &c->d_materials, &c->d_textures, &c->d_tex_u32, &c->d_tex_f4, &c->d_sky, &c->d_area, &c->d_point,
 					  &c->d_spot, &c->d_dir, &c->d_org[0], &c->d_org[1], &c->d_dir2[0], &c->d_dir2[1], &c->d_thr[0],
-					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_sh_org[0], &c->d_sh_org[1],
+					  &c->d_thr[1], &c->d_hit, &c->d_hit_inst, &c->d_hit0, &c->d_hit0_inst, &c->d_hit0_done, &c->d_sh_org[0], &c->d_sh_org[1],
 					  &c->d_sh_dir[0], &c->d_sh_dir[1], &c->d_sh_rad[0], &c->d_sh_rad[1], &c->d_rad[0], &c->d_rad[1],
 					  &c->d_rad_nee[0], &c->d_rad_nee[1], &c->d_acc, &c->d_counters, &c->d_packet_rng, &c->d_jump_table,
 					  &c->d_present};
@@ -1817,6 +1818,7 @@ static int sync_all(rfwhip_context *c);
 // sub-batches double-buffers sets 0 / 1).
 constexpr size_t WAVE_SLOT_BYTES = 2 * 3 * sizeof(f4) + 2 * (sizeof(f4) + 4) + 2 * 3 * sizeof(f4);
 constexpr size_t RAD_SLOT_BYTES = 2 * sizeof(f4);
+constexpr size_t HIT0_DONE_PAD = 512; // bytes beyond one per 64 slots in WaveView::hit0_done: every slice in flight begins on a byte of its own
 constexpr double SHADOW_PACKET_MAX_BINS_PER_RUN = 8.0; // (shadow_packets = -1; measured: DESIGN.md §4 "Round 6")
 static size_t wave_bytes_held(const rfwhip_context *c);
 static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots0, size_t rad_slots1)
@@ -1836,7 +1838,7 @@ static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots
 			 c->d_sh_org[k].ensure_exact(b16) || c->d_sh_dir[k].ensure_exact(b16) || c->d_sh_rad[k].ensure_exact(b16) ||
 			 c->d_rad[k].ensure_exact(rad_slots[k] * sizeof(f4)) || c->d_rad_nee[k].ensure_exact(rad_slots[k] * sizeof(f4));
 	rc = rc || c->d_hit.ensure_exact(b16) || c->d_hit_inst.ensure_exact(paths * 4) || c->d_hit0.ensure_exact(b16) ||
-		 c->d_hit0_inst.ensure_exact(paths * 4);
+		 c->d_hit0_inst.ensure_exact(paths * 4) || c->d_hit0_done.ensure_exact((paths >> 6) + HIT0_DONE_PAD);
 	if (rc)
 		return set_error(RFWHIP_ERR_HIP, "out of device memory for the path state: %zu slots x %zu B + %zu radiance slots x %zu B "
 										 "(%.1f GB; lower spp, or ring / streams)", paths, WAVE_SLOT_BYTES, rad_slots0 + rad_slots1,
@@ -1846,7 +1848,7 @@ static int ensure_wave_buffers(rfwhip_context *c, size_t paths, size_t rad_slots
 }
 static size_t wave_bytes_held(const rfwhip_context *c)
 {
-	size_t n = c->d_hit.cap + c->d_hit_inst.cap + c->d_hit0.cap + c->d_hit0_inst.cap;
+	size_t n = c->d_hit.cap + c->d_hit_inst.cap + c->d_hit0.cap + c->d_hit0_inst.cap + c->d_hit0_done.cap;
 	for (int k = 0; k < 2; k++)
 		n += c->d_org[k].cap + c->d_dir2[k].cap + c->d_thr[k].cap + c->d_sh_org[k].cap + c->d_sh_dir[k].cap + c->d_sh_rad[k].cap +
 			 c->d_rad[k].cap + c->d_rad_nee[k].cap;
@@ -1902,7 +1904,7 @@ static void fill_params(rfwhip_context *c, const rfwhip_camera *cam, rtk::Params
 	for (int k = 0; k < 2; k++)
 		wv.org[k] = c->d_org[k].as<f4>(), wv.dir[k] = c->d_dir2[k].as<f4>(), wv.thr[k] = c->d_thr[k].as<f4>();
 	wv.hit = c->d_hit.as<f4>(), wv.hit_inst = c->d_hit_inst.as<int>();
-	wv.hit0 = c->d_hit0.as<f4>(), wv.hit0_inst = c->d_hit0_inst.as<int>();
+	wv.hit0 = c->d_hit0.as<f4>(), wv.hit0_inst = c->d_hit0_inst.as<int>(), wv.hit0_done = nullptr;
 	wv.sh_org = c->d_sh_org[0].as<f4>(), wv.sh_dir = c->d_sh_dir[0].as<f4>(), wv.sh_rad = c->d_sh_rad[0].as<f4>();
 	wv.rad = c->d_rad[0].as<f4>(), wv.rad_nee = nullptr, wv.acc = c->d_acc.as<f4>();
 	wv.packet_rng = c->d_packet_rng.as<uint32_t>();
@@ -2231,6 +2233,10 @@ extern "C" int rfwhip_render(rfwhip_context *c, const rfwhip_camera *cam, int st
 			for (uint32_t b = rt::SHADOW_BIN_BITS; b >= 1u && !p.fr.shadow_bins; b--) // (as many bin bits as the batch's slots leave room for)
 				if ((unsigned long long)n <= (1ull << rt::shadow_slot_bits(b)))
 					p.fr.shadow_bins = b;
+		// flags of the 64-slot groups the packet form of the primary wave finishes (this slice's own bytes: slices begin anywhere)
+		p.wv.hit0_done = c->integrator == 1 && c->group_flags && rtk::primary_packet_form(p, n) && (size_t)i < HIT0_DONE_PAD / 2
+							 ? c->d_hit0_done.as<unsigned char>() + (off >> 6) + (size_t)i
+							 : nullptr;
 		rtk::launch_init_counters(p.wv.counters, n, s);
 		uint32_t queue = 0; // every traversal launch pulls from its own chunk queue
 		bool conn_now = false;
@@ -2647,7 +2653,7 @@ extern "C" int rfwhip_get_stats(rfwhip_context *c, rfwhip_render_stats *stats)
 	return RFWHIP_OK;
 }
 
-static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "shadow_packets", "shadow_side"};
+static const char *const k_setting_keys[] = {"integrator", "spp", "max_depth", "jitter", "stage_timing", "count_traversal", "lds_nodes", "refill", "streams", "sampler", "builder", "overlap", "sub_batch_paths", "ring", "sample_group", "flat_instances", "flatten_bytes", "fuse", "shadow_packets", "shadow_side", "group_flags"};
 
 extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char *value)
 {
@@ -2721,6 +2727,8 @@ extern "C" int rfwhip_set_setting(rfwhip_context *c, const char *key, const char
 		c->fuse = atoi(value) != 0;
 	else if (k == "shadow_side")
 		c->shadow_side = atoi(value) != 0;
+	else if (k == "group_flags")
+		c->group_flags = atoi(value) != 0;
 	else if (k == "shadow_packets")
 	{
 		const int v = atoi(value);
@@ -2811,6 +2819,8 @@ extern "C" int rfwhip_get_setting(rfwhip_context *c, const char *key, char *valu
 		snprintf(value, cap, "%d", c->shadow_packets);
 	else if (k == "shadow_side")
 		snprintf(value, cap, "%d", c->shadow_side);
+	else if (k == "group_flags")
+		snprintf(value, cap, "%d", c->group_flags);
 	else if (k == "shadow_packets_on") // (read-only: would the next large pt call take the packet form of the depth-0 connection wave?)
 		snprintf(value, cap, "%d", (c->shadow_packets > 0 || (c->shadow_packets < 0 && c->shadow_packets_auto_on)) && c->packet_ok && c->nodes4f_current && (c->refill & 8) ? 1 : 0);
 	else if (k == "shadow_bins_per_run") // (read-only: light bins per sorted run of the last waited frames, see shadow_packets)

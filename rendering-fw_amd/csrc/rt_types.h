@@ -438,6 +438,9 @@ struct WaveView
 	int *hit_inst;
 	f4 *hit0;	 // same, primary wave (kept for read_primary_hits / probe)
 	int *hit0_inst;
+	// one byte per 64-slot group of the primary wave, written by the packet kernel: 1 = every path of the group is finished (all
+	// missed: the sky term is in `rad`), the shade kernel's scan passes the group by without reading its records.  Null: no flags
+	unsigned char *hit0_done;
 	f4 *sh_org;	 // shadow ray origin.xyz, bits(slot)
 	f4 *sh_dir;	 // direction.xyz, tmax
 	f4 *sh_rad;	 // contribution.rgb

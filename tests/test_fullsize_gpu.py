@@ -157,6 +157,36 @@ def test_queue_blocks_and_kernel_forms_do_not_change_the_image(pkg, make_hip, te
     assert np.abs(c.framebuffer() - a.framebuffer()).max() <= 1e-4 * max(1.0, float(a.framebuffer().max()))
 
 
+def test_finished_group_flags_do_not_change_the_image(pkg, make_hip, terrain):
+    """The packet form of the primary wave flags the 64-slot groups it finishes itself (no hit: sky terms written) and the shade
+    kernel's scan passes them by (`group_flags`).  A quarter of the terrain's groups are such.  Same image bit for bit, same ray
+    counts, same primary hits — with sub-batches that begin anywhere in the buffers (streams, a strip rank) as well."""
+    ref = None
+    for settings in (dict(group_flags=0), dict(group_flags=1), dict(group_flags=1, streams=3, sub_batch_paths=5_000_000)):
+        c = _ctx(pkg, make_hip, terrain, spp=16, max_depth=2, **settings)
+        c.render_frame(terrain.camera, pkg.RESET)
+        st = c.get_stats()
+        out = (c.framebuffer().copy(), (st.primaryCount, st.secondaryCount, st.deepCount, st.shadowCount), c.primary_hits())
+        if ref is None:
+            ref = out
+            continue
+        assert np.array_equal(out[0], ref[0]) and out[1] == ref[1], settings
+        for key in ref[2]:
+            assert np.array_equal(out[2][key], ref[2][key]), key
+    # a strip rank: its slices are other rows, its groups other pixels
+    import torch
+    imgs = []
+    for flags in (0, 1):
+        c = _ctx(pkg, make_hip, terrain, rank=3, world=8, spp=16, max_depth=2, group_flags=flags)
+        c.render_frame(terrain.camera, pkg.RESET)
+        local = torch.empty((c.local_rows(), W, 4), dtype=torch.float32, device="cuda:0")
+        c.read_local_framebuffer_device(local.data_ptr())
+        torch.cuda.synchronize()
+        imgs.append(local.cpu().numpy())
+        c.destroy()
+    assert np.array_equal(imgs[0], imgs[1]) and imgs[0].size > 0 and float(imgs[0][..., :3].max()) > 0.0
+
+
 def test_sample_groups_at_full_size(pkg, make_hip, terrain):
     """The slot layout's sample groups (a wave = 64 / g pixels x g samples, rt_core.h) at the bench's own size: 1920 x 1080 x
     32 spp on the 1 M-triangle terrain with g = 1 (a wave = one 8 x 8 tile of one sample), 8 and 32 — the images, the primary
