@@ -665,6 +665,7 @@ def main():
                 source = {"file": None, "own_passes_not_taken_because": pmc_note}
         stages = []
         chip_hbm_bytes_per_step = 0.0 if (pm and fresh) else None
+        chip_valu_ms = 0.0  # per sub-batch: sum over the stages of (VALU-occupied share of the SIMD time x the stage's duration)
         for name in ("primary", "bounce", "shadow", "shade"):
             s_ms = ser[name]
             a_gbs = algo[name] / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None
@@ -705,6 +706,8 @@ def main():
                 pm_ms = k.get("avg_dispatch_us", 0.0) * 1e-3 * n  # the same dispatches under the (serialising) PMC passes
                 if hbm and chip_hbm_bytes_per_step is not None:
                     chip_hbm_bytes_per_step += hbm * n * subs
+                if k.get("valu_busy_frac") is not None:
+                    chip_valu_ms += k["valu_busy_frac"] * pm_ms
                 rate = insts * n / (pm_ms * 1e-3) if (insts and pm_ms > 0) else None
                 ent.update({
                     "counter_hbm_bytes_per_sub_batch": hbm * n if hbm else None,
@@ -866,6 +869,10 @@ def main():
             "chip": {"counter_hbm_bytes_per_step": chip_hbm_bytes_per_step,
                      "counter_hbm_gbs": round(chip_hbm_bytes_per_step / (step_ms * 1e-3) / 1e9, 1) if chip_hbm_bytes_per_step else None,
                      "counter_hbm_frac_of_peak": round(chip_hbm_bytes_per_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chip_hbm_bytes_per_step else None,
+                     # VALU-occupied SIMD time of every stage (its valu_busy_frac x its counter-pass duration: class-weighted instruction
+                     # cycles, profiles/summarize.py) over the pipelined step: how busy the chip's 1024 VALUs are while the step runs
+                     "valu_busy_ms_per_step": round(chip_valu_ms * subs, 2) if chip_valu_ms else None,
+                     "valu_busy_frac_over_step": round(chip_valu_ms * subs / step_ms, 4) if chip_valu_ms else None,
                      "binding_ceiling": "VALU issue: a step is %.1f G wave-instructions of mostly 4-cycle operations on 1024 SIMDs" % (
                          sum((e.get("valu_wave_insts_per_sub_batch") or 0) for e in stages) * subs / 1e9) if (pm and fresh) else None},
             "per_ray": {"inner_nodes": per_step["inner_extend"] / max(1, per_step["rays_extend"]),

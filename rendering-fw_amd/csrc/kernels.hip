@@ -199,17 +199,21 @@ RT_FN void primary_finish_item(const Params &q, uint32_t idx, f3 D, const Hit &h
 		q.wv.rad[idx] = mk4(radiance.x, radiance.y, radiance.z, q.wv.rad_nee ? -1.0f : 1.0f);
 		prim = HIT_MISS_SHADED;
 	}
-	else
-	{
-		if (RT_PRIMARY_RAY_RECORD)
-			q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
-		// a hit's slot starts as what most hits leave there — no radiance, a path that goes on — from here, where the stores of a
-		// wave are neighbours and the memory pipes idle; the shade kernel writes the slot of a path that adds light or ends only
-		if (RT_PRIMARY_INITS_RAD)
-			q.wv.rad[idx] = mk4(0.0f, 0.0f, 0.0f, 1.0f);
-	}
+	else if (RT_PRIMARY_RAY_RECORD)
+		q.wv.dir[0][idx] = mk4(D.x, D.y, D.z, 0.0f);
 	q.wv.hit0[idx] = mk4(h.t, h.u, h.v, ubits((uint32_t)prim));
 	q.wv.hit0_inst[idx] = h.inst;
+	// a hit's slot starts as what most hits leave there — no radiance, a path that goes on — from here, where the stores of a
+	// wave are neighbours and the memory pipes idle; the shade kernel writes the slot of a path that adds light or ends only
+	// (after the hit record's stores: its registers are free then — in front of them the packet kernel spilled four)
+	if (RT_PRIMARY_INITS_RAD && prim >= 0)
+	{
+		float zero = 0.0f, one = 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("" : "+v"(zero), "+v"(one)); // (made here: hoisted out of the packet loop, the constant record was spilled and reloaded per packet)
+#endif
+		q.wv.rad[idx] = mk4(zero, zero, zero, one);
+	}
 }
 
 template <int GEN, bool COUNT>
