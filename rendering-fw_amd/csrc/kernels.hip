@@ -1377,6 +1377,26 @@ struct PacketStack
 		s0 = rt_writelane((int)ec, (int)(sp + na + nb), s0);
 		sp += na + nb + nc;
 	}
+	// the same with the KEYS of the three entries (all ones: not wanted) and the stack pointer in m0: a compare sets SCC, an add
+	// with carry takes it — 7 scalar instructions instead of 12 (round 6, late: the packet kernels are bound by the scalar unit
+	// as much as by the VALUs — one scalar instruction per SIMD every 4.5 clocks, tools/dev/micro/inst_rate5.hip).  One scalar
+	// instruction sits between every write of m0 and the v_writelane that selects its lane with it.
+	__device__ __forceinline__ void push3_keys(uint32_t ea, uint32_t ka, uint32_t eb, uint32_t kb, uint32_t ec, uint32_t kc)
+	{
+		asm volatile("s_mov_b32 m0, %1\n\t"
+					 "s_cmp_lg_u32 %3, -1\n\t"
+					 "v_writelane_b32 %0, %2, m0\n\t"
+					 "s_addc_u32 m0, m0, 0\n\t"
+					 "s_cmp_lg_u32 %5, -1\n\t"
+					 "v_writelane_b32 %0, %4, m0\n\t"
+					 "s_addc_u32 m0, m0, 0\n\t"
+					 "s_cmp_lg_u32 %7, -1\n\t"
+					 "v_writelane_b32 %0, %6, m0\n\t"
+					 "s_addc_u32 %1, m0, 0"
+					 : "+v"(s0), "+s"(sp)
+					 : "s"(ea), "s"(ka), "s"(eb), "s"(kb), "s"(ec), "s"(kc)
+					 : "scc", "m0");
+	}
 };
 
 struct PacketSpace
@@ -1384,10 +1404,12 @@ struct PacketSpace
 	f3 o, d, id, noid;	  // the lane's ray in the current space, 1/d, -o/d
 	const char *row_n[3]; // wave-uniform: the node table offset to the near / far plane row of a Node4f per axis — a row is
 	const char *row_f[3]; // fetched as s_load_dwordx4 dst, row, node_byte_offset with no address arithmetic
-	bool mixed;			  // the lanes disagree about a direction sign on some axis
+	uint32_t mixed;		  // 1: the lanes disagree about a direction sign on some axis (an integer in an SGPR: a wave-uniform bool lives in a lane mask)
 	// t_hit: the lane's hit distance — 1/d and -o/d are NORMALISED by k = norm_k(t_hit) (rt_core.h, RT_NORM_T: the interval a box
 	// must meet becomes [0, 1], which the clamp modifier of v_max3 / v_min3 folds into the slab test)
-	__device__ __forceinline__ void enter(f3 o_, f3 d_, float t_hit, unsigned long long act, const char *nodes)
+	// off: this lane holds no ray and the caller does not mask its ballots — 1/d = -o/d = 0: every slab distance is 0, entry == exit,
+	// and no box is entered (0 < 0)
+	__device__ __forceinline__ void enter(f3 o_, f3 d_, float t_hit, unsigned long long act, const char *nodes, bool off = false)
 	{
 		o = o_, d = d_;
 		id = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
@@ -1396,7 +1418,9 @@ struct PacketSpace
 #endif
 		noid = mk3(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
 		const unsigned long long mx = __ballot(id.x < 0.0f) & act, my = __ballot(id.y < 0.0f) & act, mz = __ballot(id.z < 0.0f) & act;
-		mixed = (mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act);
+		if (off)
+			id = mk3(0, 0, 0), noid = mk3(0, 0, 0);
+		mixed = (uint32_t)__builtin_amdgcn_readfirstlane(((mx != 0ull && mx != act) || (my != 0ull && my != act) || (mz != 0ull && mz != act)) ? 1 : 0);
 		row_n[0] = nodes + (mx ? 48u : 0u), row_f[0] = nodes + (mx ? 0u : 48u);
 		row_n[1] = nodes + (my ? 64u : 16u), row_f[1] = nodes + (my ? 16u : 64u);
 		row_n[2] = nodes + (mz ? 80u : 32u), row_f[2] = nodes + (mz ? 32u : 80u);
@@ -1418,14 +1442,16 @@ template <bool COUNT, bool ANY = false>
 __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool active, const f3 O, const f3 D, const float t_min, Hit &hit, TStat &st)
 {
 	unsigned long long act = __ballot(active);
-	// a lane without a ray never enters a box (its bit of every ballot is masked: `act`) and never takes a hit (t > tt fails)
+	// a lane without a ray never enters a box — closest hit: its ray is degenerate (PacketSpace::enter, `off`), no ballot is masked;
+	// ANY: its bit of every ballot is masked with `act`, which shrinks as lanes find their occluders — and never takes a hit (t > tt fails)
+	const bool off = !ANY && !active;
 	hit.t = active ? hit.t : -3.0e38f;
 	if (act == 0ull)
 		return;
 	int ref_lane = __ffsll((long long)act) - 1;
 	PacketSpace sp;
 	const char *const nodes = (const char *)sc.nodes4f; // (the table stays below 4 GiB: 32-bit byte offsets)
-	sp.enter(O, D, hit.t, act, nodes);
+	sp.enter(O, D, hit.t, act, nodes, off);
 	PacketStack stk;
 	int cur_inst = -1;
 	uint32_t cur = sc.instance_count ? sc.tlas_root_entry : ENTRY_DONE;
@@ -1458,7 +1484,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #if RT_NORM_T
 					tk[k] = max3_clamp01(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y), fmaf(r.nz[k], sp.id.z, sp.noid.z));
 					const float tmax = min3_clamp01(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y), fmaf(r.fz[k], sp.id.z, sp.noid.z));
-					m[k] = __ballot(tk[k] < tmax) & act;
+					m[k] = ANY ? (__ballot(tk[k] < tmax) & act) : __ballot(tk[k] < tmax);
 #else
 					const float tmin = fmaxf(fmaxf(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y)), fmaf(r.nz[k], sp.id.z, sp.noid.z));
 					const float tmax = fminf(fminf(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y)), fmaf(r.fz[k], sp.id.z, sp.noid.z));
@@ -1482,7 +1508,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #if RT_NORM_T
 					tk[k] = max3_clamp01(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
 					const float tmax = min3_clamp01(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
-					m[k] = ent[k] != ENTRY_EMPTY ? (__ballot(tk[k] < tmax) & act) : 0ull;
+					m[k] = ent[k] != ENTRY_EMPTY ? (ANY ? (__ballot(tk[k] < tmax) & act) : __ballot(tk[k] < tmax)) : 0ull;
 #else
 					const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 					const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
@@ -1529,9 +1555,9 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			}
 #undef RT_PSWAP
 			// (three of the five comparators: the nearest entered child first, the others in no particular order — all five measure
-			// the same, 5.18 against 4.93 ms per primary wave.)  The pop below reads what was just written
-			// (1 when the key is not all ones, as integer arithmetic)
-			stk.push3(e3, packet_flag(k3), e2, packet_flag(k2), e1, packet_flag(k1));
+			// the same, 5.18 against 4.93 ms per primary wave; (key, entry) as one 64-bit scalar each and s_cselect_b64: the compiler
+			// splits the selects again.)  The pop below reads what was just written
+			stk.push3_keys(e3, k3, e2, k2, e1, k1);
 			if (k0 == 0xFFFFFFFFu)
 				e0 = stk.pop();
 			cur = e0;
@@ -1540,7 +1566,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			break;
 		if (cur == ENTRY_SENTINEL)
 		{
-			sp.enter(O, D, hit.t, act, nodes); // leaving an instance: back to the world-space ray
+			sp.enter(O, D, hit.t, act, nodes, off); // leaving an instance: back to the world-space ray
 			cur_inst = -1;
 			cur = stk.pop();
 			continue;
@@ -1556,7 +1582,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			stk.push(ENTRY_SENTINEL);
 			const float m0[4] = {r0[0], r0[1], r0[2], r0[3]}, m1[4] = {r1[0], r1[1], r1[2], r1[3]}, m2[4] = {r2[0], r2[1], r2[2], r2[3]};
 			sp.enter(mk3(row_point_r(m0, O), row_point_r(m1, O), row_point_r(m2, O)), mk3(row_dir_r(m0, D), row_dir_r(m1, D), row_dir_r(m2, D)),
-					 hit.t, act, nodes);
+					 hit.t, act, nodes, off);
 			cur_inst = (int)ii;
 			cur = root;
 			continue;
