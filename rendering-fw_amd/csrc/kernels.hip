@@ -1397,6 +1397,23 @@ struct PacketStack
 					 : "s"(ea), "s"(ka), "s"(eb), "s"(kb), "s"(ec), "s"(kc)
 					 : "scc", "m0");
 	}
+	// ... and with the lane MASKS of the three entries (nobody enters: not wanted): the occlusion packets keep no keys
+	__device__ __forceinline__ void push3_masks(uint32_t ea, unsigned long long ma, uint32_t eb, unsigned long long mb, uint32_t ec, unsigned long long mc)
+	{
+		asm volatile("s_mov_b32 m0, %1\n\t"
+					 "s_cmp_lg_u64 %3, 0\n\t"
+					 "v_writelane_b32 %0, %2, m0\n\t"
+					 "s_addc_u32 m0, m0, 0\n\t"
+					 "s_cmp_lg_u64 %5, 0\n\t"
+					 "v_writelane_b32 %0, %4, m0\n\t"
+					 "s_addc_u32 m0, m0, 0\n\t"
+					 "s_cmp_lg_u64 %7, 0\n\t"
+					 "v_writelane_b32 %0, %6, m0\n\t"
+					 "s_addc_u32 %1, m0, 0"
+					 : "+v"(s0), "+s"(sp)
+					 : "s"(ea), "s"(ma), "s"(eb), "s"(mb), "s"(ec), "s"(mc)
+					 : "scc", "m0");
+	}
 };
 
 struct PacketSpace
@@ -1442,9 +1459,9 @@ template <bool COUNT, bool ANY = false>
 __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool active, const f3 O, const f3 D, const float t_min, Hit &hit, TStat &st)
 {
 	unsigned long long act = __ballot(active);
-	// a lane without a ray never enters a box — closest hit: its ray is degenerate (PacketSpace::enter, `off`), no ballot is masked;
-	// ANY: its bit of every ballot is masked with `act`, which shrinks as lanes find their occluders — and never takes a hit (t > tt fails)
-	const bool off = !ANY && !active;
+	// a lane without a ray — or, ANY, one that has found its occluder — never enters a box: its ray is degenerate (PacketSpace::enter,
+	// `off`), no ballot is masked; and it never takes a hit (t > tt fails)
+	bool off = !active;
 	hit.t = active ? hit.t : -3.0e38f;
 	if (act == 0ull)
 		return;
@@ -1484,7 +1501,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #if RT_NORM_T
 					tk[k] = max3_clamp01(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y), fmaf(r.nz[k], sp.id.z, sp.noid.z));
 					const float tmax = min3_clamp01(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y), fmaf(r.fz[k], sp.id.z, sp.noid.z));
-					m[k] = ANY ? (__ballot(tk[k] < tmax) & act) : __ballot(tk[k] < tmax);
+					m[k] = __ballot(tk[k] < tmax);
 #else
 					const float tmin = fmaxf(fmaxf(fmaf(r.nx[k], sp.id.x, sp.noid.x), fmaf(r.ny[k], sp.id.y, sp.noid.y)), fmaf(r.nz[k], sp.id.z, sp.noid.z));
 					const float tmax = fminf(fminf(fmaf(r.fx[k], sp.id.x, sp.noid.x), fmaf(r.fy[k], sp.id.y, sp.noid.y)), fmaf(r.fz[k], sp.id.z, sp.noid.z));
@@ -1508,7 +1525,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 #if RT_NORM_T
 					tk[k] = max3_clamp01(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
 					const float tmax = min3_clamp01(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
-					m[k] = ent[k] != ENTRY_EMPTY ? (ANY ? (__ballot(tk[k] < tmax) & act) : __ballot(tk[k] < tmax)) : 0ull;
+					m[k] = ent[k] != ENTRY_EMPTY ? __ballot(tk[k] < tmax) : 0ull;
 #else
 					const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
 					const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
@@ -1535,10 +1552,9 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			// the nearest child some lane enters comes next, the other entered children go on the stack (scalar unit)
 			// (ANY: an occlusion ray that reaches its light walks every node along it whatever the order, and most do — the children
 			// are taken as they come: no entry distances fetched from the reference lane, no comparators)
-#define RT_ANY_KEY(M) ((uint32_t)__builtin_amdgcn_readfirstlane((int)((M) ? 0u : 0xFFFFFFFFu)))
-			uint32_t k0 = ANY ? RT_ANY_KEY(m[0]) : packet_key(tk[0], m[0], ref_lane), k1 = ANY ? RT_ANY_KEY(m[1]) : packet_key(tk[1], m[1], ref_lane);
-			uint32_t k2 = ANY ? RT_ANY_KEY(m[2]) : packet_key(tk[2], m[2], ref_lane), k3 = ANY ? RT_ANY_KEY(m[3]) : packet_key(tk[3], m[3], ref_lane);
-#undef RT_ANY_KEY
+			uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+			if (!ANY)
+				k0 = packet_key(tk[0], m[0], ref_lane), k1 = packet_key(tk[1], m[1], ref_lane), k2 = packet_key(tk[2], m[2], ref_lane), k3 = packet_key(tk[3], m[3], ref_lane);
 			uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3];
 #define RT_PSWAP(KA, EA, KB, EB)                          \
 	{                                                     \
@@ -1557,8 +1573,11 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 			// (three of the five comparators: the nearest entered child first, the others in no particular order — all five measure
 			// the same, 5.18 against 4.93 ms per primary wave; (key, entry) as one 64-bit scalar each and s_cselect_b64: the compiler
 			// splits the selects again.)  The pop below reads what was just written
-			stk.push3_keys(e3, k3, e2, k2, e1, k1);
-			if (k0 == 0xFFFFFFFFu)
+			if (ANY)
+				stk.push3_masks(e3, m[3], e2, m[2], e1, m[1]);
+			else
+				stk.push3_keys(e3, k3, e2, k2, e1, k1);
+			if (ANY ? m[0] == 0ull : k0 == 0xFFFFFFFFu)
 				e0 = stk.pop();
 			cur = e0;
 		}
@@ -1604,7 +1623,7 @@ __device__ __forceinline__ void trace_packet(const SceneView &sc, const bool act
 					hit.prim = (int)fbits(v0[3]);
 					hit.inst = tri_inst;
 					if (ANY)
-						hit.t = -3.0e38f; // (occluded: this lane takes no further hit ...)
+						hit.t = -3.0e38f, off = true, sp.id = mk3(0, 0, 0), sp.noid = mk3(0, 0, 0); // (occluded: this lane takes no further hit and enters no further box)
 				}
 			}
 			if (ANY)
