@@ -244,7 +244,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 		if (GEN == GEN_PT)
 		{
 			if (active)
-				pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
+				pt_primary_ray(p.cam, p.fr, pr.x, pr.y, p.fr.sample_base + pr.sample, O, D);
 		}
 		else
 		{
@@ -276,7 +276,7 @@ RT_FN void extend_item(const Params &p, uint32_t i, bool active, Ctx &ctx)
 							r3 = r;
 					}
 				}
-				parity_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, r0, r1, r2, r3, O, D);
+				parity_primary_ray(p.cam, p.fr, pr.x, pr.y, r0, r1, r2, r3, O, D);
 			}
 		}
 		if (active)
@@ -411,7 +411,7 @@ template <bool TEX> RT_FN void shade_pt_item(const Params &p, uint32_t i, bool a
 	{
 		// (the primary wave: entry i IS path slot i, and its ray is a function of pixel and sample — regenerated, not read)
 		const PixelRef pr = slot_to_pixel(p.fr, i);
-		pt_primary_ray(p.cam, p.fr.W, p.fr.H, pr.x, pr.y, p.fr.sample_base + pr.sample, in.O, in.D);
+		pt_primary_ray(p.cam, p.fr, pr.x, pr.y, p.fr.sample_base + pr.sample, in.O, in.D);
 		in.slot = i, in.flags = 1u, in.packedN = 0u;
 	}
 	else if (active)
@@ -1702,7 +1702,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, RT_PACKET_WAVES) k_primary_packet
 					active = pr.valid;
 					if (active)
 					{
-						pt_primary_ray(q.cam, q.fr.W, q.fr.H, pr.x, pr.y, q.fr.sample_base + pr.sample, O, D);
+						pt_primary_ray(q.cam, q.fr, pr.x, pr.y, q.fr.sample_base + pr.sample, O, D);
 						if (q.cam.aperture != 0.0f) // (pinhole: no origin record, extend_item)
 							q.wv.org[0][idx] = mk4(O.x, O.y, O.z, ubits((idx << 1) | 1u));
 					}

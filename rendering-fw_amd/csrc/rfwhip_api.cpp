@@ -726,6 +726,7 @@ extern "C" int rfwhip_init(rfwhip_context *c, uint32_t width, uint32_t height)
 	RF_TRY(dm::zero(c->d_acc.p, (size_t)lr * width * sizeof(f4), c->stream));
 	c->samples_done = 0;
 	c->fr.W = width, c->fr.H = height, c->fr.local_rows = lr;
+	c->fr.inv_w = 1.0f / (float)width, c->fr.inv_h = 1.0f / (float)height;
 	c->fr.tiles_x = (width + rt::TILE - 1) / rt::TILE;
 	c->fr.div_tiles_x = rt::make_fastdiv(c->fr.tiles_x);
 	c->fr.slots = c->fr.tiles_x * rt::TILE * lr;

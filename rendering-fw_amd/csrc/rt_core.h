@@ -334,7 +334,7 @@ RT_FN PixelRef slot_to_pixel(const FrameView &fr, uint32_t slot)
 // ---------------------------------------------------------------------------------------------------------------
 // EmbreeRT: u = (x + r0)/W, v = (y + r1)/H, point = p1 + (u*right + v*up), dir = (point - org) * (1/sqrt(len2)) with
 // len2 accumulated x, y, z (Ray.cpp:318-373).  The lens sample follows the scalar form Ray.cpp:16-47.
-RT_FN void parity_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float r0, float r1,
+RT_FN void parity_primary_ray(const CamView &cam, const FrameView &fr, uint32_t x, uint32_t y, float r0, float r1,
 							  float r2, float r3, f3 &O, f3 &D)
 {
 	f3 org = cam.pos;
@@ -350,8 +350,8 @@ RT_FN void parity_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32
 		const float xr = x1 * r2 + x2 * r3, yr = y1 * r2 + y2 * r3;
 		org = cam.pos + (cam.right * xr + cam.up * yr) * cam.aperture;
 	}
-	const float u = ((float)x + r0) * (1.0f / (float)W);
-	const float v = ((float)y + r1) * (1.0f / (float)H);
+	const float u = ((float)x + r0) * fr.inv_w; // (1.0f / (float)W, Ray.cpp:318-373)
+	const float v = ((float)y + r1) * fr.inv_h;
 	const f3 pix = cam.p1 + (cam.right * u + cam.up * v);
 	const f3 d = pix - org;
 	float l2 = d.x * d.x;
@@ -379,10 +379,10 @@ RT_FN float blue_noise_sample(const uint32_t *table, int x, int y, int sampleIdx
 
 // CUDART generatePrimaryRay (Kernels.cu:383-426): r0..r3 from the blue-noise sampler when a table was handed over
 // (what the reference runs), else its hash-RNG branch: seed = WangHash(pixel*16789 + sample*1791), four RandomFloat.
-RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t sampleIdx,
+RT_FN void pt_primary_ray(const CamView &cam, const FrameView &fr, uint32_t x, uint32_t y, uint32_t sampleIdx,
 						  f3 &O, f3 &D)
 {
-	const uint32_t pixel = y * W + x;
+	const uint32_t pixel = y * fr.W + x;
 	float r0, r1, r2, r3;
 	if (cam.blue_noise)
 	{
@@ -412,7 +412,7 @@ RT_FN void pt_primary_ray(const CamView &cam, uint32_t W, uint32_t H, uint32_t x
 		const float xr = fmaf(x2, r3, rounded(x1 * r2)), yr = fmaf(y2, r3, rounded(y1 * r2));
 		O = madd2_r(cam.pos, cam.right, rounded(xr * cam.aperture), cam.up, rounded(yr * cam.aperture));
 	}
-	const float u = rounded(((float)x + r0) * (1.0f / (float)W)), v = rounded(((float)y + r1) * (1.0f / (float)H));
+	const float u = rounded(((float)x + r0) * fr.inv_w), v = rounded(((float)y + r1) * fr.inv_h); // (x (1.0f / (float)W): Kernels.cu:418-419)
 	D = normalize_r(madd2_r(cam.p1, cam.right, u, cam.up, v) - O);
 }
 

@@ -346,6 +346,7 @@ RT_FN uint32_t fast_div(uint32_t n, const FastDiv f)
 struct FrameView
 {
 	uint32_t W, H;		   // full image
+	float inv_w, inv_h;	   // 1.0f / W, 1.0f / H — divided once on the host (correctly rounded, like the v_div sequence every ray generation paid for)
 	uint32_t local_rows;   // padded rows on this rank (multiple of STRIP_ROWS)
 	uint32_t tiles_x;	   // ceil(W / 8)
 	uint32_t slots;		   // tiles_x*8 * local_rows  = path slots per sample
