@@ -173,6 +173,16 @@ def test_finished_group_flags_do_not_change_the_image(pkg, make_hip, terrain):
         assert np.array_equal(out[0], ref[0]) and out[1] == ref[1], settings
         for key in ref[2]:
             assert np.array_equal(out[2][key], ref[2][key]), key
+    # frames in flight: calls enqueued without waiting take turns through the ring of buffer sets — every set has flag bytes of its own
+    acc = []
+    for flags in (0, 1):
+        c = _ctx(pkg, make_hip, terrain, spp=8, max_depth=2, group_flags=flags)
+        for k in range(7):
+            c.render_async(terrain.camera, pkg.RESET if k == 0 else pkg.CONVERGE)
+        c.wait()
+        acc.append(c.framebuffer().copy())
+        c.destroy()
+    assert np.array_equal(acc[0], acc[1])
     # a strip rank: its slices are other rows, its groups other pixels
     import torch
     imgs = []
