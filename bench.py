@@ -657,11 +657,17 @@ def main():
         pm, fresh, source, pmc_note = own_pm, bool(own_pm), own_source, own_note
         if not pm:
             pm, fresh = load_stage_counters(args.stage_json, scene.name, args.spp, args.streams)
+            if pm and world > 1:
+                # the committed counters describe the launches of ONE rank rendering the whole frame; a rank of a strip split launches
+                # 1 / world of that, and no counters were taken for it: the line says so instead of setting them beside its own bytes
+                pm, fresh = None, False
+                source = {"file": None, "own_passes_not_taken_because": "world %d: the committed counters (%s) are a single rank's whole-frame launches" % (
+                    world, os.path.relpath(args.stage_json, ROOT))}
             if pm:
                 source = {"file": os.path.relpath(args.stage_json, ROOT), "taken_by": "an earlier run (tools/evidence.sh), committed",
                           "own_passes_not_taken_because": pmc_note or "--pmc off", "tag": pm.get("tag"), "csrc_hash": pm.get("csrc_hash"),
                           "matches_running_sources": fresh, "valu_busy_validation": pm.get("valu_busy_validation")}
-            elif pmc_note:
+            elif pmc_note and world == 1:
                 source = {"file": None, "own_passes_not_taken_because": pmc_note}
         stages = []
         chip_hbm_bytes_per_step = 0.0 if (pm and fresh) else None
