@@ -197,7 +197,7 @@ def load_stage_counters(path, scene_name, spp, streams):
 
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("lanes", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"]),
-              ("mix", ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"]))
+              ("mix", ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_SALU"]))
 
 
 def collect_stage_counters(args, scene_name, timeout_s=240):
@@ -703,7 +703,9 @@ def main():
                          "avg_dispatch_us": tot("avg_dispatch_us") / launches[name],
                          "valu_lanes_per_instruction": wavg("valu_lanes_per_instruction"), "valu_busy_frac": wavg("valu_busy_frac"),
                          "valu_2_cycle_share": wavg("valu_2_cycle_share"), "valu_slow_pipe_frac": wavg("valu_slow_pipe_frac"),
-                         "valu_issue_frac": wavg("valu_issue_frac"), "valu_transcendental_share": wavg("valu_transcendental_share")}
+                         "valu_issue_frac": wavg("valu_issue_frac"), "valu_transcendental_share": wavg("valu_transcendental_share"),
+                         "sq_insts_salu_per_dispatch": tot("sq_insts_salu_per_dispatch") / launches[name] if tot("sq_insts_salu_per_dispatch") else None,
+                         "salu_busy_frac": wavg("salu_busy_frac")}
                     ent["kernel"] = "%s (depth 0) + %s" % (STAGE_KERNELS["shadow0"], STAGE_KERNELS["shadow"])
             if k:
                 n = launches[name]
@@ -737,6 +739,10 @@ def main():
                     # transcendentals, 2.5 x all VALU instructions) over the SIMD cycles
                     "valu_slow_pipe_frac": k.get("valu_slow_pipe_frac"), "valu_issue_frac": k.get("valu_issue_frac"),
                     "valu_transcendental_share": k.get("valu_transcendental_share"),
+                    # the CU's scalar unit: 4.46 SIMD clocks per scalar instruction (tools/dev/micro/inst_rate5.hip) over the launch's SIMD
+                    # cycles — the packet kernels are bound by it as much as by their VALUs (DESIGN.md §4 "Round 6")
+                    "salu_insts_per_sub_batch": k.get("sq_insts_salu_per_dispatch") * n if k.get("sq_insts_salu_per_dispatch") else None,
+                    "salu_busy_frac": k.get("salu_busy_frac"),
                 })
             else:
                 ent.update({"counter_hbm_bytes_per_sub_batch": None, "valu_wave_insts_per_sub_batch": None, "valu_lanes_active_of_64": None,

@@ -151,6 +151,13 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
                 e["valu_transcendental_share"] = round(mv[2], 4)
                 e["valu_slow_pipe_frac"] = round(mv[3], 4)  # 4.3 clocks per 4-clock-class instruction, 8.6 per transcendental
                 e["valu_issue_frac"] = round(mv[4], 4)      # 2.5 clocks per VALU instruction of any class
+        # the CU's scalar unit: one scalar instruction per CU and clock, i.e. 4.46 clocks of a SIMD's turn each whatever it is
+        # (tools/dev/micro/inst_rate5.hip, round 6): its share of the launch's SIMD cycles — beside valu_busy_frac, the other pipe a
+        # wave-uniform ("packet") kernel can be bound by
+        if per("SQ_INSTS_SALU") is not None:
+            e["sq_insts_salu_per_dispatch"] = int(per("SQ_INSTS_SALU"))
+            if t.get("GRBM_GUI_ACTIVE", 0) > 0:
+                e["salu_busy_frac"] = round(4.46 * t["SQ_INSTS_SALU"] / disp[k]["SQ_INSTS_SALU"] * disp[k]["GRBM_GUI_ACTIVE"] / (t["GRBM_GUI_ACTIVE"] * 32.0 * 4.0), 4)
         if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t and t["SQ_WAVE_CYCLES"] > 0:
             e["wave_cycles_waiting_frac"] = round(t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"], 4)
         out["kernels"][k] = e
@@ -159,7 +166,7 @@ def stages(spp, streams, workload, tag, csrc_hash, *paths):
                          "l2 bytes = TCC_REQ_sum x 128; valu_busy_frac = (2 x (FMA + MUL + ADD_F32) + 8 x TRANS_F32 + 4 x the other VALU instructions) / "
                          "(GRBM_GUI_ACTIVE x 32 CUs x 4 SIMDs): the share of SIMD cycles a VALU instruction occupied, by instruction class "
                          "(valu_busy_validation: the same model on a pure v_fma_f32 kernel); valu_slow_pipe_frac / valu_issue_frac: round 5's non-additive model, "
-                         "max(4.3 x slow + 8.6 x trans, 2.5 x all) / SIMD cycles (tools/dev/micro/inst_rate3.hip); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
+                         "max(4.3 x slow + 8.6 x trans, 2.5 x all) / SIMD cycles (tools/dev/micro/inst_rate3.hip); salu_busy_frac = 4.46 x SQ_INSTS_SALU / SIMD cycles (tools/dev/micro/inst_rate5.hip); csrc_hash = bench.py csrc_hash() of the sources profiled" % tag)
     print(json.dumps(out, indent=1))
 
 
