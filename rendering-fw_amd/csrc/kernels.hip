@@ -5,7 +5,8 @@
 //                 (parity primaries, small pt launches, rfwhip_trace_rays)
 //   shade_parity  EmbreeRT-equivalent direct-lighting integrator (shadow rays traced inline, fixed light order)
 //   shade_pt      path-tracing shade: per-wave hit queues, emits the shadow-ray and extension-ray queues in blocks
-//   connect       any-hit traversal of the shadow queue (k_trace_stream<true> / k_connect), adds unoccluded contributions
+//   connect       any-hit traversal of the shadow queue (k_trace_stream<true> / k_connect; the primary vertices' connections as packets
+//                 sorted by light: k_shadow_packet), adds unoccluded contributions
 //   resolve/present/deinterleave   accumulate the batch, scale by 1/samples, undo the multi-GPU strip interleave
 //   rng_states    xor128 jump-ahead: per-packet generator states for the parity integrator's jitter stream
 //   refit / skin / morph   bottom-up BVH refit after a same-topology set_mesh; vertex posing on the device
@@ -26,7 +27,8 @@
 //   * wave counts come from device-side counters; the host never reads a counter between bounces
 //     (contrast CUDART/src/Context.cpp:98,145).
 // No MFMA: the path is divergent pointer chasing — VALU issue at ~half-full waves and the vector L1's lane-load rate bound
-// the traversal kernels, HBM traffic the shade kernel.
+// the per-lane traversal kernels, VALU issue and the CU's scalar unit (one scalar instruction per CU and clock: 4.5 clocks of a
+// SIMD's turn each, tools/dev/micro/inst_rate5.hip) the packet kernels, HBM traffic the shade kernel.
 #include "kernels.h"
 #include "rt_core.h"
 
